@@ -1,0 +1,105 @@
+/* kocr.h — C-ABI of libkocr.so: the MI355X (gfx950) hot path of
+ * keras_ocr.pipeline.Pipeline.recognize().
+ *
+ * The reference (faustomorales/keras-ocr) is pure Python and has NO FFI; the seams this
+ * library replaces are the two Keras `predict` calls and the OpenCV/shapely host loops
+ * between them.  Every entry point cites the reference interface it replaces
+ * (file:line relative to the reference checkout).
+ *
+ * Conventions
+ *   - every call returns 0 on success, a negative KOCR_E* code on failure;
+ *     kocr_last_error() gives the message of the last failure on that ctx.
+ *   - the caller owns every buffer passed in or out; the library owns weights and
+ *     workspace.  `on_device` != 0 means the pointers are HIP device pointers on the
+ *     ctx's device (e.g. torch.Tensor.data_ptr()); 0 means host pointers (numpy).
+ *   - one ctx per device; calls on a ctx are serialised on its HIP stream and are not
+ *     re-entrant.  Device-pointer calls are asynchronous on that stream unless they
+ *     return host-side counts (documented per call).
+ *   - tensors are dense, row-major, channels-last (NHWC), exactly the layouts the
+ *     reference hands to / receives from Keras.
+ */
+#ifndef KOCR_H
+#define KOCR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kocr_ctx kocr_ctx;
+
+enum {
+  KOCR_OK = 0,
+  KOCR_EINVAL = -1,   /* bad argument (the reference would raise AssertionError/ValueError) */
+  KOCR_EHIP = -2,     /* HIP runtime error */
+  KOCR_ENOWEIGHTS = -3, /* forward called before kocr_load_* */
+  KOCR_ECAPACITY = -4,  /* caller-provided output capacity too small */
+  KOCR_ENOMEM = -5
+};
+
+enum { KOCR_U8 = 0, KOCR_F32 = 1 };
+
+/* ---- context ------------------------------------------------------------------------ */
+int kocr_create(kocr_ctx** out, int hip_device);
+void kocr_destroy(kocr_ctx* ctx);
+const char* kocr_last_error(const kocr_ctx* ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL restores the ctx's own stream. */
+int kocr_set_stream(kocr_ctx* ctx, void* hip_stream);
+int kocr_synchronize(kocr_ctx* ctx);
+/* Device-buffer helpers so a host without torch can still keep data resident. */
+int kocr_device_alloc(kocr_ctx* ctx, void** out, uint64_t bytes);
+int kocr_device_free(kocr_ctx* ctx, void* p);
+int kocr_memcpy_h2d(kocr_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+int kocr_memcpy_d2h(kocr_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+
+/* ---- weights ------------------------------------------------------------------------ */
+/* CRAFT detector weights.  Replaces detection.build_keras_model(weights_path) +
+ * load_torch_weights (detection.py:353-424, 428-468).  `names[i]` are the PyTorch
+ * state-dict keys minus the "module." prefix (the naming load_torch_weights uses,
+ * detection.py:432-461), e.g. "basenet.slice1.0.weight" (OIHW), "...bias",
+ * BN "...weight/bias/running_mean/running_var".  shapes is n x 4 (unused dims = 1). */
+int kocr_load_craft(kocr_ctx* ctx, int n, const char* const* names,
+                    const float* const* data, const int64_t* shapes, const int* ranks);
+/* CRNN recogniser weights.  Replaces recognition.build_model + Recognizer.__init__
+ * load_weights (recognition.py:187-350, 365-404).  Names are Keras layer/variable
+ * names: "conv_1/kernel" (HWIO) "conv_1/bias" ... "conv_7/...", "bn_3|5|7/gamma|beta|
+ * moving_mean|moving_variance", STN localisation net "stn_conv_1/...", "stn_conv_2/...",
+ * "stn_dense_1/kernel|bias", "stn_dense_2/...", "fc_9/...", "lstm_10|lstm_10_back|
+ * lstm_11|lstm_11_back/kernel|recurrent_kernel|bias", "fc_12/kernel|bias". */
+int kocr_load_crnn(kocr_ctx* ctx, int n, const char* const* names,
+                   const float* const* data, const int64_t* shapes, const int* ranks);
+
+/* ---- inner seam #1: detector.model.predict (detection.py:779) ------------------------ */
+/* img: N x H x W x 3.  dtype KOCR_U8 = raw RGB bytes, normalised in the first conv's
+ * loader exactly as detection.compute_input (detection.py:34-42); KOCR_F32 = already
+ * normalised.  heat: N x (H/2) x (W/2) x 2 float32 (ch0 text, ch1 link), linear output
+ * (detection.py:408-413).  micro_batch <= 0 selects the default (Keras predict's
+ * batch_size=32 analogue, detection.py:779). */
+int kocr_craft_forward(kocr_ctx* ctx, const void* img, int dtype, int N, int H, int W,
+                       float* heat, int micro_batch, int on_device);
+
+/* ---- single fused-epilogue convolution (unit-test seam for the MFMA kernel) ---------- */
+/* out = post_a * act(pre_a * conv(in, w) + pre_b) + post_b, NHWC, stride 1, 'same'
+ * padding; w is HWIO (the Keras kernel layout, detection.py:461).  pre_a/pre_b/post_a/
+ * post_b are per-Cout vectors or NULL (identity).  Host pointers only. */
+int kocr_conv2d_nhwc(kocr_ctx* ctx, const float* in, int N, int H, int W, int Cin,
+                     const float* w_hwio, int KH, int KW, int dilation, int Cout,
+                     const float* pre_a, const float* pre_b, int relu,
+                     const float* post_a, const float* post_b, float* out);
+
+/* ---- measurement -------------------------------------------------------------------- */
+/* When enabled, every kernel launch on the ctx is bracketed by hipEvents on the ctx
+ * stream; kocr_profile_report fills parallel arrays (up to cap rows) with per-kernel-name
+ * launch count, total milliseconds and algorithmic FLOPs / bytes.  Returns the number of
+ * rows available. */
+int kocr_profile_enable(kocr_ctx* ctx, int on);
+int kocr_profile_reset(kocr_ctx* ctx);
+int kocr_profile_report(kocr_ctx* ctx, int cap, char* names /* cap x 64 */, int64_t* launches,
+                        double* total_ms, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KOCR_H */

@@ -1,0 +1,195 @@
+"""ctypes binding of libkocr.so (the C-ABI declared in include/kocr.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` /
+``make -C keras-ocr_amd/csrc``.  There is NO CPU fallback: if the library is missing or
+no HIP device is visible, the product fails loudly here.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libkocr.so")
+
+KOCR_U8, KOCR_F32 = 0, 1
+
+_c_float_p = ctypes.POINTER(ctypes.c_float)
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+_c_i64_p = ctypes.POINTER(ctypes.c_int64)
+_c_dbl_p = ctypes.POINTER(ctypes.c_double)
+
+_lib = None
+
+
+class KocrError(RuntimeError):
+    """A libkocr call returned a non-zero code."""
+
+
+def load_library():
+    """Load libkocr.so (once).  Raises ImportError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C keras-ocr_amd/csrc). "
+            "keras-ocr_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    sigs = {
+        "kocr_create": (ci, [ctypes.POINTER(vp), ci]),
+        "kocr_destroy": (None, [vp]),
+        "kocr_last_error": (ctypes.c_char_p, [vp]),
+        "kocr_set_stream": (ci, [vp, vp]),
+        "kocr_synchronize": (ci, [vp]),
+        "kocr_device_alloc": (ci, [vp, ctypes.POINTER(vp), ctypes.c_uint64]),
+        "kocr_device_free": (ci, [vp, vp]),
+        "kocr_memcpy_h2d": (ci, [vp, vp, vp, ctypes.c_uint64]),
+        "kocr_memcpy_d2h": (ci, [vp, vp, vp, ctypes.c_uint64]),
+        "kocr_load_craft": (ci, [vp, ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp), _c_i64_p, _c_int_p]),
+        "kocr_load_crnn": (ci, [vp, ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp), _c_i64_p, _c_int_p]),
+        "kocr_craft_forward": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, ci]),
+        "kocr_conv2d_nhwc": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp]),
+        "kocr_profile_enable": (ci, [vp, ci]),
+        "kocr_profile_reset": (ci, [vp]),
+        "kocr_profile_report": (ci, [vp, ci, ctypes.c_char_p, _c_i64_p, _c_dbl_p, _c_dbl_p, _c_dbl_p]),
+    }
+    for name, (res, args) in sigs.items():
+        if not hasattr(lib, name):
+            continue  # entry points land incrementally; tests check the header against the .so
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    """Host numpy array / device pointer int / None -> c_void_p."""
+    if a is None:
+        return ctypes.c_void_p(0)
+    if isinstance(a, (int, np.integer)):
+        return ctypes.c_void_p(int(a))
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One kocr_ctx: one HIP device, one stream, weights + workspace."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self._lib.kocr_create(ctypes.byref(h), int(device))
+        if rc != 0:
+            raise KocrError(
+                f"kocr_create(device={device}) failed with code {rc}: no usable HIP device. "
+                "keras-ocr_amd runs only on an AMD GPU (gfx950); there is no CPU fallback.")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.kocr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            msg = self._lib.kocr_last_error(self._h).decode("utf-8", "replace")
+            raise KocrError(f"libkocr error {rc}: {msg}")
+        return rc
+
+    # -- plumbing ------------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.kocr_set_stream(self._h, ctypes.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        self._check(self._lib.kocr_synchronize(self._h))
+
+    def _load(self, fn, weights):
+        names = sorted(weights)
+        arrs = [np.ascontiguousarray(weights[k], dtype=np.float32) for k in names]
+        n = len(names)
+        c_names = (ctypes.c_char_p * n)(*[k.encode() for k in names])
+        c_data = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        shapes = np.ones((n, 4), dtype=np.int64)
+        ranks = np.zeros(n, dtype=np.int32)
+        for i, a in enumerate(arrs):
+            if a.ndim > 4:
+                raise ValueError(f"weight {names[i]} has rank {a.ndim} > 4")
+            shapes[i, : a.ndim] = a.shape
+            ranks[i] = a.ndim
+        self._check(fn(self._h, n, c_names, c_data, shapes.ctypes.data_as(_c_i64_p),
+                       ranks.ctypes.data_as(_c_int_p)))
+
+    def load_craft(self, weights):
+        self._load(self._lib.kocr_load_craft, weights)
+
+    def load_crnn(self, weights):
+        self._load(self._lib.kocr_load_crnn, weights)
+
+    # -- inner seam #1 ---------------------------------------------------------------
+    def craft_forward(self, images, micro_batch=0):
+        """images: (N,H,W,3) uint8 (raw RGB) or float32 (normalised) numpy array on the host.
+        Returns (N,H//2,W//2,2) float32."""
+        x = np.ascontiguousarray(images)
+        if x.ndim != 4 or x.shape[3] != 3:
+            raise ValueError("images must have shape (N,H,W,3)")
+        if x.dtype == np.uint8:
+            dt = KOCR_U8
+        else:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            dt = KOCR_F32
+        n, h, w, _ = x.shape
+        out = np.empty((n, h // 2, w // 2, 2), dtype=np.float32)
+        self._check(self._lib.kocr_craft_forward(self._h, _ptr(x), dt, n, h, w, _ptr(out), int(micro_batch), 0))
+        return out
+
+    def craft_forward_device(self, d_img, dtype, n, h, w, d_heat, micro_batch=0):
+        """Device-pointer variant (asynchronous on the ctx stream)."""
+        self._check(self._lib.kocr_craft_forward(self._h, _ptr(d_img), int(dtype), n, h, w, _ptr(d_heat),
+                                                 int(micro_batch), 1))
+
+    def conv2d_nhwc(self, x, w_hwio, dilation=1, pre_a=None, pre_b=None, relu=False, post_a=None, post_b=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        w = np.ascontiguousarray(w_hwio, dtype=np.float32)
+        n, h, wd, cin = x.shape
+        kh, kw, cin2, cout = w.shape
+        assert cin == cin2
+        out = np.empty((n, h, wd, cout), dtype=np.float32)
+        vecs = [None if v is None else np.ascontiguousarray(v, dtype=np.float32) for v in (pre_a, pre_b, post_a, post_b)]
+        self._check(self._lib.kocr_conv2d_nhwc(self._h, _ptr(x), n, h, wd, cin, _ptr(w), kh, kw, int(dilation), cout,
+                                               _ptr(vecs[0]), _ptr(vecs[1]), int(bool(relu)), _ptr(vecs[2]),
+                                               _ptr(vecs[3]), _ptr(out)))
+        return out
+
+    # -- measurement -------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self._lib.kocr_profile_enable(self._h, int(bool(on))))
+
+    def profile_reset(self):
+        self._check(self._lib.kocr_profile_reset(self._h))
+
+    def profile_report(self):
+        cap = 128
+        names = ctypes.create_string_buffer(cap * 64)
+        launches = np.zeros(cap, dtype=np.int64)
+        ms = np.zeros(cap, dtype=np.float64)
+        flops = np.zeros(cap, dtype=np.float64)
+        byts = np.zeros(cap, dtype=np.float64)
+        n = self._check(self._lib.kocr_profile_report(
+            self._h, cap, names, launches.ctypes.data_as(_c_i64_p), ms.ctypes.data_as(_c_dbl_p),
+            flops.ctypes.data_as(_c_dbl_p), byts.ctypes.data_as(_c_dbl_p)))
+        rows = {}
+        for i in range(min(n, cap)):
+            nm = names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode()
+            rows[nm] = {"launches": int(launches[i]), "ms": float(ms[i]), "flops": float(flops[i]),
+                        "bytes": float(byts[i])}
+        return rows

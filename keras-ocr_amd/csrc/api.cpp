@@ -1,0 +1,298 @@
+// api.cpp — the extern "C" surface declared in include/kocr.h (context, memory, profiler,
+// and the entry points that wrap the graphs).  No torch types: plain pointers and sizes.
+#include "common.h"
+#include <algorithm>
+
+// ---------------------------------------------------------------------------------------
+// ctx internals
+// ---------------------------------------------------------------------------------------
+int kocr_ctx::ws_reserve(size_t bytes) {
+  if (bytes <= ws.cap) return KOCR_OK;
+  if (ws.base) {
+    KOCR_HIP(this, hipStreamSynchronize(stream));
+    KOCR_HIP(this, hipFree(ws.base));
+    ws.base = nullptr;
+    ws.cap = 0;
+  }
+  const size_t want = bytes + (bytes >> 3);
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {
+    set_err("workspace hipMalloc(" + std::to_string(want) + " B) failed: " + hipGetErrorString(e));
+    return KOCR_ENOMEM;
+  }
+  ws.base = (char*)p;
+  ws.cap = want;
+  ws.off = 0;
+  return KOCR_OK;
+}
+
+int kocr_ctx::dev_alloc(void** out, size_t bytes) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 4);
+  if (e != hipSuccess) {
+    set_err(std::string("hipMalloc failed: ") + hipGetErrorString(e));
+    return KOCR_ENOMEM;
+  }
+  owned.push_back(p);
+  *out = p;
+  return KOCR_OK;
+}
+
+int kocr_ctx::upload(float** out, const std::vector<float>& host) {
+  void* p = nullptr;
+  KOCR_TRY(dev_alloc(&p, host.size() * sizeof(float)));
+  KOCR_HIP(this, hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = (float*)p;
+  return KOCR_OK;
+}
+
+hipEvent_t kocr_ctx::get_event() {
+  if (!ev_pool.empty()) {
+    hipEvent_t e = ev_pool.back();
+    ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+void kocr_ctx::prof_begin(const char* name, double flops, double bytes) {
+  Pending pd;
+  pd.name = name;
+  pd.a = get_event();
+  pd.b = get_event();
+  hipEventRecord(pd.a, stream);
+  pending.push_back(pd);
+  ProfRow& r = prof[name];
+  r.launches += 1;
+  r.flops += flops;
+  r.bytes += bytes;
+}
+
+void kocr_ctx::prof_end() { hipEventRecord(pending.back().b, stream); }
+
+int kocr_ctx::prof_flush() {
+  if (pending.empty()) return KOCR_OK;
+  KOCR_HIP(this, hipStreamSynchronize(stream));
+  for (Pending& pd : pending) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, pd.a, pd.b);
+    prof[pd.name].ms += ms;
+    ev_pool.push_back(pd.a);
+    ev_pool.push_back(pd.b);
+  }
+  pending.clear();
+  return KOCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int kocr_create(kocr_ctx** out, int hip_device) {
+  if (!out) return KOCR_EINVAL;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || hip_device < 0 || hip_device >= count) return KOCR_EHIP;
+  if (hipSetDevice(hip_device) != hipSuccess) return KOCR_EHIP;
+  kocr_ctx* c = new kocr_ctx();
+  c->device = hip_device;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return KOCR_EHIP;
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return KOCR_OK;
+}
+
+void kocr_destroy(kocr_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  craft_free(ctx);
+  crnn_free(ctx);
+  for (void* p : ctx->owned) hipFree(p);
+  if (ctx->ws.base) hipFree(ctx->ws.base);
+  for (auto& pd : ctx->pending) {
+    hipEventDestroy(pd.a);
+    hipEventDestroy(pd.b);
+  }
+  for (hipEvent_t e : ctx->ev_pool) hipEventDestroy(e);
+  hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+const char* kocr_last_error(const kocr_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int kocr_set_stream(kocr_ctx* ctx, void* hip_stream) {
+  if (!ctx) return KOCR_EINVAL;
+  KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return KOCR_OK;
+}
+
+int kocr_synchronize(kocr_ctx* ctx) {
+  if (!ctx) return KOCR_EINVAL;
+  KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KOCR_OK;
+}
+
+int kocr_device_alloc(kocr_ctx* ctx, void** out, uint64_t bytes) {
+  if (!ctx || !out) return KOCR_EINVAL;
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  KOCR_HIP(ctx, hipMalloc(out, bytes ? bytes : 4));
+  return KOCR_OK;
+}
+
+int kocr_device_free(kocr_ctx* ctx, void* p) {
+  if (!ctx) return KOCR_EINVAL;
+  KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  KOCR_HIP(ctx, hipFree(p));
+  return KOCR_OK;
+}
+
+int kocr_memcpy_h2d(kocr_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+  if (!ctx) return KOCR_EINVAL;
+  KOCR_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KOCR_OK;
+}
+
+int kocr_memcpy_d2h(kocr_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+  if (!ctx) return KOCR_EINVAL;
+  KOCR_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KOCR_OK;
+}
+
+int kocr_load_craft(kocr_ctx* ctx, int n, const char* const* names, const float* const* data,
+                    const int64_t* shapes, const int* ranks) {
+  if (!ctx || n <= 0 || !names || !data || !shapes || !ranks) return KOCR_EINVAL;
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  return craft_load(ctx, n, names, data, shapes, ranks);
+}
+
+int kocr_craft_forward(kocr_ctx* ctx, const void* img, int dtype, int N, int H, int W, float* heat,
+                       int micro_batch, int on_device) {
+  if (!ctx) return KOCR_EINVAL;
+  if (N < 0 || (N > 0 && (!img || !heat))) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_craft_forward: null buffer");
+  if (dtype != KOCR_U8 && dtype != KOCR_F32) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_craft_forward: bad dtype");
+  if (N == 0) return KOCR_OK;
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  int mb = micro_batch > 0 ? micro_batch : 32;  // Keras predict default batch_size (detection.py:779)
+  // keep the per-micro-batch workspace under ~64 GiB of the 288 GB HBM
+  while (mb > 1 && craft_workspace_bytes(mb, H, W) > ((size_t)64 << 30)) mb = (mb + 1) / 2;
+  mb = std::min(mb, N);
+  const size_t esz = dtype == KOCR_U8 ? 1 : 4;
+  const size_t in_img = (size_t)H * W * 3 * esz;
+  const size_t out_img = (size_t)(H / 2) * (W / 2) * 2 * sizeof(float);
+  size_t need = craft_workspace_bytes(mb, H, W);
+  if (!on_device) need += (in_img + out_img) * mb + 1024;
+  KOCR_TRY(ctx->ws_reserve(need));
+  for (int s = 0; s < N; s += mb) {
+    const int nb = std::min(mb, N - s);
+    ctx->ws_reset();
+    const void* d_in;
+    float* d_out;
+    if (on_device) {
+      d_in = (const char*)img + (size_t)s * in_img;
+      d_out = (float*)((char*)heat + (size_t)s * out_img);
+    } else {
+      void* di = ctx->ws_alloc(in_img * nb);
+      void* dout = ctx->ws_alloc(out_img * nb);
+      if (!di || !dout) KOCR_FAIL(ctx, KOCR_ENOMEM, "kocr_craft_forward: workspace exhausted");
+      KOCR_HIP(ctx, hipMemcpyAsync(di, (const char*)img + (size_t)s * in_img, in_img * nb,
+                                   hipMemcpyHostToDevice, ctx->stream));
+      d_in = di;
+      d_out = (float*)dout;
+    }
+    KOCR_TRY(craft_forward(ctx, d_in, dtype, nb, H, W, d_out));
+    if (!on_device) {
+      KOCR_HIP(ctx, hipMemcpyAsync((char*)heat + (size_t)s * out_img, d_out, out_img * nb,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+      KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  }
+  return KOCR_OK;
+}
+
+int kocr_conv2d_nhwc(kocr_ctx* ctx, const float* in, int N, int H, int W, int Cin, const float* w_hwio,
+                     int KH, int KW, int dilation, int Cout, const float* pre_a, const float* pre_b,
+                     int relu, const float* post_a, const float* post_b, float* out) {
+  if (!ctx || !in || !w_hwio || !out) return KOCR_EINVAL;
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || dilation <= 0 ||
+      !(KH & 1) || !(KW & 1))
+    KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_conv2d_nhwc: bad shape (odd kernels, positive sizes)");
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t first_owned = ctx->owned.size();
+  ConvLayer L;
+  L.name = "kocr_conv2d_nhwc";
+  int rc = prepare_conv(ctx, L, w_hwio, /*oihw=*/false, Cin, Cout, KH, KW, dilation, pre_a, pre_b, relu,
+                        post_a, post_b);
+  const size_t nin = (size_t)N * H * W * Cin, nout = (size_t)N * H * W * Cout;
+  if (rc == KOCR_OK) rc = ctx->ws_reserve((nin + nout) * sizeof(float) + 4096);
+  if (rc == KOCR_OK) {
+    ctx->ws_reset();
+    Tensor ti, to;
+    ti.N = to.N = N;
+    ti.H = to.H = H;
+    ti.W = to.W = W;
+    ti.C = ti.cs = Cin;
+    to.C = to.cs = Cout;
+    ti.p = (float*)ctx->ws_alloc(nin * sizeof(float));
+    to.p = (float*)ctx->ws_alloc(nout * sizeof(float));
+    auto run = [&]() -> int {
+      KOCR_HIP(ctx, hipMemcpyAsync(ti.p, in, nin * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+      KOCR_TRY(launch_conv(ctx, L, ti, nullptr, nullptr, to));
+      KOCR_HIP(ctx, hipMemcpyAsync(out, to.p, nout * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+      KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      return KOCR_OK;
+    };
+    rc = run();
+  }
+  // release the temporary layer's device buffers
+  hipStreamSynchronize(ctx->stream);
+  while (ctx->owned.size() > first_owned) {
+    hipFree(ctx->owned.back());
+    ctx->owned.pop_back();
+  }
+  return rc;
+}
+
+int kocr_profile_enable(kocr_ctx* ctx, int on) {
+  if (!ctx) return KOCR_EINVAL;
+  KOCR_TRY(ctx->prof_flush());
+  ctx->prof_on = on != 0;
+  return KOCR_OK;
+}
+
+int kocr_profile_reset(kocr_ctx* ctx) {
+  if (!ctx) return KOCR_EINVAL;
+  KOCR_TRY(ctx->prof_flush());
+  ctx->prof.clear();
+  return KOCR_OK;
+}
+
+int kocr_profile_report(kocr_ctx* ctx, int cap, char* names, int64_t* launches, double* total_ms,
+                        double* flops, double* bytes) {
+  if (!ctx) return KOCR_EINVAL;
+  KOCR_TRY(ctx->prof_flush());
+  int i = 0;
+  for (auto& kv : ctx->prof) {
+    if (i < cap && names && launches && total_ms && flops && bytes) {
+      snprintf(names + (size_t)i * 64, 64, "%s", kv.first.c_str());
+      launches[i] = kv.second.launches;
+      total_ms[i] = kv.second.ms;
+      flops[i] = kv.second.flops;
+      bytes[i] = kv.second.bytes;
+    }
+    ++i;
+  }
+  return i;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+// common.h — internal (non-ABI) declarations shared by the libkocr translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <cstdio>
+#include <cstring>
+#include "../../include/kocr.h"
+
+// ---------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------
+#define KOCR_HIP(ctx, expr)                                                         \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      (ctx)->set_err(std::string(#expr) + ": " + hipGetErrorString(_e) + " at " +   \
+                     __FILE__ + ":" + std::to_string(__LINE__));                    \
+      return KOCR_EHIP;                                                             \
+    }                                                                               \
+  } while (0)
+
+#define KOCR_TRY(expr)            \
+  do {                            \
+    int _rc = (expr);             \
+    if (_rc != KOCR_OK) return _rc; \
+  } while (0)
+
+#define KOCR_FAIL(ctx, code, msg) \
+  do {                            \
+    (ctx)->set_err(msg);          \
+    return (code);                \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------
+// device tensors (NHWC fp32, optionally a channel slice of a wider buffer)
+// ---------------------------------------------------------------------------------------
+struct Tensor {
+  float* p = nullptr;  // base of the (wider) buffer
+  int N = 0, H = 0, W = 0, C = 0;
+  int cs = 0;  // channel stride of the underlying buffer (floats per pixel)
+  int co = 0;  // channel offset of this view inside the buffer
+  size_t pixels() const { return (size_t)N * H * W; }
+  Tensor slice(int off, int c) const {
+    Tensor t = *this;
+    t.co = co + off;
+    t.C = c;
+    return t;
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// a prepared convolution / dense layer
+// ---------------------------------------------------------------------------------------
+struct ConvLayer {
+  std::string name;
+  int Cin = 0, Cout = 0, KH = 1, KW = 1, dil = 1;
+  int Kreal = 0, Kpad = 0, Cout_pad = 0, BN = 0;
+  float* d_w = nullptr;       // [Kpad][Cout_pad], k = (ky*KW + kx)*Cin + c
+  float* d_pre_a = nullptr;   // [Cout_pad]  v = acc*pre_a + pre_b
+  float* d_pre_b = nullptr;
+  float* d_post_a = nullptr;  // [Cout_pad] or nullptr: out = relu?(v)*post_a + post_b
+  float* d_post_b = nullptr;
+  int relu = 0;
+  bool ready() const { return d_w != nullptr; }
+};
+
+// ---------------------------------------------------------------------------------------
+// profiler: per kernel name, HIP-event bracketed launches on the ctx stream
+// ---------------------------------------------------------------------------------------
+struct ProfRow {
+  int64_t launches = 0;
+  double ms = 0, flops = 0, bytes = 0;
+};
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0;
+};
+
+struct CraftNet;
+struct CrnnNet;
+
+struct kocr_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  void set_err(const std::string& s) { err = s; }
+
+  // workspace arena (bump allocated per forward, grown on demand)
+  Arena ws;
+  int ws_reserve(size_t bytes);
+  void ws_reset() { ws.off = 0; }
+  void* ws_alloc(size_t bytes) {
+    size_t a = (ws.off + 255) & ~(size_t)255;
+    if (a + bytes > ws.cap) return nullptr;
+    ws.off = a + bytes;
+    return ws.base + a;
+  }
+
+  // persistent allocations (weights)
+  std::vector<void*> owned;
+  int dev_alloc(void** out, size_t bytes);
+  int upload(float** out, const std::vector<float>& host);
+
+  CraftNet* craft = nullptr;
+  CrnnNet* crnn = nullptr;
+
+  // profiler
+  bool prof_on = false;
+  std::map<std::string, ProfRow> prof;
+  struct Pending {
+    std::string name;
+    hipEvent_t a, b;
+  };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> ev_pool;
+  hipEvent_t get_event();
+  void prof_begin(const char* name, double flops, double bytes);
+  void prof_end();
+  int prof_flush();
+};
+
+// RAII-less helper used around launches
+struct ProfScope {
+  kocr_ctx* c;
+  ProfScope(kocr_ctx* ctx, const char* name, double flops, double bytes) : c(ctx) {
+    if (c->prof_on) c->prof_begin(name, flops, bytes);
+  }
+  ~ProfScope() {
+    if (c->prof_on) c->prof_end();
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// kernels (launchers)
+// ---------------------------------------------------------------------------------------
+// conv_mfma.hip
+int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, int Cin, int Cout,
+                 int KH, int KW, int dil, const float* pre_a, const float* pre_b, int relu,
+                 const float* post_a, const float* post_b);
+// in_u8 != nullptr: first-layer mode, raw RGB bytes + LUT normalisation.
+int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8,
+                const float* lut, const Tensor& out);
+// elementwise.hip
+int launch_maxpool2x2(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
+int launch_maxpool3x3s1(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
+int launch_resize_bilinear(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
+int launch_copy_channels(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
+
+// craft.cpp
+int craft_load(kocr_ctx* ctx, int n, const char* const* names, const float* const* data,
+               const int64_t* shapes, const int* ranks);
+int craft_forward(kocr_ctx* ctx, const void* d_img, int dtype, int N, int H, int W, float* d_heat);
+size_t craft_workspace_bytes(int N, int H, int W);
+void craft_free(kocr_ctx* ctx);
+
+// crnn.cpp
+void crnn_free(kocr_ctx* ctx);

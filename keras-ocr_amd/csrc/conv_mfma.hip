@@ -1,0 +1,346 @@
+// conv_mfma.hip — fp32 implicit-GEMM convolution on the gfx950 matrix cores.
+//
+// Replaces every keras.layers.Conv2D / Dense on the hot path of the reference
+// (CRAFT: detection.py:65-103, 365-410; CRNN: recognition.py:217-327).  One kernel
+// template covers 3x3 (incl. dilation 6), 5x5, 1x1 and dense layers:
+//
+//   GEMM view   M = N*H*W output pixels, N = Cout, K = KH*KW*Cin  (k = (ky*KW+kx)*Cin + c)
+//   A[m][k]     gathered on the fly from the NHWC activation ('same' zero padding)
+//   B[k][n]     weights pre-packed as [Kpad][Cout_pad]
+//   D           v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD), fp32 accumulate
+//   epilogue    out = post_a * relu?(pre_a*acc + pre_b) + post_b   (bias + folded BN)
+//
+// Block = 256 threads = 4 waves; block tile BM x BN, K-step 16; register-staged global
+// loads (float4, 64 B contiguous per pixel) into a double-buffered k-major LDS image so
+// that both MFMA operand reads are conflict-free ds_read_b32 (lane -> consecutive m / n).
+// blockIdx -> tile mapping is XCD-aware: each XCD (private L2) gets a contiguous range of
+// tiles, n-tile fastest, so the A halo and the weight panel are re-read from the same L2.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+  const float* in;
+  const uint8_t* in_u8;
+  const float* lut;  // [3][256] normalisation table for u8 input
+  const float* wgt;
+  float* out;
+  const float* pre_a;
+  const float* pre_b;
+  const float* post_a;
+  const float* post_b;
+  int H, W, Cin, in_cs, in_co;
+  int Cout, Cout_pad, out_cs, out_co;
+  int KH, KW, dil, padh, padw;
+  int relu;
+  int Mtotal;
+  int Kreal, nchunks;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// MODE 0: Cin % 16 == 0, float4 gathers.  MODE 1: generic scalar gather (f32).
+// MODE 2: generic scalar gather from raw u8 RGB through the normalisation LUT.
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
+  constexpr int BK = 16;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int A_PER_T = BM * 4 / 256;
+  constexpr int B_F4 = BK * BN / 4;
+  constexpr int B_PER_T = (B_F4 + 255) / 256;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(TM >= 1 && TN >= 1, "tile");
+
+  __shared__ float As[2][BK][LDA];
+  __shared__ float Bs[2][BK][LDB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, lk = lane >> 5;
+
+  const int nblk_n = p.Cout_pad / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = tile / nblk_n, nt = tile - mt * nblk_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- per-thread gather coordinates (fixed over the K loop) --------------------------
+  const int quad = tid & 3;
+  int a_oy[A_PER_T], a_ox[A_PER_T];
+  long a_pm[A_PER_T];
+#pragma unroll
+  for (int i = 0; i < A_PER_T; ++i) {
+    const int pm = m0 + (tid >> 2) + 64 * i;
+    if (pm < p.Mtotal) {
+      const int ox = pm % p.W;
+      const int t = pm / p.W;
+      a_ox[i] = ox;
+      a_oy[i] = t % p.H;
+      a_pm[i] = pm;
+    } else {
+      a_ox[i] = -(1 << 28);  // every tap falls outside -> zeros
+      a_oy[i] = -(1 << 28);
+      a_pm[i] = 0;
+    }
+  }
+
+  float4 ra[A_PER_T];
+  float4 rb[B_PER_T];
+
+  auto load_chunk = [&](int ch) {
+    if constexpr (MODE == 0) {
+      const int cpt = p.Cin >> 4;  // chunks per tap
+      const int tap = ch / cpt;
+      const int c0 = (ch - tap * cpt) << 4;
+      const int ky = tap / p.KW, kx = tap - ky * p.KW;
+      const int dy = ky * p.dil - p.padh, dx = kx * p.dil - p.padw;
+#pragma unroll
+      for (int i = 0; i < A_PER_T; ++i) {
+        const int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+          const long off = (a_pm[i] + (long)dy * p.W + dx) * p.in_cs + p.in_co + c0 + quad * 4;
+          v = *reinterpret_cast<const float4*>(p.in + off);
+        }
+        ra[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_PER_T; ++i) {
+        float e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = ch * BK + quad * 4 + q;
+          float v = 0.f;
+          if (k < p.Kreal) {
+            const int tap = k / p.Cin;
+            const int c = k - tap * p.Cin;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            const int dy = ky * p.dil - p.padh, dx = kx * p.dil - p.padw;
+            const int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+              const long off = (a_pm[i] + (long)dy * p.W + dx) * p.in_cs + p.in_co + c;
+              if constexpr (MODE == 2)
+                v = p.lut[c * 256 + p.in_u8[off]];
+              else
+                v = p.in[off];
+            }
+          }
+          e[q] = v;
+        }
+        ra[i] = make_float4(e[0], e[1], e[2], e[3]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER_T; ++j) {
+      const int f = tid + 256 * j;
+      if (B_F4 % 256 == 0 || f < B_F4) {
+        const int krow = f / (BN / 4), nc = f - krow * (BN / 4);
+        rb[j] = *reinterpret_cast<const float4*>(p.wgt + (size_t)(ch * BK + krow) * p.Cout_pad + n0 +
+                                                  nc * 4);
+      }
+    }
+  };
+
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      const int m = (tid >> 2) + 64 * i;
+      As[buf][quad * 4 + 0][m] = ra[i].x;
+      As[buf][quad * 4 + 1][m] = ra[i].y;
+      As[buf][quad * 4 + 2][m] = ra[i].z;
+      As[buf][quad * 4 + 3][m] = ra[i].w;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER_T; ++j) {
+      const int f = tid + 256 * j;
+      if (B_F4 % 256 == 0 || f < B_F4) {
+        const int krow = f / (BN / 4), nc = f - krow * (BN / 4);
+        *reinterpret_cast<float4*>(&Bs[buf][krow][nc * 4]) = rb[j];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  const int nch = p.nchunks;
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nch) load_chunk(ch + 1);
+#pragma unroll
+    for (int kp = 0; kp < BK / 2; ++kp) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[buf][2 * kp + lk][wm * WTM + i * 32 + lr];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[buf][2 * kp + lk][wn * WTN + j * 32 + lr];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (ch + 1 < nch) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WTN + j * 32 + lr;
+    if (n >= p.Cout) continue;
+    const float pa = p.pre_a[n], pb = p.pre_b[n];
+    const bool has_post = p.post_a != nullptr;
+    const float qa = has_post ? p.post_a[n] : 1.f;
+    const float qb = has_post ? p.post_b[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int m = m0 + wm * WTM + i * 32 + row;
+        if (m < p.Mtotal) {
+          float v = acc[i][j][r] * pa + pb;
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (has_post) v = v * qa + qb;
+          p.out[(size_t)m * p.out_cs + p.out_co + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+static int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, int Cin, int Cout,
+                 int KH, int KW, int dil, const float* pre_a, const float* pre_b, int relu,
+                 const float* post_a, const float* post_b) {
+  L.Cin = Cin;
+  L.Cout = Cout;
+  L.KH = KH;
+  L.KW = KW;
+  L.dil = dil;
+  L.relu = relu;
+  L.Kreal = KH * KW * Cin;
+  L.Kpad = round_up(L.Kreal, 16);
+  L.BN = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+  L.Cout_pad = round_up(Cout, L.BN);
+  std::vector<float> wp((size_t)L.Kpad * L.Cout_pad, 0.f);
+  for (int ky = 0; ky < KH; ++ky)
+    for (int kx = 0; kx < KW; ++kx)
+      for (int c = 0; c < Cin; ++c)
+        for (int o = 0; o < Cout; ++o) {
+          const float v = w_is_oihw ? w[(((size_t)o * Cin + c) * KH + ky) * KW + kx]
+                                    : w[(((size_t)ky * KW + kx) * Cin + c) * Cout + o];
+          wp[(size_t)((ky * KW + kx) * Cin + c) * L.Cout_pad + o] = v;
+        }
+  KOCR_TRY(ctx->upload(&L.d_w, wp));
+  std::vector<float> a(L.Cout_pad, 1.f), b(L.Cout_pad, 0.f);
+  for (int o = 0; o < Cout; ++o) {
+    if (pre_a) a[o] = pre_a[o];
+    if (pre_b) b[o] = pre_b[o];
+  }
+  KOCR_TRY(ctx->upload(&L.d_pre_a, a));
+  KOCR_TRY(ctx->upload(&L.d_pre_b, b));
+  L.d_post_a = L.d_post_b = nullptr;
+  if (post_a || post_b) {
+    std::vector<float> qa(L.Cout_pad, 1.f), qb(L.Cout_pad, 0.f);
+    for (int o = 0; o < Cout; ++o) {
+      if (post_a) qa[o] = post_a[o];
+      if (post_b) qb[o] = post_b[o];
+    }
+    KOCR_TRY(ctx->upload(&L.d_post_a, qa));
+    KOCR_TRY(ctx->upload(&L.d_post_b, qb));
+  }
+  return KOCR_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+static void dispatch_mode(int mode, dim3 grid, hipStream_t s, const ConvParams& p) {
+  if (mode == 0)
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 0>), grid, dim3(256), 0, s, p);
+  else if (mode == 1)
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), 0, s, p);
+}
+
+int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8,
+                const float* lut, const Tensor& out) {
+  if (!L.ready()) KOCR_FAIL(ctx, KOCR_ENOWEIGHTS, "conv layer " + L.name + " has no weights");
+  if (in.C != L.Cin || out.C != L.Cout || in.N != out.N || in.H != out.H || in.W != out.W)
+    KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": shape mismatch");
+  const size_t M = in.pixels();
+  if (M == 0) return KOCR_OK;
+  if (M > (size_t)0x7fffffff - 512) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": too many pixels");
+  ConvParams p;
+  p.in = in.p;
+  p.in_u8 = in_u8;
+  p.lut = lut;
+  p.wgt = L.d_w;
+  p.out = out.p;
+  p.pre_a = L.d_pre_a;
+  p.pre_b = L.d_pre_b;
+  p.post_a = L.d_post_a;
+  p.post_b = L.d_post_b;
+  p.H = in.H;
+  p.W = in.W;
+  p.Cin = L.Cin;
+  p.in_cs = in.cs;
+  p.in_co = in.co;
+  p.Cout = L.Cout;
+  p.Cout_pad = L.Cout_pad;
+  p.out_cs = out.cs;
+  p.out_co = out.co;
+  p.KH = L.KH;
+  p.KW = L.KW;
+  p.dil = L.dil;
+  p.padh = L.dil * (L.KH - 1) / 2;
+  p.padw = L.dil * (L.KW - 1) / 2;
+  p.relu = L.relu;
+  p.Mtotal = (int)M;
+  p.Kreal = L.Kreal;
+  p.nchunks = L.Kpad / 16;
+  int mode;
+  if (in_u8)
+    mode = 2;
+  else if (L.Cin % 16 == 0 && in.cs % 4 == 0 && in.co % 4 == 0 && ((uintptr_t)in.p & 15) == 0)
+    mode = 0;
+  else
+    mode = 1;
+  const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
+  const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
+  char nm[64];
+  const int BM = (L.BN == 128) ? 128 : 256;
+  snprintf(nm, sizeof nm, "conv_mfma_%dx%d_m%d", BM, L.BN, mode);
+  ProfScope ps(ctx, nm, flops, bytes);
+  const int mtiles = (int)((M + BM - 1) / BM);
+  dim3 grid(mtiles * (L.Cout_pad / L.BN));
+  if (L.BN == 128)
+    dispatch_mode<128, 128, 2, 2>(mode, grid, ctx->stream, p);
+  else if (L.BN == 64)
+    dispatch_mode<256, 64, 4, 1>(mode, grid, ctx->stream, p);
+  else
+    dispatch_mode<256, 32, 4, 1>(mode, grid, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}

@@ -1,0 +1,211 @@
+// elementwise.hip — HBM-bound NHWC helpers of the CRAFT / CRNN graphs.
+//   maxpool 2x2 / stride 2 / 'valid'   keras MaxPooling2D  (detection.py:99-102, recognition.py:227,235)
+//   maxpool 3x3 / stride 1 / 'same'    basenet.slice5.0    (detection.py:365-367), padding ignored (-inf)
+//   bilinear resize, half-pixel centres UpsampleLike        (detection.py:290-303) written straight into
+//                                       the channel slice of the concat buffer it feeds (detection.py:380-389)
+// All kernels move float4 (4 channels) per lane, lanes run along channels then pixels, so a
+// wave touches whole 128-B lines of both the source and the destination.
+#include "common.h"
+
+struct EwParams {
+  const float* in;
+  float* out;
+  int N, Hi, Wi, Ho, Wo, C4;  // C4 = channels / 4
+  int in_cs, in_co, out_cs, out_co;
+  float sy, sx;
+};
+
+__global__ void maxpool2x2_kernel(EwParams p) {
+  const size_t total = (size_t)p.N * p.Ho * p.Wo * p.C4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = i % p.C4;
+    size_t t = i / p.C4;
+    const int ox = t % p.Wo;
+    t /= p.Wo;
+    const int oy = t % p.Ho;
+    const int n = t / p.Ho;
+    const size_t base = (((size_t)n * p.Hi + 2 * oy) * p.Wi + 2 * ox) * p.in_cs + p.in_co + c4 * 4;
+    const float4 a = *reinterpret_cast<const float4*>(p.in + base);
+    const float4 b = *reinterpret_cast<const float4*>(p.in + base + p.in_cs);
+    const float4 c = *reinterpret_cast<const float4*>(p.in + base + (size_t)p.Wi * p.in_cs);
+    const float4 d = *reinterpret_cast<const float4*>(p.in + base + (size_t)p.Wi * p.in_cs + p.in_cs);
+    float4 r;
+    r.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x));
+    r.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+    r.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z));
+    r.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
+    const size_t o = (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.out_cs + p.out_co + c4 * 4;
+    *reinterpret_cast<float4*>(p.out + o) = r;
+  }
+}
+
+__global__ void maxpool3x3s1_kernel(EwParams p) {
+  const size_t total = (size_t)p.N * p.Ho * p.Wo * p.C4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = i % p.C4;
+    size_t t = i / p.C4;
+    const int ox = t % p.Wo;
+    t /= p.Wo;
+    const int oy = t % p.Ho;
+    const int n = t / p.Ho;
+    float4 r = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int iy = oy + dy;
+      if (iy < 0 || iy >= p.Hi) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int ix = ox + dx;
+        if (ix < 0 || ix >= p.Wi) continue;
+        const float4 v = *reinterpret_cast<const float4*>(
+            p.in + (((size_t)n * p.Hi + iy) * p.Wi + ix) * p.in_cs + p.in_co + c4 * 4);
+        r.x = fmaxf(r.x, v.x);
+        r.y = fmaxf(r.y, v.y);
+        r.z = fmaxf(r.z, v.z);
+        r.w = fmaxf(r.w, v.w);
+      }
+    }
+    const size_t o = (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.out_cs + p.out_co + c4 * 4;
+    *reinterpret_cast<float4*>(p.out + o) = r;
+  }
+}
+
+// tf.compat.v1.image.resize_bilinear(half_pixel_centers=True): src = (dst+0.5)*(in/out)-0.5,
+// lower = max(floor(src),0), upper = min(ceil(src), in-1), lerp = src - floor(src);
+// top = tl + (tr-tl)*xl; bottom = bl + (br-bl)*xl; out = top + (bottom-top)*yl.
+__global__ void resize_bilinear_kernel(EwParams p) {
+  const size_t total = (size_t)p.N * p.Ho * p.Wo * p.C4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = i % p.C4;
+    size_t t = i / p.C4;
+    const int ox = t % p.Wo;
+    t /= p.Wo;
+    const int oy = t % p.Ho;
+    const int n = t / p.Ho;
+    const float fy = ((float)oy + 0.5f) * p.sy - 0.5f;
+    const float fx = ((float)ox + 0.5f) * p.sx - 0.5f;
+    const float fly = floorf(fy), flx = floorf(fx);
+    const int y0 = max((int)fly, 0), y1 = min((int)ceilf(fy), p.Hi - 1);
+    const int x0 = max((int)flx, 0), x1 = min((int)ceilf(fx), p.Wi - 1);
+    const float yl = fy - fly, xl = fx - flx;
+    const size_t rb = (size_t)n * p.Hi;
+    const float* b0 = p.in + ((rb + y0) * p.Wi) * p.in_cs + p.in_co + c4 * 4;
+    const float* b1 = p.in + ((rb + y1) * p.Wi) * p.in_cs + p.in_co + c4 * 4;
+    const float4 tl = *reinterpret_cast<const float4*>(b0 + (size_t)x0 * p.in_cs);
+    const float4 tr = *reinterpret_cast<const float4*>(b0 + (size_t)x1 * p.in_cs);
+    const float4 bl = *reinterpret_cast<const float4*>(b1 + (size_t)x0 * p.in_cs);
+    const float4 br = *reinterpret_cast<const float4*>(b1 + (size_t)x1 * p.in_cs);
+    float4 r;
+    {
+      const float top = tl.x + (tr.x - tl.x) * xl, bot = bl.x + (br.x - bl.x) * xl;
+      r.x = top + (bot - top) * yl;
+    }
+    {
+      const float top = tl.y + (tr.y - tl.y) * xl, bot = bl.y + (br.y - bl.y) * xl;
+      r.y = top + (bot - top) * yl;
+    }
+    {
+      const float top = tl.z + (tr.z - tl.z) * xl, bot = bl.z + (br.z - bl.z) * xl;
+      r.z = top + (bot - top) * yl;
+    }
+    {
+      const float top = tl.w + (tr.w - tl.w) * xl, bot = bl.w + (br.w - bl.w) * xl;
+      r.w = top + (bot - top) * yl;
+    }
+    const size_t o = (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.out_cs + p.out_co + c4 * 4;
+    *reinterpret_cast<float4*>(p.out + o) = r;
+  }
+}
+
+__global__ void copy_channels_kernel(EwParams p) {
+  const size_t total = (size_t)p.N * p.Ho * p.Wo * p.C4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = i % p.C4;
+    const size_t px = i / p.C4;
+    *reinterpret_cast<float4*>(p.out + px * p.out_cs + p.out_co + c4 * 4) =
+        *reinterpret_cast<const float4*>(p.in + px * p.in_cs + p.in_co + c4 * 4);
+  }
+}
+
+static int check_vec(kocr_ctx* ctx, const Tensor& in, const Tensor& out, const char* what) {
+  if (in.C != out.C || in.N != out.N) KOCR_FAIL(ctx, KOCR_EINVAL, std::string(what) + ": shape mismatch");
+  if (in.C % 4 || in.cs % 4 || in.co % 4 || out.cs % 4 || out.co % 4)
+    KOCR_FAIL(ctx, KOCR_EINVAL, std::string(what) + ": channels must be multiples of 4");
+  return KOCR_OK;
+}
+
+static EwParams make_params(const Tensor& in, const Tensor& out) {
+  EwParams p;
+  p.in = in.p;
+  p.out = out.p;
+  p.N = in.N;
+  p.Hi = in.H;
+  p.Wi = in.W;
+  p.Ho = out.H;
+  p.Wo = out.W;
+  p.C4 = in.C / 4;
+  p.in_cs = in.cs;
+  p.in_co = in.co;
+  p.out_cs = out.cs;
+  p.out_co = out.co;
+  p.sy = p.sx = 1.f;
+  return p;
+}
+
+static dim3 ew_grid(size_t total) {
+  size_t b = (total + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b == 0) b = 1;
+  return dim3((unsigned)b);
+}
+
+int launch_maxpool2x2(kocr_ctx* ctx, const Tensor& in, const Tensor& out) {
+  KOCR_TRY(check_vec(ctx, in, out, "maxpool2x2"));
+  if (out.H != in.H / 2 || out.W != in.W / 2) KOCR_FAIL(ctx, KOCR_EINVAL, "maxpool2x2: bad output size");
+  EwParams p = make_params(in, out);
+  const size_t total = out.pixels() * p.C4;
+  if (!total) return KOCR_OK;
+  ProfScope ps(ctx, "maxpool2x2", 0, 4.0 * (in.pixels() + out.pixels()) * in.C);
+  hipLaunchKernelGGL(maxpool2x2_kernel, ew_grid(total), dim3(256), 0, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
+int launch_maxpool3x3s1(kocr_ctx* ctx, const Tensor& in, const Tensor& out) {
+  KOCR_TRY(check_vec(ctx, in, out, "maxpool3x3s1"));
+  if (out.H != in.H || out.W != in.W) KOCR_FAIL(ctx, KOCR_EINVAL, "maxpool3x3s1: bad output size");
+  EwParams p = make_params(in, out);
+  const size_t total = out.pixels() * p.C4;
+  if (!total) return KOCR_OK;
+  ProfScope ps(ctx, "maxpool3x3s1", 0, 4.0 * (in.pixels() + out.pixels()) * in.C);
+  hipLaunchKernelGGL(maxpool3x3s1_kernel, ew_grid(total), dim3(256), 0, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
+int launch_resize_bilinear(kocr_ctx* ctx, const Tensor& in, const Tensor& out) {
+  KOCR_TRY(check_vec(ctx, in, out, "resize_bilinear"));
+  EwParams p = make_params(in, out);
+  p.sy = (float)in.H / (float)out.H;
+  p.sx = (float)in.W / (float)out.W;
+  const size_t total = out.pixels() * p.C4;
+  if (!total) return KOCR_OK;
+  ProfScope ps(ctx, "resize_bilinear", 0, 4.0 * (in.pixels() + out.pixels()) * in.C);
+  hipLaunchKernelGGL(resize_bilinear_kernel, ew_grid(total), dim3(256), 0, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
+int launch_copy_channels(kocr_ctx* ctx, const Tensor& in, const Tensor& out) {
+  KOCR_TRY(check_vec(ctx, in, out, "copy_channels"));
+  if (out.H != in.H || out.W != in.W) KOCR_FAIL(ctx, KOCR_EINVAL, "copy_channels: bad output size");
+  EwParams p = make_params(in, out);
+  const size_t total = out.pixels() * p.C4;
+  if (!total) return KOCR_OK;
+  ProfScope ps(ctx, "copy_channels", 0, 8.0 * out.pixels() * in.C);
+  hipLaunchKernelGGL(copy_channels_kernel, ew_grid(total), dim3(256), 0, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}

@@ -1,0 +1,75 @@
+"""Parity of the MFMA implicit-GEMM convolution (csrc/conv_mfma.hip) against a plain
+PyTorch fp32 reference of the same op (floating-point kernel -> torch fp32 reference).
+
+Tolerance: both sides accumulate in fp32 in different orders; |err| <= 2e-5 * sqrt(K) *
+max|out| is far above fp32 round-off for these sizes and far below the heat-map tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # N, H, W, Cin, Cout, k, dil
+    (1, 16, 16, 16, 32, 3, 1),
+    (2, 17, 23, 64, 64, 3, 1),     # ragged pixel count, 256x64 tile
+    (1, 24, 40, 128, 256, 3, 1),   # 128x128 tile, 2 n-tiles
+    (2, 9, 11, 32, 16, 3, 1),      # Cout < 32
+    (1, 20, 12, 16, 2, 1, 1),      # conv_cls.8 shape class
+    (1, 14, 14, 512, 1024, 3, 6),  # dilated slice5.1 class (reduced spatial)
+    (1, 12, 12, 1536, 512, 1, 1),  # upconv1.conv.0 class
+    (3, 13, 10, 3, 64, 3, 1),      # Cin = 3 scalar gather
+    (2, 31, 20, 1, 64, 3, 1),      # Cin = 1 (CRNN conv_1 class)
+    (1, 50, 7, 512, 16, 5, 1),     # STN localisation conv (5x5)
+    (4, 1, 1, 11200, 64, 1, 1),    # dense as 1x1 conv
+    (1, 50, 1, 256, 37, 1, 1),     # fc_12 class (Cout = 37)
+]
+
+
+def _ref(x, w, dil, pre_a, pre_b, relu, post_a, post_b):
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    wt = torch.from_numpy(w).permute(3, 2, 0, 1)  # HWIO -> OIHW
+    kh, kw = w.shape[:2]
+    y = F.conv2d(xt, wt, None, padding=(dil * (kh - 1) // 2, dil * (kw - 1) // 2), dilation=dil)
+    y = y * torch.from_numpy(pre_a).view(1, -1, 1, 1) + torch.from_numpy(pre_b).view(1, -1, 1, 1)
+    if relu:
+        y = F.relu(y)
+    if post_a is not None:
+        y = y * torch.from_numpy(post_a).view(1, -1, 1, 1) + torch.from_numpy(post_b).view(1, -1, 1, 1)
+    return y.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+@pytest.mark.parametrize("variant", ["bias_relu", "relu_then_bn", "linear"])
+def test_conv_matches_torch(ctx, case, variant):
+    n, h, w, cin, cout, k, dil = case
+    rng = np.random.default_rng(hash((case, variant)) % (2 ** 32))
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = (rng.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32)
+    pre_a = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    pre_b = rng.uniform(-0.3, 0.3, cout).astype(np.float32)
+    post_a = post_b = None
+    relu = variant != "linear"
+    if variant == "relu_then_bn":  # CRNN bn_3/5/7 placement (recognition.py:226-242)
+        post_a = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        post_b = rng.uniform(-0.3, 0.3, cout).astype(np.float32)
+    got = ctx.conv2d_nhwc(x, wt, dilation=dil, pre_a=pre_a, pre_b=pre_b, relu=relu, post_a=post_a, post_b=post_b)
+    want = _ref(x, wt, dil, pre_a, pre_b, relu, post_a, post_b)
+    tol = 2e-5 * np.sqrt(cin * k * k) * max(1.0, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max())
+    assert got.shape == want.shape
+    assert err <= tol, f"max abs err {err} > {tol}"
+
+
+def test_conv_transpose_detecting(ctx):
+    """A = identity-like probe with an ASYMMETRIC weight matrix: catches a swapped C/D map."""
+    cin, cout = 32, 64
+    x = np.zeros((1, 8, 8, cin), np.float32)
+    for c in range(cin):
+        x[0, c // 8, c % 8, c] = 1.0
+    w = (np.arange(cin * cout, dtype=np.float32).reshape(1, 1, cin, cout) + 1) / 100.0
+    got = ctx.conv2d_nhwc(x, w)
+    want = np.einsum("nhwc,co->nhwo", x, w[0, 0])
+    assert np.array_equal(got, want)

@@ -1,0 +1,61 @@
+"""CRAFT forward on the GPU (HIP path, through the C-ABI) vs the CPU oracle.
+
+Tolerance (stated, fp32): max |heat_gpu - heat_oracle| <= 2e-4 — the reference's own
+cross-framework bar is decimal=4, i.e. 1.5e-4 (tests/test_pytorch_keras.py:49) on
+real weights; seeded weights keep activations O(1) so the same scale applies.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HEAT_TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def craft_ctx(ctx, craft_weights):
+    ctx.load_craft(craft_weights)
+    return ctx
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 96, 80), (1, 50, 70), (3, 32, 48)])
+def test_heatmap_f32_input(craft_ctx, craft_weights, shape):
+    from oracle import craft as ocraft
+
+    n, h, w = shape
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((n, h, w, 3), dtype=np.float32)
+    got = craft_ctx.craft_forward(x)
+    want = ocraft.craft_forward(craft_weights, x)
+    assert got.shape == want.shape == (n, h // 2, w // 2, 2)
+    err = float(np.abs(got - want).max())
+    assert err <= HEAT_TOL, f"max abs heat-map error {err}"
+
+
+def test_heatmap_u8_input_fused_normalisation(craft_ctx, craft_weights):
+    """uint8 input: compute_input (detection.py:34-42) fused into the first conv's loader."""
+    from oracle import craft as ocraft
+
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (2, 64, 96, 3), dtype=np.uint8)
+    got = craft_ctx.craft_forward(img)
+    want = ocraft.detector_predict(craft_weights, img)
+    err = float(np.abs(got - want).max())
+    assert err <= HEAT_TOL, f"max abs heat-map error {err}"
+
+
+def test_micro_batching_is_invisible(craft_ctx):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (5, 32, 32, 3), dtype=np.uint8)
+    a = craft_ctx.craft_forward(img, micro_batch=2)
+    b = craft_ctx.craft_forward(img, micro_batch=5)
+    assert np.array_equal(a, b)
+
+
+def test_forward_before_load_fails_loudly():
+    import keras_ocr_amd
+
+    c = keras_ocr_amd.Context(0)
+    with pytest.raises(keras_ocr_amd.KocrError):
+        c.craft_forward(np.zeros((1, 32, 32, 3), np.uint8))
+    c.close()

@@ -35,7 +35,9 @@ enum {
   KOCR_EHIP = -2,     /* HIP runtime error */
   KOCR_ENOWEIGHTS = -3, /* forward called before kocr_load_* */
   KOCR_ECAPACITY = -4,  /* caller-provided output capacity too small */
-  KOCR_ENOMEM = -5
+  KOCR_ENOMEM = -5,
+  KOCR_EEMPTYCONTOUR = -6, /* reference: IndexError at detection.py:272 */
+  KOCR_EZERODIV = -7       /* reference: ZeroDivisionError at tools.py:95 */
 };
 
 enum { KOCR_U8 = 0, KOCR_F32 = 1 };
@@ -79,6 +81,29 @@ int kocr_load_crnn(kocr_ctx* ctx, int n, const char* const* names,
  * batch_size=32 analogue, detection.py:779). */
 int kocr_craft_forward(kocr_ctx* ctx, const void* img, int dtype, int N, int H, int W,
                        float* heat, int micro_batch, int on_device);
+
+/* ---- detection.getBoxes (detection.py:207-287) ---------------------------------------- */
+/* heat: N x h x w x 2 float32.  Thresholds as Detector.detect's keyword arguments
+ * (detection.py:748-751).  boxes: N x cap x 4 x 2 float32, corner order and x2 scaling as the
+ * reference (clockwise from the min(x+y) corner, or l,t,r,b for near-square boxes); counts:
+ * HOST int32[N] (the call synchronises).  Box order inside an image = connected-component
+ * label order of cv2.connectedComponentsWithStats (raster order of the first pixel).
+ * KOCR_ECAPACITY if an image has more than cap boxes (counts still hold the true numbers);
+ * KOCR_EEMPTYCONTOUR where the reference would raise IndexError (a component whose
+ * segmentation map is empty after removing text AND link pixels, detection.py:246, 272). */
+int kocr_get_boxes(kocr_ctx* ctx, const float* heat, int N, int h, int w, float detection_threshold,
+                   float text_threshold, float link_threshold, int size_threshold, float* boxes,
+                   int32_t* counts, int cap, int on_device);
+
+/* ---- crops: recognize_from_boxes' cvtColor + tools.warpBox loop (recognition.py:506-526,
+ * tools.py:61-117) ---------------------------------------------------------------------- */
+/* img_rgb: N x H x W x 3 uint8 (device if on_device).  boxes: HOST float32 [M][4][2], the
+ * images' boxes concatenated in image order; counts: HOST int32[N], sum = M.  crops:
+ * M x target_h x target_w float32 = gray/255, zero outside the warped region (device if
+ * on_device).  KOCR_EZERODIV where the reference raises ZeroDivisionError (box with integer
+ * width or height 0, tools.py:95). */
+int kocr_warp_crops(kocr_ctx* ctx, const uint8_t* img_rgb, int N, int H, int W, const float* boxes,
+                    const int32_t* counts, int target_h, int target_w, float* crops, int on_device);
 
 /* ---- single fused-epilogue convolution (unit-test seam for the MFMA kernel) ---------- */
 /* out = post_a * act(pre_a * conv(in, w) + pre_b) + post_b, NHWC, stride 1, 'same'

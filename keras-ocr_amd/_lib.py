@@ -51,6 +51,8 @@ def load_library():
         "kocr_load_craft": (ci, [vp, ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp), _c_i64_p, _c_int_p]),
         "kocr_load_crnn": (ci, [vp, ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp), _c_i64_p, _c_int_p]),
         "kocr_craft_forward": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, ci]),
+        "kocr_get_boxes": (ci, [vp, vp, ci, ci, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, vp, vp, ci, ci]),
+        "kocr_warp_crops": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, ci, vp, ci]),
         "kocr_conv2d_nhwc": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp]),
         "kocr_profile_enable": (ci, [vp, ci]),
         "kocr_profile_reset": (ci, [vp]),
@@ -156,6 +158,52 @@ class Context:
         """Device-pointer variant (asynchronous on the ctx stream)."""
         self._check(self._lib.kocr_craft_forward(self._h, _ptr(d_img), int(dtype), n, h, w, _ptr(d_heat),
                                                  int(micro_batch), 1))
+
+    # -- detection.getBoxes ----------------------------------------------------------------
+    def get_boxes(self, heat, detection_threshold=0.7, text_threshold=0.4, link_threshold=0.4,
+                  size_threshold=10, cap=None):
+        """heat: (N,h,w,2) float32 host array -> list of (n_i,4,2) float32 arrays
+        (``np.array([])`` for an image without boxes, detection.py:286)."""
+        y = np.ascontiguousarray(heat, dtype=np.float32)
+        if y.ndim != 4 or y.shape[3] != 2:
+            raise ValueError("heat must have shape (N,h,w,2)")
+        n, h, w, _ = y.shape
+        cap = int(cap) if cap else 1024
+        while True:
+            boxes = np.zeros((n, cap, 4, 2), dtype=np.float32)
+            counts = np.zeros(n, dtype=np.int32)
+            rc = self._lib.kocr_get_boxes(self._h, _ptr(y), n, h, w, float(detection_threshold),
+                                          float(text_threshold), float(link_threshold), int(size_threshold),
+                                          _ptr(boxes), _ptr(counts), cap, 0)
+            if rc == -4 and n and counts.max() > cap:  # KOCR_ECAPACITY: retry with the true maximum
+                cap = int(counts.max())
+                continue
+            if rc == -6:
+                raise IndexError("list index out of range")  # detection.py:272 on an empty contour list
+            self._check(rc)
+            break
+        return [boxes[i, :counts[i]].copy() if counts[i] else np.array([]) for i in range(n)]
+
+    # -- crops --------------------------------------------------------------------------------
+    def warp_crops(self, images, box_groups, target_height=31, target_width=200):
+        """images: (N,H,W,3) uint8; box_groups: list of (n_i,4,2).  Returns (M,th,tw) float32."""
+        x = np.ascontiguousarray(images, dtype=np.uint8)
+        n, h, w, c = x.shape
+        if c != 3:
+            raise ValueError("images must be RGB")
+        counts = np.array([len(b) for b in box_groups], dtype=np.int32)
+        m = int(counts.sum())
+        out = np.zeros((m, target_height, target_width), dtype=np.float32)
+        if m == 0:
+            return out
+        flat = np.ascontiguousarray(
+            np.concatenate([np.asarray(b, dtype=np.float32).reshape(-1, 4, 2) for b in box_groups if len(b)]))
+        rc = self._lib.kocr_warp_crops(self._h, _ptr(x), n, h, w, _ptr(flat), _ptr(counts), int(target_height),
+                                       int(target_width), _ptr(out), 0)
+        if rc == -7:
+            raise ZeroDivisionError("division by zero")  # tools.py:95
+        self._check(rc)
+        return out
 
     def conv2d_nhwc(self, x, w_hwio, dilation=1, pre_a=None, pre_b=None, relu=False, post_a=None, post_b=None):
         x = np.ascontiguousarray(x, dtype=np.float32)

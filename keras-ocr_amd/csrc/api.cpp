@@ -6,26 +6,28 @@
 // ---------------------------------------------------------------------------------------
 // ctx internals
 // ---------------------------------------------------------------------------------------
-int kocr_ctx::ws_reserve(size_t bytes) {
-  if (bytes <= ws.cap) return KOCR_OK;
-  if (ws.base) {
-    KOCR_HIP(this, hipStreamSynchronize(stream));
-    KOCR_HIP(this, hipFree(ws.base));
-    ws.base = nullptr;
-    ws.cap = 0;
+int arena_reserve(kocr_ctx* ctx, Arena& a, size_t bytes) {
+  if (bytes <= a.cap) return KOCR_OK;
+  if (a.base) {
+    KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    KOCR_HIP(ctx, hipFree(a.base));
+    a.base = nullptr;
+    a.cap = 0;
   }
-  const size_t want = bytes + (bytes >> 3);
+  const size_t want = bytes + (bytes >> 3) + 4096;
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, want);
   if (e != hipSuccess) {
-    set_err("workspace hipMalloc(" + std::to_string(want) + " B) failed: " + hipGetErrorString(e));
+    ctx->set_err("workspace hipMalloc(" + std::to_string(want) + " B) failed: " + hipGetErrorString(e));
     return KOCR_ENOMEM;
   }
-  ws.base = (char*)p;
-  ws.cap = want;
-  ws.off = 0;
+  a.base = (char*)p;
+  a.cap = want;
+  a.off = 0;
   return KOCR_OK;
 }
+
+int kocr_ctx::ws_reserve(size_t bytes) { return arena_reserve(this, ws, bytes); }
 
 int kocr_ctx::dev_alloc(void** out, size_t bytes) {
   void* p = nullptr;
@@ -116,7 +118,8 @@ void kocr_destroy(kocr_ctx* ctx) {
   craft_free(ctx);
   crnn_free(ctx);
   for (void* p : ctx->owned) hipFree(p);
-  if (ctx->ws.base) hipFree(ctx->ws.base);
+  for (Arena* a : {&ctx->ws, &ctx->pp, &ctx->pp2, &ctx->io})
+    if (a->base) hipFree(a->base);
   for (auto& pd : ctx->pending) {
     hipEventDestroy(pd.a);
     hipEventDestroy(pd.b);
@@ -217,6 +220,83 @@ int kocr_craft_forward(kocr_ctx* ctx, const void* img, int dtype, int N, int H, 
       KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
   }
+  return KOCR_OK;
+}
+
+int kocr_get_boxes(kocr_ctx* ctx, const float* heat, int N, int h, int w, float detection_threshold,
+                   float text_threshold, float link_threshold, int size_threshold, float* boxes,
+                   int32_t* counts, int cap, int on_device) {
+  if (!ctx) return KOCR_EINVAL;
+  if (N < 0 || (N > 0 && (!heat || !boxes || !counts))) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_get_boxes: null buffer");
+  if (N == 0) return KOCR_OK;
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t hb = (size_t)N * h * w * 2 * sizeof(float), bb = (size_t)N * cap * 8 * sizeof(float);
+  const float* d_heat = heat;
+  float* d_boxes = boxes;
+  if (!on_device) {
+    KOCR_TRY(arena_reserve(ctx, ctx->io, hb + bb + 1024));
+    ctx->io.off = 0;
+    float* dh = (float*)arena_alloc(ctx->io, hb);
+    d_boxes = (float*)arena_alloc(ctx->io, bb);
+    KOCR_HIP(ctx, hipMemcpyAsync(dh, heat, hb, hipMemcpyHostToDevice, ctx->stream));
+    d_heat = dh;
+  }
+  int n_empty = 0;
+  const int rc = postproc_get_boxes(ctx, d_heat, N, h, w, detection_threshold, text_threshold, link_threshold,
+                                    size_threshold, d_boxes, cap, counts, &n_empty);
+  if (rc != KOCR_OK) return rc;
+  if (!on_device) {
+    KOCR_HIP(ctx, hipMemcpyAsync(boxes, d_boxes, bb, hipMemcpyDeviceToHost, ctx->stream));
+    KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (n_empty > 0)
+    KOCR_FAIL(ctx, KOCR_EEMPTYCONTOUR,
+              "kocr_get_boxes: a component has no pixels left after removing text&link overlap "
+              "(the reference raises IndexError at detection.py:272)");
+  return KOCR_OK;
+}
+
+int kocr_warp_crops(kocr_ctx* ctx, const uint8_t* img_rgb, int N, int H, int W, const float* boxes,
+                    const int32_t* counts, int target_h, int target_w, float* crops, int on_device) {
+  if (!ctx) return KOCR_EINVAL;
+  if (N < 0 || target_h <= 0 || target_w <= 0 || (N > 0 && (!img_rgb || !counts)))
+    KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_warp_crops: bad argument");
+  long M = 0;
+  for (int i = 0; i < N; ++i) {
+    if (counts[i] < 0) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_warp_crops: negative count");
+    M += counts[i];
+  }
+  if (M == 0) return KOCR_OK;
+  if (!boxes || !crops) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_warp_crops: null buffer");
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<WarpParam> prm((size_t)M);
+  long m = 0;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < counts[i]; ++j, ++m) {
+      const int rc = warp_prepare(boxes + m * 8, target_h, target_w, &prm[m], nullptr);
+      if (rc == 1)
+        KOCR_FAIL(ctx, KOCR_EZERODIV, "kocr_warp_crops: box with zero width or height (ZeroDivisionError at tools.py:95)");
+      if (rc != 0) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_warp_crops: singular perspective transform");
+      prm[m].img = i;
+    }
+  const size_t ib = (size_t)N * H * W * 3, cb = (size_t)M * target_h * target_w * sizeof(float);
+  const size_t pb = (size_t)M * sizeof(WarpParam);
+  KOCR_TRY(arena_reserve(ctx, ctx->io, pb + (on_device ? 0 : ib + cb) + 2048));
+  ctx->io.off = 0;
+  WarpParam* d_prm = (WarpParam*)arena_alloc(ctx->io, pb);
+  KOCR_HIP(ctx, hipMemcpyAsync(d_prm, prm.data(), pb, hipMemcpyHostToDevice, ctx->stream));
+  const uint8_t* d_img = img_rgb;
+  float* d_crops = crops;
+  if (!on_device) {
+    uint8_t* di = (uint8_t*)arena_alloc(ctx->io, ib);
+    d_crops = (float*)arena_alloc(ctx->io, cb);
+    KOCR_HIP(ctx, hipMemcpyAsync(di, img_rgb, ib, hipMemcpyHostToDevice, ctx->stream));
+    d_img = di;
+  }
+  KOCR_TRY(launch_warp(ctx, d_img, H, W, d_prm, (int)M, target_h, target_w, d_crops));
+  if (!on_device) KOCR_HIP(ctx, hipMemcpyAsync(crops, d_crops, cb, hipMemcpyDeviceToHost, ctx->stream));
+  // prm is host memory about to go out of scope: the H2D copy must have completed
+  KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return KOCR_OK;
 }
 

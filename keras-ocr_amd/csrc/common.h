@@ -90,16 +90,12 @@ struct kocr_ctx {
   std::string err;
   void set_err(const std::string& s) { err = s; }
 
-  // workspace arena (bump allocated per forward, grown on demand)
-  Arena ws;
+  // workspace arenas (bump allocated per call, grown on demand): ws = network activations,
+  // pp = post-processing per-pixel scratch, pp2 = post-processing canvases, io = staging
+  Arena ws, pp, pp2, io;
   int ws_reserve(size_t bytes);
   void ws_reset() { ws.off = 0; }
-  void* ws_alloc(size_t bytes) {
-    size_t a = (ws.off + 255) & ~(size_t)255;
-    if (a + bytes > ws.cap) return nullptr;
-    ws.off = a + bytes;
-    return ws.base + a;
-  }
+  void* ws_alloc(size_t bytes);
 
   // persistent allocations (weights)
   std::vector<void*> owned;
@@ -123,6 +119,15 @@ struct kocr_ctx {
   void prof_end();
   int prof_flush();
 };
+
+int arena_reserve(kocr_ctx* ctx, Arena& a, size_t bytes);
+inline void* arena_alloc(Arena& a, size_t bytes) {
+  const size_t o = (a.off + 255) & ~(size_t)255;
+  if (o + bytes > a.cap) return nullptr;
+  a.off = o + bytes;
+  return a.base + o;
+}
+inline void* kocr_ctx::ws_alloc(size_t bytes) { return arena_alloc(ws, bytes); }
 
 // RAII-less helper used around launches
 struct ProfScope {
@@ -160,3 +165,19 @@ void craft_free(kocr_ctx* ctx);
 
 // crnn.cpp
 void crnn_free(kocr_ctx* ctx);
+
+// postproc.hip
+int postproc_get_boxes(kocr_ctx* ctx, const float* d_heat, int N, int h, int w, float det_thr,
+                       float text_thr, float link_thr, int size_thr, float* d_boxes, int cap,
+                       int* h_counts, int* n_empty_out);
+
+// warp.hip
+struct WarpParam {
+  double mi[9];  // inverse homography (crop px -> image px)
+  int img;       // image index
+  int cw, ch;    // crop size (<= target); outside -> 0
+  int pad;
+};
+int warp_prepare(const float* box, int target_h, int target_w, WarpParam* out, float* ordered_box);
+int launch_warp(kocr_ctx* ctx, const uint8_t* d_img, int H, int W, const WarpParam* d_prm, int M, int th,
+                int tw, float* d_crops);

@@ -105,6 +105,17 @@ int kocr_get_boxes(kocr_ctx* ctx, const float* heat, int N, int h, int w, float 
 int kocr_warp_crops(kocr_ctx* ctx, const uint8_t* img_rgb, int N, int H, int W, const float* boxes,
                     const int32_t* counts, int target_h, int target_w, float* crops, int on_device);
 
+/* ---- inner seam #2: recognizer.prediction_model.predict (recognition.py:535) ------------ */
+/* crops: M x 31 x 200 float32 in [0,1] (the (M,31,200,1) array recognize_from_boxes builds,
+ * recognition.py:524-526).  labels: M x 48 int32, the CTCDecoder output: greedy decode,
+ * repeats merged, blank (= n_classes-1) removed, -1 padded (recognition.py:169-184).
+ * probs (may be NULL): M x 48 x n_classes float32 = recognizer.model.predict, the softmax
+ * after dropping the first 2 steps (recognition.py:322-328). */
+int kocr_crnn_forward(kocr_ctx* ctx, const float* crops, int M, int32_t* labels, float* probs,
+                      int on_device);
+/* len(alphabet) + 1 of the loaded recogniser (recognition.py:323), 0 if none is loaded. */
+int kocr_crnn_classes(kocr_ctx* ctx);
+
 /* ---- single fused-epilogue convolution (unit-test seam for the MFMA kernel) ---------- */
 /* out = post_a * act(pre_a * conv(in, w) + pre_b) + post_b, NHWC, stride 1, 'same'
  * padding; w is HWIO (the Keras kernel layout, detection.py:461).  pre_a/pre_b/post_a/

@@ -51,6 +51,8 @@ def load_library():
         "kocr_load_craft": (ci, [vp, ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp), _c_i64_p, _c_int_p]),
         "kocr_load_crnn": (ci, [vp, ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(vp), _c_i64_p, _c_int_p]),
         "kocr_craft_forward": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, ci]),
+        "kocr_crnn_forward": (ci, [vp, vp, ci, vp, vp, ci]),
+        "kocr_crnn_classes": (ci, [vp]),
         "kocr_get_boxes": (ci, [vp, vp, ci, ci, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, vp, vp, ci, ci]),
         "kocr_warp_crops": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, ci, vp, ci]),
         "kocr_conv2d_nhwc": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp]),
@@ -158,6 +160,28 @@ class Context:
         """Device-pointer variant (asynchronous on the ctx stream)."""
         self._check(self._lib.kocr_craft_forward(self._h, _ptr(d_img), int(dtype), n, h, w, _ptr(d_heat),
                                                  int(micro_batch), 1))
+
+    # -- inner seam #2 ---------------------------------------------------------------
+    def crnn_classes(self):
+        return self._check(self._lib.kocr_crnn_classes(self._h))
+
+    def crnn_forward(self, crops, return_probs=False):
+        """crops: (M,31,200[,1]) float32 in [0,1].  Returns labels (M,48) int32 (-1 padded)
+        [, probs (M,48,n_classes)]."""
+        x = np.ascontiguousarray(crops, dtype=np.float32)
+        if x.ndim == 4 and x.shape[-1] == 1:
+            x = x[..., 0]
+        if x.ndim != 3 or x.shape[1:] != (31, 200):
+            raise ValueError("crops must have shape (M,31,200[,1])")
+        m = x.shape[0]
+        c = self.crnn_classes()
+        labels = np.full((m, 48), -1, dtype=np.int32)
+        probs = np.zeros((m, 48, c), dtype=np.float32) if return_probs else None
+        self._check(self._lib.kocr_crnn_forward(self._h, _ptr(x), m, _ptr(labels), _ptr(probs), 0))
+        return (labels, probs) if return_probs else labels
+
+    def crnn_forward_device(self, d_crops, m, d_labels, d_probs=None):
+        self._check(self._lib.kocr_crnn_forward(self._h, _ptr(d_crops), int(m), _ptr(d_labels), _ptr(d_probs), 1))
 
     # -- detection.getBoxes ----------------------------------------------------------------
     def get_boxes(self, heat, detection_threshold=0.7, text_threshold=0.4, link_threshold=0.4,

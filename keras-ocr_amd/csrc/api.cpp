@@ -223,6 +223,50 @@ int kocr_craft_forward(kocr_ctx* ctx, const void* img, int dtype, int N, int H, 
   return KOCR_OK;
 }
 
+int kocr_load_crnn(kocr_ctx* ctx, int n, const char* const* names, const float* const* data,
+                   const int64_t* shapes, const int* ranks) {
+  if (!ctx || n <= 0 || !names || !data || !shapes || !ranks) return KOCR_EINVAL;
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  return crnn_load(ctx, n, names, data, shapes, ranks);
+}
+
+int kocr_crnn_classes(kocr_ctx* ctx) { return ctx ? crnn_classes(ctx) : KOCR_EINVAL; }
+
+int kocr_crnn_forward(kocr_ctx* ctx, const float* crops, int M, int32_t* labels, float* probs, int on_device) {
+  if (!ctx) return KOCR_EINVAL;
+  if (M < 0 || (M > 0 && (!crops || !labels))) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_crnn_forward: null buffer");
+  const int C = crnn_classes(ctx);
+  if (C == 0) KOCR_FAIL(ctx, KOCR_ENOWEIGHTS, "kocr_crnn_forward: call kocr_load_crnn first");
+  if (M == 0) return KOCR_OK;
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  const int mb = std::min(M, 1024);
+  const size_t cb = (size_t)31 * 200 * sizeof(float), lb = 48 * sizeof(int32_t), pb = (size_t)48 * C * sizeof(float);
+  KOCR_TRY(ctx->ws_reserve(crnn_workspace_bytes(mb, C) + (on_device ? 0 : (cb + lb + pb) * mb + 2048)));
+  for (int s = 0; s < M; s += mb) {
+    const int nb = std::min(mb, M - s);
+    ctx->ws_reset();
+    const float* d_c = crops + (size_t)s * 31 * 200;
+    int32_t* d_l = labels + (size_t)s * 48;
+    float* d_p = probs ? probs + (size_t)s * 48 * C : nullptr;
+    if (!on_device) {
+      float* dc = (float*)ctx->ws_alloc(cb * nb);
+      d_l = (int32_t*)ctx->ws_alloc(lb * nb);
+      d_p = probs ? (float*)ctx->ws_alloc(pb * nb) : nullptr;
+      if (!dc || !d_l || (probs && !d_p)) KOCR_FAIL(ctx, KOCR_ENOMEM, "kocr_crnn_forward: workspace exhausted");
+      KOCR_HIP(ctx, hipMemcpyAsync(dc, d_c, cb * nb, hipMemcpyHostToDevice, ctx->stream));
+      d_c = dc;
+    }
+    KOCR_TRY(crnn_forward(ctx, d_c, nb, d_l, d_p));
+    if (!on_device) {
+      KOCR_HIP(ctx, hipMemcpyAsync(labels + (size_t)s * 48, d_l, lb * nb, hipMemcpyDeviceToHost, ctx->stream));
+      if (probs)
+        KOCR_HIP(ctx, hipMemcpyAsync(probs + (size_t)s * 48 * C, d_p, pb * nb, hipMemcpyDeviceToHost, ctx->stream));
+      KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  }
+  return KOCR_OK;
+}
+
 int kocr_get_boxes(kocr_ctx* ctx, const float* heat, int N, int h, int w, float detection_threshold,
                    float text_threshold, float link_threshold, int size_threshold, float* boxes,
                    int32_t* counts, int cap, int on_device) {

@@ -165,6 +165,11 @@ void craft_free(kocr_ctx* ctx);
 
 // crnn.cpp
 void crnn_free(kocr_ctx* ctx);
+int crnn_load(kocr_ctx* ctx, int n, const char* const* names, const float* const* data, const int64_t* shapes,
+              const int* ranks);
+int crnn_classes(kocr_ctx* ctx);
+size_t crnn_workspace_bytes(int M, int n_classes);
+int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, float* d_probs);
 
 // postproc.hip
 int postproc_get_boxes(kocr_ctx* ctx, const float* d_heat, int N, int h, int w, float det_thr,

@@ -1,0 +1,196 @@
+// crnn_kernels.hip — the non-GEMM kernels of the CRNN recogniser (recognition.py:187-333).
+//
+//   crnn_input_kernel   Permute((2,1,3)) + flip axis 2 (recognition.py:215-216)
+//   stn_sample_kernel   _transform bilinear sampler (recognition.py:73-166)
+//   lstm_kernel         keras LSTM recurrence on the matrix cores (recognition.py:292-319):
+//                       one workgroup = 32 crops x one direction for all 50 steps; h lives in LDS,
+//                       c in registers, h@U is 32x512x128 per step on v_mfma_f32_32x32x2_f32 with the
+//                       four gates of a hidden unit in the same lane (so the cell update is
+//                       register-only); x@W+b is precomputed by the conv/GEMM kernel.
+//   ctc_kernel          fc_12 softmax + CTCDecoder (recognition.py:169-184, 322-328): one wave per
+//                       crop, lanes = classes, per-step argmax as a wavefront reduction, repeat
+//                       merge + blank removal by lane 0.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// in: [M][Hc=31][Wc=200] -> out: [M][Wc][Hc] with out[m][w][j] = in[m][Hc-1-j][w]
+__global__ void crnn_input_kernel(const float* __restrict__ in, float* __restrict__ out, int M, int Hc, int Wc) {
+  const size_t total = (size_t)M * Hc * Wc;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i % Hc;
+    const size_t t = i / Hc;
+    const int w = t % Wc;
+    const size_t m = t / Wc;
+    out[i] = in[(m * Hc + (Hc - 1 - j)) * Wc + w];
+  }
+}
+
+// x: [M][H][W][C], theta: [M][6] -> out [M][H][W][C]
+__global__ void stn_sample_kernel(const float* __restrict__ x, const float* __restrict__ theta, float* __restrict__ out,
+                                  int M, int H, int W, int C) {
+  const int pix = blockIdx.x;  // m*H*W + oy*W + ox
+  const int ox = pix % W;
+  const int oy = (pix / W) % H;
+  const int m = pix / (W * H);
+  const float* th = theta + (size_t)m * 6;
+  // tf.linspace(-1, 1, n): start + i*delta, last element exactly 1
+  const float xt = (ox == W - 1) ? 1.f : -1.f + (float)ox * (2.f / (float)(W - 1));
+  const float yt = (oy == H - 1) ? 1.f : -1.f + (float)oy * (2.f / (float)(H - 1));
+  const float xs = (th[0] * xt + th[1] * yt) + th[2];
+  const float ys = (th[3] * xt + th[4] * yt) + th[5];
+  const float fx = 0.5f * (xs + 1.0f) * (float)W;   // scaled by W, not W-1 (recognition.py:109)
+  const float fy = 0.5f * (ys + 1.0f) * (float)H;
+  int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+  int x1 = x0 + 1, y1 = y0 + 1;
+  x0 = min(max(x0, 0), W - 1);
+  x1 = min(max(x1, 0), W - 1);
+  y0 = min(max(y0, 0), H - 1);
+  y1 = min(max(y1, 0), H - 1);
+  // weights from the CLIPPED corners (recognition.py:144-152)
+  const float wa = ((float)x1 - fx) * ((float)y1 - fy);
+  const float wb = ((float)x1 - fx) * (fy - (float)y0);
+  const float wc = (fx - (float)x0) * ((float)y1 - fy);
+  const float wd = (fx - (float)x0) * (fy - (float)y0);
+  const float* base = x + (size_t)m * H * W * C;
+  const float* pa = base + ((size_t)y0 * W + x0) * C;
+  const float* pb = base + ((size_t)y1 * W + x0) * C;
+  const float* pc = base + ((size_t)y0 * W + x1) * C;
+  const float* pd = base + ((size_t)y1 * W + x1) * C;
+  float* o = out + (size_t)pix * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) o[c] = ((wa * pa[c] + wb * pb[c]) + wc * pc[c]) + wd * pd[c];
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+// xp: [M][T][2*4*U] (dir-major, gate order i,f,c,o); Uf/Ub: [U][4U]; out: [M][T][2U] in PROCESSING order
+template <int UNITS>
+__global__ __launch_bounds__(256) void lstm_kernel(const float* __restrict__ xp, const float* __restrict__ Uf,
+                                                   const float* __restrict__ Ub, float* __restrict__ out, int M,
+                                                   int T) {
+  static_assert(UNITS == 128, "4 waves x 32 hidden units");
+  constexpr int LD = UNITS + 1;
+  __shared__ float hs[32][LD];
+  const int dir = blockIdx.y;
+  const int m0 = blockIdx.x * 32;
+  const float* Ur = dir ? Ub : Uf;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lk = lane >> 5;
+  const int j = wave * 32 + lr;  // hidden unit of this lane
+  for (int i = tid; i < 32 * LD; i += 256) (&hs[0][0])[i] = 0.f;
+  float c[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const int tin = dir ? (T - 1 - t) : t;
+    f32x16 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        acc[g][r] = m < M ? xp[((size_t)m * T + tin) * (8 * UNITS) + dir * 4 * UNITS + g * UNITS + j] : 0.f;
+      }
+#pragma unroll 4
+    for (int kp = 0; kp < UNITS / 2; ++kp) {
+      const int k = 2 * kp + lk;
+      const float a = hs[lr][k];
+      const float* ur = Ur + (size_t)k * (4 * UNITS) + j;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ur[g * UNITS], acc[g], 0, 0, 0);
+    }
+    __syncthreads();  // every wave has finished reading h(t-1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+      const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]);
+      const float gg = tanhf(acc[2][r]), og = sigmoidf_(acc[3][r]);
+      c[r] = fg * c[r] + ig * gg;
+      const float h = og * tanhf(c[r]);
+      hs[row][j] = h;
+      const int m = m0 + row;
+      if (m < M) out[((size_t)m * T + t) * (2 * UNITS) + dir * UNITS + j] = h;
+    }
+    __syncthreads();
+  }
+}
+
+// logits: [M][T][C] (C <= 64); labels: [M][T-discard] (-1 padded); probs (nullable): [M][T-discard][C]
+__global__ void ctc_kernel(const float* __restrict__ logits, int M, int T, int C, int discard, int* __restrict__ labels,
+                           float* __restrict__ probs) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int To = T - discard;
+  const int blank = C - 1;
+  int prev = -1, k = 0;
+  for (int t = 0; t < To; ++t) {
+    const float* row = logits + ((size_t)m * T + t + discard) * C;
+    const float v = lane < C ? row[lane] : -INFINITY;
+    // argmax with lowest index on ties: reduce (value, index) pairs
+    float bv = v;
+    int bi = lane < C ? lane : 0x7fffffff;
+    for (int o = 32; o; o >>= 1) {
+      const float ov = __shfl_xor(bv, o);
+      const int oi = __shfl_xor(bi, o);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (probs) {
+      const float e = lane < C ? expf(v - bv) : 0.f;
+      float s = e;
+      for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+      if (lane < C) probs[((size_t)m * To + t) * C + lane] = e / s;
+    }
+    if (lane == 0) {
+      if (bi != prev && bi != blank) labels[(size_t)m * To + k++] = bi;
+      prev = bi;
+    }
+  }
+  if (lane == 0)
+    for (; k < To; ++k) labels[(size_t)m * To + k] = -1;
+}
+
+int launch_crnn_input(kocr_ctx* ctx, const float* d_crops, float* d_x, int M, int Hc, int Wc) {
+  const size_t total = (size_t)M * Hc * Wc;
+  if (!total) return KOCR_OK;
+  ProfScope ps(ctx, "crnn_input", 0, 8.0 * total);
+  size_t b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(crnn_input_kernel, dim3((unsigned)b), dim3(256), 0, ctx->stream, d_crops, d_x, M, Hc, Wc);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
+int launch_stn_sample(kocr_ctx* ctx, const Tensor& x, const float* d_theta, const Tensor& out) {
+  if (x.cs != x.C || out.cs != out.C || x.co || out.co) KOCR_FAIL(ctx, KOCR_EINVAL, "stn: dense tensors only");
+  const size_t pix = x.pixels();
+  if (!pix) return KOCR_OK;
+  ProfScope ps(ctx, "stn_sample", 0, 4.0 * pix * x.C * 5);
+  hipLaunchKernelGGL(stn_sample_kernel, dim3((unsigned)pix), dim3(128), 0, ctx->stream, x.p, d_theta, out.p, x.N,
+                     x.H, x.W, x.C);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
+int launch_lstm(kocr_ctx* ctx, const float* d_xp, const float* d_Uf, const float* d_Ub, float* d_out, int M, int T) {
+  if (M <= 0) return KOCR_OK;
+  ProfScope ps(ctx, "lstm_recurrence", 2.0 * 2 * M * (double)T * 128 * 512, 0);
+  hipLaunchKernelGGL(lstm_kernel<128>, dim3((M + 31) / 32, 2), dim3(256), 0, ctx->stream, d_xp, d_Uf, d_Ub, d_out, M, T);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
+int launch_ctc(kocr_ctx* ctx, const float* d_logits, int M, int T, int C, int discard, int* d_labels, float* d_probs) {
+  if (M <= 0) return KOCR_OK;
+  if (C > 64) KOCR_FAIL(ctx, KOCR_EINVAL, "ctc: alphabet larger than 63 symbols is not supported by the wave decoder");
+  ProfScope ps(ctx, "ctc_greedy", 0, 4.0 * M * T * C);
+  hipLaunchKernelGGL(ctc_kernel, dim3((M + 3) / 4), dim3(256), 0, ctx->stream, d_logits, M, T, C, discard, d_labels,
+                     d_probs);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}

@@ -64,3 +64,58 @@ def synthetic_craft_weights(seed=1234):
     # keep the linear 2-channel output at heat-map scale (O(1), like the real [0,1] maps)
     w["conv_cls.8.weight"] *= np.float32(0.1)
     return w
+
+
+# ---------------------------------------------------------------------------------------
+# CRNN (recognition.py:13-23, 187-333)
+# ---------------------------------------------------------------------------------------
+CRNN_FILTERS = (64, 128, 256, 256, 512, 512, 512)
+CRNN_FLOPS_PER_CROP = 13.444e9
+
+
+def synthetic_crnn_weights(seed=4321, n_classes=37):
+    """Keras variable naming (conv kernels HWIO, dense [in,out], LSTM [in,4u] gate order i,f,c,o).
+    The STN's last Dense is initialised near a 0.9x zoom (identity-like, as trained STNs are) so
+    the sampler reads mostly inside the feature map."""
+    rng = np.random.default_rng(seed)
+    w = {}
+
+    def conv(name, k, cin, cout):
+        w[name + "/kernel"] = rng.normal(0, np.sqrt(2.0 / (k * k * cin)), (k, k, cin, cout)).astype(np.float32)
+        w[name + "/bias"] = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+
+    def dense(name, cin, cout, gain=2.0):
+        w[name + "/kernel"] = rng.normal(0, np.sqrt(gain / cin), (cin, cout)).astype(np.float32)
+        w[name + "/bias"] = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+
+    def bn(name, c):
+        w[name + "/gamma"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+        w[name + "/beta"] = rng.uniform(-0.1, 0.1, c).astype(np.float32)
+        w[name + "/moving_mean"] = rng.normal(0, 0.1, c).astype(np.float32)
+        w[name + "/moving_variance"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+
+    def lstm(name, cin, units):
+        # x3 gain: keeps the gates away from their linear regime so decoded strings are diverse
+        w[name + "/kernel"] = rng.normal(0, 3.0 / np.sqrt(cin), (cin, 4 * units)).astype(np.float32)
+        w[name + "/recurrent_kernel"] = rng.normal(0, 1.0 / np.sqrt(units), (units, 4 * units)).astype(np.float32)
+        w[name + "/bias"] = rng.uniform(-0.1, 0.1, 4 * units).astype(np.float32)
+
+    cin = 1
+    for i, f in enumerate(CRNN_FILTERS, 1):
+        conv(f"conv_{i}", 3, cin, f)
+        cin = f
+    for i in (3, 5, 7):
+        bn(f"bn_{i}", CRNN_FILTERS[i - 1])
+    conv("stn_conv_1", 5, 512, 16)
+    conv("stn_conv_2", 5, 16, 32)
+    dense("stn_dense_1", 50 * 7 * 32, 64)
+    w["stn_dense_2/kernel"] = rng.normal(0, 0.002, (64, 6)).astype(np.float32)
+    w["stn_dense_2/bias"] = (np.array([0.9, 0, 0, 0, 0.9, 0]) + rng.normal(0, 0.02, 6)).astype(np.float32)
+    dense("fc_9", 7 * 512, 128)
+    lstm("lstm_10", 128, 128)
+    lstm("lstm_10_back", 128, 128)
+    lstm("lstm_11", 128, 128)
+    lstm("lstm_11_back", 128, 128)
+    dense("fc_12", 256, n_classes, gain=40.0)
+    w["fc_12/bias"] *= np.float32(0.2)
+    return w

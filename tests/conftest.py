@@ -27,3 +27,10 @@ def craft_weights():
     import keras_ocr_amd
 
     return keras_ocr_amd.weights.synthetic_craft_weights(1234)
+
+
+@pytest.fixture(scope="session")
+def crnn_weights():
+    import keras_ocr_amd
+
+    return keras_ocr_amd.weights.synthetic_crnn_weights(4321)

@@ -1,0 +1,70 @@
+"""CRNN recogniser on the GPU (conv/GEMM on MFMA, STN sampler, LSTM recurrence, CTC wave
+decoder — through kocr_crnn_forward) vs the CPU oracle (oracle/crnn.py, recognition.py:187-333).
+
+Tolerance (stated, fp32): softmax probabilities |dp| <= 2e-4; label rows must be EXACTLY equal
+wherever the oracle's per-step top-2 probability margin exceeds 1e-3 on every step of the row
+ — a smaller margin can legitimately flip an argmax under fp32 reordering."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 2e-4
+MARGIN = 1e-3
+
+
+def _crops(n, seed):
+    x = np.zeros((n, 31, 200), np.float32)
+    for i in range(n):
+        x[i] = synth.text_page(31, 200, 3, seed=seed + i)[..., 0] / np.float32(255)
+    return x
+
+
+@pytest.fixture(scope="module")
+def crnn_ctx(ctx, crnn_weights):
+    ctx.load_crnn(crnn_weights)
+    assert ctx.crnn_classes() == 37
+    return ctx
+
+
+@pytest.mark.parametrize("m", [1, 5, 40])
+def test_probs_and_labels_match_oracle(crnn_ctx, crnn_weights, m):
+    from oracle import crnn as ocrnn
+
+    x = _crops(m, seed=100)
+    labels, probs = crnn_ctx.crnn_forward(x, return_probs=True)
+    want_p = ocrnn.crnn_forward(crnn_weights, x[..., None])
+    want_l = ocrnn.ctc_greedy_decode(want_p)
+    assert probs.shape == want_p.shape == (m, 48, 37)
+    err = float(np.abs(probs - want_p).max())
+    assert err <= PROB_TOL, f"max abs prob error {err}"
+    srt = np.sort(want_p, -1)
+    safe = ((srt[..., -1] - srt[..., -2]) > MARGIN).all(1)
+    assert safe.sum() >= max(1, m // 2)
+    assert np.array_equal(labels[safe], want_l[safe])
+    strings = ocrnn.decode_strings(labels)
+    assert len(set(strings)) > 1 or m == 1  # the synthetic weights give diverse strings
+
+
+def test_labels_only_path_equals_probs_path(crnn_ctx):
+    x = _crops(7, seed=5)
+    a = crnn_ctx.crnn_forward(x)
+    b, _ = crnn_ctx.crnn_forward(x, return_probs=True)
+    assert np.array_equal(a, b)
+
+
+def test_ctc_collapse_rules(crnn_ctx):
+    """Decoded rows never contain the blank (36), never repeat without a blank in between in the
+    argmax path, and are -1 padded on the right only."""
+    labels, probs = crnn_ctx.crnn_forward(_crops(16, seed=50), return_probs=True)
+    best = probs.argmax(-1)
+    for row, path in zip(labels, best):
+        want, prev = [], -1
+        for c in path:
+            if c != prev and c != 36:
+                want.append(int(c))
+            prev = c
+        want = want + [-1] * (48 - len(want))
+        assert list(row) == want

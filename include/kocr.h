@@ -116,6 +116,29 @@ int kocr_crnn_forward(kocr_ctx* ctx, const float* crops, int M, int32_t* labels,
 /* len(alphabet) + 1 of the loaded recogniser (recognition.py:323), 0 if none is loaded. */
 int kocr_crnn_classes(kocr_ctx* ctx);
 
+/* ---- tools.resize_image + tools.pad (tools.py:356-398; pipeline.py:44-57) -------------- */
+/* src: n x sh x sw x 3 uint8 (n images of one size); each is resized to dh x dw exactly as
+ * cv2.resize(image, dsize=(dw, dh)) (INTER_LINEAR, uint8 fixed point) and written to the
+ * top-left of an Hmax x Wmax canvas filled with cval (255 for tools.pad, tools.py:356; 0 for the
+ * letterbox of Recognizer.recognize, tools.py:442, recognition.py:473-478).  dst: n x Hmax x Wmax x 3. */
+int kocr_resize_pad(kocr_ctx* ctx, const uint8_t* src, int n, int sh, int sw, int dh, int dw,
+                    int Hmax, int Wmax, int cval, uint8_t* dst, int on_device);
+
+/* ---- the fused path of Pipeline.recognize (pipeline.py:28-75) ---------------------------- */
+/* imgs[i]: RGB uint8 image i of size hs[i] x ws[i] (device pointers if on_device); dhs/dws:
+ * its size after tools.resize_image (the caller applies the scale rule of tools.py:387-397,
+ * int(h*scale), int(w*scale)); Hmax/Wmax: the batch's padded size (pipeline.py:48-57).
+ * Runs resize+pad -> CRAFT -> getBoxes -> warp crops -> CRNN -> CTC decode without leaving HBM.
+ * Outputs (HOST): boxes N x cap x 4 x 2 in detector-input pixels (the caller divides by its
+ * scale, tools.adjust_boxes / pipeline.py:66-71), counts[N], labels [sum(counts)] x 48 (-1
+ * padded, image-major, box order), n_crops = sum(counts).  KOCR_ECAPACITY if an image has more
+ * than cap boxes or sum(counts) > max_crops (counts / n_crops hold the true numbers). */
+int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, const int32_t* hs,
+                  const int32_t* ws, const int32_t* dhs, const int32_t* dws, int Hmax, int Wmax,
+                  float detection_threshold, float text_threshold, float link_threshold,
+                  int size_threshold, int micro_batch, float* boxes, int32_t* counts, int cap,
+                  int32_t* labels, int max_crops, int32_t* n_crops, int on_device);
+
 /* ---- single fused-epilogue convolution (unit-test seam for the MFMA kernel) ---------- */
 /* out = post_a * act(pre_a * conv(in, w) + pre_b) + post_b, NHWC, stride 1, 'same'
  * padding; w is HWIO (the Keras kernel layout, detection.py:461).  pre_a/pre_b/post_a/

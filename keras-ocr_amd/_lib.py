@@ -55,6 +55,9 @@ def load_library():
         "kocr_crnn_classes": (ci, [vp]),
         "kocr_get_boxes": (ci, [vp, vp, ci, ci, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, vp, vp, ci, ci]),
         "kocr_warp_crops": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, ci, vp, ci]),
+        "kocr_resize_pad": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci]),
+        "kocr_pipeline": (ci, [vp, ci, ctypes.POINTER(vp), _c_int_p, _c_int_p, _c_int_p, _c_int_p, ci, ci,
+                               ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, ci, vp, ci, vp, ci]),
         "kocr_conv2d_nhwc": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp]),
         "kocr_profile_enable": (ci, [vp, ci]),
         "kocr_profile_reset": (ci, [vp]),
@@ -229,6 +232,57 @@ class Context:
         self._check(rc)
         return out
 
+    # -- tools.resize_image + pad --------------------------------------------------------------
+    def resize_pad(self, images, dsize, out_hw=None, cval=255):
+        """images: (n,sh,sw,3) uint8; dsize=(dw,dh) as cv2.resize; out_hw=(Hmax,Wmax) canvas."""
+        x = np.ascontiguousarray(images, dtype=np.uint8)
+        n, sh, sw, c = x.shape
+        if c != 3:
+            raise ValueError("images must be RGB")
+        dw, dh = int(dsize[0]), int(dsize[1])
+        hmax, wmax = (dh, dw) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
+        out = np.empty((n, hmax, wmax, 3), dtype=np.uint8)
+        self._check(self._lib.kocr_resize_pad(self._h, _ptr(x), n, sh, sw, dh, dw, hmax, wmax, int(cval), _ptr(out), 0))
+        return out
+
+    # -- fused Pipeline.recognize ----------------------------------------------------------------
+    def pipeline(self, ptrs, hs, ws, dhs, dws, hmax, wmax, detection_threshold=0.7, text_threshold=0.4,
+                 link_threshold=0.4, size_threshold=10, micro_batch=0, on_device=False, cap=256, max_crops=None):
+        """ptrs: per-image source pointers (ints) or host uint8 arrays.  Returns
+        (boxes list[(n_i,4,2) f32, detector-input px], labels (M,48) int32)."""
+        n = len(ptrs)
+        keep = [np.ascontiguousarray(p, dtype=np.uint8) if not isinstance(p, (int, np.integer)) else p for p in ptrs]
+        c_ptrs = (ctypes.c_void_p * n)(*[int(p) if isinstance(p, (int, np.integer)) else p.ctypes.data for p in keep])
+        arr = [np.ascontiguousarray(v, dtype=np.int32) for v in (hs, ws, dhs, dws)]
+        cap = int(cap)
+        max_crops = int(max_crops) if max_crops else max(64, n * cap)
+        while True:
+            boxes = np.zeros((n, cap, 4, 2), dtype=np.float32)
+            counts = np.zeros(n, dtype=np.int32)
+            labels = np.full((max_crops, 48), -1, dtype=np.int32)
+            n_crops = np.zeros(1, dtype=np.int32)
+            rc = self._lib.kocr_pipeline(
+                self._h, n, c_ptrs, *[a.ctypes.data_as(_c_int_p) for a in arr], int(hmax), int(wmax),
+                float(detection_threshold), float(text_threshold), float(link_threshold), int(size_threshold),
+                int(micro_batch), _ptr(boxes), _ptr(counts), cap, _ptr(labels), max_crops, _ptr(n_crops),
+                int(bool(on_device)))
+            if rc == -4:  # KOCR_ECAPACITY: grow and retry
+                if n and counts.max() > cap:
+                    cap = int(counts.max())
+                    max_crops = max(max_crops, int(counts.sum()))
+                    continue
+                if int(n_crops[0]) > max_crops:
+                    max_crops = int(n_crops[0])
+                    continue
+            if rc == -6:
+                raise IndexError("list index out of range")
+            if rc == -7:
+                raise ZeroDivisionError("division by zero")
+            self._check(rc)
+            break
+        m = int(n_crops[0])
+        return [boxes[i, :counts[i]].copy() if counts[i] else np.array([]) for i in range(n)], labels[:m].copy()
+
     def conv2d_nhwc(self, x, w_hwio, dilation=1, pre_a=None, pre_b=None, relu=False, post_a=None, post_b=None):
         x = np.ascontiguousarray(x, dtype=np.float32)
         w = np.ascontiguousarray(w_hwio, dtype=np.float32)
@@ -265,3 +319,14 @@ class Context:
             rows[nm] = {"launches": int(launches[i]), "ms": float(ms[i]), "flops": float(flops[i]),
                         "bytes": float(byts[i])}
         return rows
+
+
+_default_ctx = None
+
+
+def default_context():
+    """The process-wide context: HIP device LOCAL_RANK (one process per GPU) or 0."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx

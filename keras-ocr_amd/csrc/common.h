@@ -91,8 +91,9 @@ struct kocr_ctx {
   void set_err(const std::string& s) { err = s; }
 
   // workspace arenas (bump allocated per call, grown on demand): ws = network activations,
-  // pp = post-processing per-pixel scratch, pp2 = post-processing canvases, io = staging
-  Arena ws, pp, pp2, io;
+  // pp = post-processing per-pixel scratch, pp2 = post-processing canvases, io = staging,
+  // pl = buffers that live for a whole kocr_pipeline call (padded batch, heat-maps, boxes)
+  Arena ws, pp, pp2, io, pl;
   int ws_reserve(size_t bytes);
   void ws_reset() { ws.off = 0; }
   void* ws_alloc(size_t bytes);
@@ -186,3 +187,7 @@ struct WarpParam {
 int warp_prepare(const float* box, int target_h, int target_w, WarpParam* out, float* ordered_box);
 int launch_warp(kocr_ctx* ctx, const uint8_t* d_img, int H, int W, const WarpParam* d_prm, int M, int th,
                 int tw, float* d_crops);
+
+// imgproc.hip
+int launch_resize_pad(kocr_ctx* ctx, const uint8_t* d_src, int n, int sh, int sw, uint8_t* d_dst, int dh, int dw,
+                      int Hmax, int Wmax, int cval, Arena& tab_arena);

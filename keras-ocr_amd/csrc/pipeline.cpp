@@ -1,0 +1,138 @@
+// pipeline.cpp — the fused device path of Pipeline.recognize (pipeline.py:28-75):
+//   resize_image + pad (pipeline.py:44-57)  ->  Detector.detect (:62; detection.py:745-785)
+//   ->  Recognizer.recognize_from_boxes (:63-65; recognition.py:491-537).
+// Everything stays resident in HBM between the stages; the host sees only the per-image box
+// counts (a few bytes, needed to size the crop batch), the boxes and the decoded label rows.
+#include "common.h"
+#include <algorithm>
+
+extern "C" int kocr_resize_pad(kocr_ctx* ctx, const uint8_t* src, int n, int sh, int sw, int dh, int dw, int Hmax,
+                               int Wmax, int cval, uint8_t* dst, int on_device) {
+  if (!ctx) return KOCR_EINVAL;
+  if (n < 0 || (n > 0 && (!src || !dst))) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_resize_pad: null buffer");
+  if (n == 0) return KOCR_OK;
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t sb = (size_t)n * sh * sw * 3, db = (size_t)n * Hmax * Wmax * 3;
+  const size_t tb = (size_t)(4 * (Wmax + Hmax) + 64) * sizeof(int);
+  KOCR_TRY(arena_reserve(ctx, ctx->io, tb + (on_device ? 0 : sb + db) + 4096));
+  ctx->io.off = 0;
+  const uint8_t* d_src = src;
+  uint8_t* d_dst = dst;
+  if (!on_device) {
+    uint8_t* ds = (uint8_t*)arena_alloc(ctx->io, sb);
+    d_dst = (uint8_t*)arena_alloc(ctx->io, db);
+    KOCR_HIP(ctx, hipMemcpyAsync(ds, src, sb, hipMemcpyHostToDevice, ctx->stream));
+    d_src = ds;
+  }
+  KOCR_TRY(launch_resize_pad(ctx, d_src, n, sh, sw, d_dst, dh, dw, Hmax, Wmax, cval, ctx->io));
+  if (!on_device) {
+    KOCR_HIP(ctx, hipMemcpyAsync(dst, d_dst, db, hipMemcpyDeviceToHost, ctx->stream));
+    KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return KOCR_OK;
+}
+
+extern "C" int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, const int32_t* hs, const int32_t* ws,
+                             const int32_t* dhs, const int32_t* dws, int Hmax, int Wmax, float detection_threshold,
+                             float text_threshold, float link_threshold, int size_threshold, int micro_batch,
+                             float* boxes, int32_t* counts, int cap, int32_t* labels, int max_crops,
+                             int32_t* n_crops, int on_device) {
+  if (!ctx) return KOCR_EINVAL;
+  if (n_crops) *n_crops = 0;
+  if (N < 0 || (N > 0 && (!imgs || !hs || !ws || !dhs || !dws || !boxes || !counts)))
+    KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_pipeline: null buffer");
+  if (N == 0) return KOCR_OK;
+  if (!ctx->craft) KOCR_FAIL(ctx, KOCR_ENOWEIGHTS, "kocr_pipeline: call kocr_load_craft first");
+  if (crnn_classes(ctx) == 0) KOCR_FAIL(ctx, KOCR_ENOWEIGHTS, "kocr_pipeline: call kocr_load_crnn first");
+  if (Hmax < 16 || Wmax < 16 || cap <= 0) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_pipeline: bad sizes");
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  const int h2 = Hmax / 2, w2 = Wmax / 2;
+  const size_t bat_b = (size_t)N * Hmax * Wmax * 3;
+  const size_t heat_b = (size_t)N * h2 * w2 * 2 * sizeof(float);
+  const size_t box_b = (size_t)N * cap * 8 * sizeof(float);
+  // ---- persistent buffers of this call ----
+  KOCR_TRY(arena_reserve(ctx, ctx->pl, bat_b + heat_b + box_b + 4096));
+  ctx->pl.off = 0;
+  uint8_t* d_bat = (uint8_t*)arena_alloc(ctx->pl, bat_b);
+  float* d_heat = (float*)arena_alloc(ctx->pl, heat_b);
+  float* d_boxes = (float*)arena_alloc(ctx->pl, box_b);
+  if (!d_bat || !d_heat || !d_boxes) KOCR_FAIL(ctx, KOCR_ENOMEM, "kocr_pipeline: arena exhausted");
+  // ---- resize + pad, runs of identically-shaped contiguous images in one launch ----
+  size_t max_src = 0;
+  for (int i = 0; i < N; ++i) max_src = std::max(max_src, (size_t)hs[i] * ws[i] * 3);
+  int i = 0;
+  while (i < N) {
+    int j = i + 1;
+    while (j < N && hs[j] == hs[i] && ws[j] == ws[i] && dhs[j] == dhs[i] && dws[j] == dws[i] &&
+           imgs[j] == imgs[j - 1] + (size_t)hs[i] * ws[i] * 3)
+      ++j;
+    const int run = j - i;
+    const size_t sb = (size_t)run * hs[i] * ws[i] * 3;
+    const size_t tb = (size_t)(4 * (Wmax + Hmax) + 64) * sizeof(int);
+    KOCR_TRY(arena_reserve(ctx, ctx->io, tb + (on_device ? 0 : sb) + 4096));
+    ctx->io.off = 0;
+    const uint8_t* d_src = imgs[i];
+    if (!on_device) {
+      uint8_t* ds = (uint8_t*)arena_alloc(ctx->io, sb);
+      KOCR_HIP(ctx, hipMemcpyAsync(ds, imgs[i], sb, hipMemcpyHostToDevice, ctx->stream));
+      d_src = ds;
+    }
+    KOCR_TRY(launch_resize_pad(ctx, d_src, run, hs[i], ws[i], d_bat + (size_t)i * Hmax * Wmax * 3, dhs[i], dws[i],
+                               Hmax, Wmax, 255, ctx->io));
+    i = j;
+  }
+  // ---- detector forward (micro-batched) ----
+  int mb = micro_batch > 0 ? micro_batch : 32;
+  while (mb > 1 && craft_workspace_bytes(mb, Hmax, Wmax) > ((size_t)64 << 30)) mb = (mb + 1) / 2;
+  mb = std::min(mb, N);
+  KOCR_TRY(ctx->ws_reserve(craft_workspace_bytes(mb, Hmax, Wmax)));
+  for (int s = 0; s < N; s += mb) {
+    const int nb = std::min(mb, N - s);
+    ctx->ws_reset();
+    KOCR_TRY(craft_forward(ctx, d_bat + (size_t)s * Hmax * Wmax * 3, KOCR_U8, nb, Hmax, Wmax,
+                           d_heat + (size_t)s * h2 * w2 * 2));
+  }
+  // ---- boxes ----
+  int n_empty = 0;
+  KOCR_TRY(postproc_get_boxes(ctx, d_heat, N, h2, w2, detection_threshold, text_threshold, link_threshold,
+                              size_threshold, d_boxes, cap, counts, &n_empty));
+  if (n_empty > 0)
+    KOCR_FAIL(ctx, KOCR_EEMPTYCONTOUR, "kocr_pipeline: empty contour list (IndexError at detection.py:272)");
+  KOCR_HIP(ctx, hipMemcpyAsync(boxes, d_boxes, box_b, hipMemcpyDeviceToHost, ctx->stream));
+  KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  long M = 0;
+  for (int k = 0; k < N; ++k) M += counts[k];
+  if (n_crops) *n_crops = (int32_t)M;
+  if (M == 0) return KOCR_OK;
+  if (!labels || M > max_crops) KOCR_FAIL(ctx, KOCR_ECAPACITY, "kocr_pipeline: more crops than max_crops");
+  // ---- crops ----
+  std::vector<WarpParam> prm((size_t)M);
+  long m = 0;
+  for (int k = 0; k < N; ++k)
+    for (int b = 0; b < counts[k]; ++b, ++m) {
+      const int rc = warp_prepare(boxes + ((size_t)k * cap + b) * 8, 31, 200, &prm[m], nullptr);
+      if (rc == 1) KOCR_FAIL(ctx, KOCR_EZERODIV, "kocr_pipeline: box with zero width or height (tools.py:95)");
+      if (rc != 0) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_pipeline: singular perspective transform");
+      prm[m].img = k;
+    }
+  const size_t crop_b = (size_t)M * 31 * 200 * sizeof(float), lab_b = (size_t)M * 48 * sizeof(int32_t);
+  KOCR_TRY(arena_reserve(ctx, ctx->io, (size_t)M * sizeof(WarpParam) + crop_b + lab_b + 4096));
+  ctx->io.off = 0;
+  WarpParam* d_prm = (WarpParam*)arena_alloc(ctx->io, (size_t)M * sizeof(WarpParam));
+  float* d_crops = (float*)arena_alloc(ctx->io, crop_b);
+  int32_t* d_lab = (int32_t*)arena_alloc(ctx->io, lab_b);
+  KOCR_HIP(ctx, hipMemcpyAsync(d_prm, prm.data(), (size_t)M * sizeof(WarpParam), hipMemcpyHostToDevice, ctx->stream));
+  KOCR_TRY(launch_warp(ctx, d_bat, Hmax, Wmax, d_prm, (int)M, 31, 200, d_crops));
+  // ---- recogniser ----
+  const int C = crnn_classes(ctx);
+  const int cmb = (int)std::min<long>(M, 1024);
+  KOCR_TRY(ctx->ws_reserve(crnn_workspace_bytes(cmb, C)));
+  for (long s = 0; s < M; s += cmb) {
+    const int nb = (int)std::min<long>(cmb, M - s);
+    ctx->ws_reset();
+    KOCR_TRY(crnn_forward(ctx, d_crops + (size_t)s * 31 * 200, nb, d_lab + (size_t)s * 48, nullptr));
+  }
+  KOCR_HIP(ctx, hipMemcpyAsync(labels, d_lab, lab_b, hipMemcpyDeviceToHost, ctx->stream));
+  KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KOCR_OK;
+}

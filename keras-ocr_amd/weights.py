@@ -119,3 +119,92 @@ def synthetic_crnn_weights(seed=4321, n_classes=37):
     dense("fc_12", 256, n_classes, gain=40.0)
     w["fc_12/bias"] *= np.float32(0.2)
     return w
+
+
+def synthetic_fc12(n_classes, seed=99):
+    """A freshly initialised top layer for a custom alphabet (recognition.py:393-404 loads the
+    'notop' backbone and leaves fc_12 at its initialiser)."""
+    rng = np.random.default_rng(seed)
+    return {
+        "fc_12/kernel": rng.normal(0, np.sqrt(2.0 / 256), (256, n_classes)).astype(np.float32),
+        "fc_12/bias": np.zeros(n_classes, np.float32),
+    }
+
+
+def read_keras_h5(path, kind):
+    """Keras HDF5 weight file -> the tensor names kocr_load_craft / kocr_load_crnn expect.
+
+    ``kind='craft'``: craft_mlt_25k.h5 (layer names = PyTorch keys, detection.py:647-658);
+    ``kind='crnn'``: crnn_kurapan[_notop].h5 (recognition.py:27-44).  Needs ``h5py``, which this
+    image does not ship and the files cannot be downloaded here: this reader follows the Keras
+    HDF5 layout (``layer/layer/variable:0``) but could not be exercised — see DESIGN.md."""
+    try:
+        import h5py  # pylint: disable=import-outside-toplevel
+    except ImportError as e:  # pragma: no cover
+        raise ImportError("reading Keras .h5 weights needs h5py; convert the file to a dict of arrays "
+                          "(see keras_ocr_amd.weights) or use load_from_torch=True for the detector") from e
+    tensors = {}
+
+    def visit(name, obj):
+        if isinstance(obj, h5py.Dataset):
+            tensors[name] = np.array(obj, dtype=np.float32)
+
+    with h5py.File(path, "r") as f:
+        (f["model_weights"] if "model_weights" in f else f).visititems(visit)
+    out = {}
+    if kind == "craft":
+        for name, arr in tensors.items():
+            parts = name.split("/")
+            layer, var = parts[0], parts[-1].split(":")[0]
+            if var == "kernel":
+                out[layer + ".weight"] = arr.transpose(3, 2, 0, 1)  # HWIO -> OIHW (detection.py:461)
+            elif var == "bias":
+                out[layer + ".bias"] = arr
+            elif var == "gamma":
+                out[layer + ".weight"] = arr
+            elif var == "beta":
+                out[layer + ".bias"] = arr
+            elif var == "moving_mean":
+                out[layer + ".running_mean"] = arr
+            elif var == "moving_variance":
+                out[layer + ".running_var"] = arr
+        return out
+    stn = {}
+    for name, arr in tensors.items():
+        parts = name.split("/")
+        layer, var = parts[0], parts[-1].split(":")[0]
+        if layer.startswith(("conv_", "bn_", "fc_", "lstm_")):
+            out[f"{layer}/{var}"] = arr
+        else:  # the unnamed layers of the nested localisation model
+            stn[(arr.shape, var)] = arr
+    for (shape, var), arr in stn.items():
+        if var == "kernel" and len(shape) == 4:
+            out[("stn_conv_1" if shape[2] == 512 else "stn_conv_2") + "/kernel"] = arr
+        elif var == "kernel":
+            out[("stn_dense_1" if shape[0] == 11200 else "stn_dense_2") + "/kernel"] = arr
+        elif var == "bias":
+            key = {16: "stn_conv_1", 32: "stn_conv_2", 64: "stn_dense_1", 6: "stn_dense_2"}[shape[0]]
+            out[key + "/bias"] = arr
+    return out
+
+
+def calibrate_craft_head(weights, heat_sample, text_frac=0.08, link_frac=0.03, peak=0.95):
+    """Rescale the last (linear) CRAFT layer of random-init weights so that its two output
+    channels behave like score maps: ``text_frac`` / ``link_frac`` of the pixels of
+    ``heat_sample`` (the head's output under ``weights``) end up above the reference's 0.4
+    thresholds (detection.py:749-750) and the 99.8th percentile lands at ``peak`` (> the 0.7
+    detection threshold).  Random weights otherwise never produce a box, which would leave the
+    crop + recognition stages of the synthetic benchmark idle.  Returns a new weight dict."""
+    out = dict(weights)
+    w = np.array(weights["conv_cls.8.weight"], dtype=np.float32, copy=True)
+    b = np.array(weights["conv_cls.8.bias"], dtype=np.float32, copy=True)
+    for c, frac in enumerate((text_frac, link_frac)):
+        v = np.asarray(heat_sample[..., c], dtype=np.float64).ravel()
+        q = np.quantile(v, 1.0 - frac)
+        top = np.quantile(v, 0.998)
+        a = (peak - 0.4) / max(top - q, 1e-6)
+        w[c] *= np.float32(a)
+        b[c] = np.float32(a * (b[c] - q) + 0.4)
+    out["conv_cls.8.weight"] = w
+    out["conv_cls.8.bias"] = b
+    return out

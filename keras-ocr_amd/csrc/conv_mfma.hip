@@ -18,6 +18,9 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// native clang vector (HIP's float4 wrapper struct defeats SROA for arrays captured by lambdas
+// and sends the staged tile through scratch)
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct ConvParams {
   const float* in;
@@ -45,13 +48,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // MODE 0: Cin % 16 == 0, float4 gathers.  MODE 1: generic scalar gather (f32).
 // MODE 2: generic scalar gather from raw u8 RGB through the normalisation LUT.
-template <int BM, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
-  constexpr int BK = 16;
+template <int BM, int BN, int WM, int WN, int MODE, int BK = 16, int PF = 0>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int A_PER_T = BM * 4 / 256;
+  constexpr int QPR = BK / 4;             // float4 quads per pixel row of the K-step
+  constexpr int A_PER_T = BM * QPR / 256;
+  constexpr int A_MSTEP = 256 / QPR;      // pixels covered by one pass of the block
   constexpr int B_F4 = BK * BN / 4;
   constexpr int B_PER_T = (B_F4 + 255) / 256;
   static_assert(WM * WN == 4, "4 waves");
@@ -71,44 +75,66 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
   const int m0 = mt * BM, n0 = nt * BN;
 
   // ---- per-thread gather coordinates (fixed over the K loop) --------------------------
-  const int quad = tid & 3;
+  const int quad = tid % QPR;
   int a_oy[A_PER_T], a_ox[A_PER_T];
   long a_pm[A_PER_T];
+  // MODE 0 fast path: 32-bit element offsets relative to the block's first pixel and a bit mask of
+  // the taps that fall inside the image (KH*KW <= 25), so the K loop needs no 64-bit multiplies
+  // and no coordinate compares.
+  int a_off[A_PER_T];
+  unsigned a_mask[A_PER_T];
+  const float* blk_in = p.in + ((long)m0 * p.in_cs + p.in_co);
 #pragma unroll
   for (int i = 0; i < A_PER_T; ++i) {
-    const int pm = m0 + (tid >> 2) + 64 * i;
+    const int pm = m0 + tid / QPR + A_MSTEP * i;
+    unsigned mask = 0;
     if (pm < p.Mtotal) {
       const int ox = pm % p.W;
       const int t = pm / p.W;
       a_ox[i] = ox;
       a_oy[i] = t % p.H;
       a_pm[i] = pm;
+      if constexpr (MODE == 0) {
+        for (int tap = 0; tap < p.KH * p.KW; ++tap) {
+          const int ky = tap / p.KW, kx = tap - ky * p.KW;
+          const int iy = a_oy[i] + ky * p.dil - p.padh, ix = ox + kx * p.dil - p.padw;
+          if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << tap;
+        }
+      }
     } else {
       a_ox[i] = -(1 << 28);  // every tap falls outside -> zeros
       a_oy[i] = -(1 << 28);
       a_pm[i] = 0;
     }
+    a_mask[i] = mask;
+    a_off[i] = (tid / QPR + A_MSTEP * i) * p.in_cs + quad * 4;
+  }
+  // weight-tile pointers advance by BK rows per K-step
+  const float* b_ptr[B_PER_T];
+#pragma unroll
+  for (int j = 0; j < B_PER_T; ++j) {
+    const int f = (B_F4 % 256 == 0) ? tid + 256 * j : (tid + 256 * j) % B_F4;  // wrap: duplicates are harmless
+    const int krow = f / (BN / 4), nc = f - krow * (BN / 4);
+    b_ptr[j] = p.wgt + (size_t)krow * p.Cout_pad + n0 + nc * 4;
   }
 
-  float4 ra[A_PER_T];
-  float4 rb[B_PER_T];
+  v4f ra[A_PER_T];
+  v4f rb[B_PER_T];
 
   auto load_chunk = [&](int ch) {
     if constexpr (MODE == 0) {
-      const int cpt = p.Cin >> 4;  // chunks per tap
+      const int cpt = p.Cin / BK;  // chunks per tap
       const int tap = ch / cpt;
-      const int c0 = (ch - tap * cpt) << 4;
+      const int c0 = (ch - tap * cpt) * BK;
       const int ky = tap / p.KW, kx = tap - ky * p.KW;
       const int dy = ky * p.dil - p.padh, dx = kx * p.dil - p.padw;
+      const int tap_off = (dy * p.W + dx) * p.in_cs + c0;  // wave-uniform
 #pragma unroll
       for (int i = 0; i < A_PER_T; ++i) {
-        const int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-          const long off = (a_pm[i] + (long)dy * p.W + dx) * p.in_cs + p.in_co + c0 + quad * 4;
-          v = *reinterpret_cast<const float4*>(p.in + off);
-        }
-        ra[i] = v;
+        const bool ok = (a_mask[i] >> tap) & 1u;
+        const int off = ok ? a_off[i] + tap_off : 0;  // offset 0 = the block's first pixel: always mapped
+        v4f v = *reinterpret_cast<const v4f*>(blk_in + off);
+        ra[i] = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
       }
     } else {
 #pragma unroll
@@ -134,24 +160,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
           }
           e[q] = v;
         }
-        ra[i] = make_float4(e[0], e[1], e[2], e[3]);
+        ra[i] = v4f{e[0], e[1], e[2], e[3]};
       }
     }
 #pragma unroll
     for (int j = 0; j < B_PER_T; ++j) {
-      const int f = tid + 256 * j;
-      if (B_F4 % 256 == 0 || f < B_F4) {
-        const int krow = f / (BN / 4), nc = f - krow * (BN / 4);
-        rb[j] = *reinterpret_cast<const float4*>(p.wgt + (size_t)(ch * BK + krow) * p.Cout_pad + n0 +
-                                                  nc * 4);
-      }
+      rb[j] = *reinterpret_cast<const v4f*>(b_ptr[j] + (size_t)ch * BK * p.Cout_pad);
     }
   };
 
   auto store_chunk = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
-      const int m = (tid >> 2) + 64 * i;
+      const int m = tid / QPR + A_MSTEP * i;
       As[buf][quad * 4 + 0][m] = ra[i].x;
       As[buf][quad * 4 + 1][m] = ra[i].y;
       As[buf][quad * 4 + 2][m] = ra[i].z;
@@ -159,11 +180,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     }
 #pragma unroll
     for (int j = 0; j < B_PER_T; ++j) {
-      const int f = tid + 256 * j;
-      if (B_F4 % 256 == 0 || f < B_F4) {
-        const int krow = f / (BN / 4), nc = f - krow * (BN / 4);
-        *reinterpret_cast<float4*>(&Bs[buf][krow][nc * 4]) = rb[j];
-      }
+      const int f = (B_F4 % 256 == 0) ? tid + 256 * j : (tid + 256 * j) % B_F4;
+      const int krow = f / (BN / 4), nc = f - krow * (BN / 4);
+      *reinterpret_cast<v4f*>(&Bs[buf][krow][nc * 4]) = rb[j];
     }
   };
 
@@ -175,30 +194,67 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  auto compute_chunk = [&](int buf) {
+    if constexpr (PF == 1) {
+      // operand fragments of k-pair kp+1 are fetched from LDS before the MFMAs of k-pair kp issue
+      float a[2][TM], b[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[0][i] = As[buf][lk][wm * WTM + i * 32 + lr];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[0][j] = Bs[buf][lk][wn * WTN + j * 32 + lr];
+#pragma unroll
+      for (int kp = 0; kp < BK / 2; ++kp) {
+        const int cur = kp & 1, nxt = cur ^ 1;
+        if (kp + 1 < BK / 2) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[nxt][i] = As[buf][2 * kp + 2 + lk][wm * WTM + i * 32 + lr];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[nxt][j] = Bs[buf][2 * kp + 2 + lk][wn * WTN + j * 32 + lr];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kp = 0; kp < BK / 2; ++kp) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = As[buf][2 * kp + lk][wm * WTM + i * 32 + lr];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Bs[buf][2 * kp + lk][wn * WTN + j * 32 + lr];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
   load_chunk(0);
   store_chunk(0);
   __syncthreads();
 
+  // steady state: no conditionals around the staging registers (a branch here makes hipcc park
+  // the prefetched B tile in scratch and wait for the loads before the MFMAs)
   const int nch = p.nchunks;
-  for (int ch = 0; ch < nch; ++ch) {
+  for (int ch = 0; ch + 1 < nch; ++ch) {
     const int buf = ch & 1;
-    if (ch + 1 < nch) load_chunk(ch + 1);
-#pragma unroll
-    for (int kp = 0; kp < BK / 2; ++kp) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[buf][2 * kp + lk][wm * WTM + i * 32 + lr];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[buf][2 * kp + lk][wn * WTN + j * 32 + lr];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    if constexpr (PF < 2) load_chunk(ch + 1);
+    // keep the prefetch loads ahead of the MFMAs: without this fence hipcc sinks the weight-tile
+    // loads to just before their LDS store and the wave eats the full L2 latency every K-step
+    __builtin_amdgcn_sched_barrier(0);
+    compute_chunk(buf);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PF != 3) {
+      store_chunk(buf ^ 1);
+      __syncthreads();
     }
-    if (ch + 1 < nch) store_chunk(buf ^ 1);
-    __syncthreads();
   }
+  compute_chunk((nch - 1) & 1);
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
 #pragma unroll
@@ -241,7 +297,7 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
   L.dil = dil;
   L.relu = relu;
   L.Kreal = KH * KW * Cin;
-  L.Kpad = round_up(L.Kreal, 16);
+  L.Kpad = round_up(L.Kreal, 32);
   L.BN = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
   L.Cout_pad = round_up(Cout, L.BN);
   std::vector<float> wp((size_t)L.Kpad * L.Cout_pad, 0.f);
@@ -274,15 +330,41 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
   return KOCR_OK;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK, int PF>
 static void dispatch_mode(int mode, dim3 grid, hipStream_t s, const ConvParams& p) {
   if (mode == 0)
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 0>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 0, BK, PF>), grid, dim3(256), 0, s, p);
   else if (mode == 1)
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 1, BK, PF>), grid, dim3(256), 0, s, p);
   else
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 2, BK, PF>), grid, dim3(256), 0, s, p);
 }
+
+// developer A/B switch (KOCR_CONV_VARIANT): 0 = BK16, 1 = BK16 + fragment prefetch,
+// 2 = BK32, 3 = BK32 + fragment prefetch
+static int conv_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("KOCR_CONV_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+template <int BM, int BN, int WM, int WN>
+static void dispatch_variant(int variant, int mode, dim3 grid, hipStream_t s, const ConvParams& p) {
+  switch (variant) {
+    case 1: dispatch_mode<BM, BN, WM, WN, 16, 1>(mode, grid, s, p); break;
+    case 2: dispatch_mode<BM, BN, WM, WN, 32, 0>(mode, grid, s, p); break;
+    case 3: dispatch_mode<BM, BN, WM, WN, 32, 1>(mode, grid, s, p); break;
+    case 4: dispatch_mode<BM, BN, WM, WN, 16, 2>(mode, grid, s, p); break;  // ablation: no global loads
+    case 5: dispatch_mode<BM, BN, WM, WN, 16, 3>(mode, grid, s, p); break;  // ablation: MFMA + LDS reads only
+    default: dispatch_mode<BM, BN, WM, WN, 16, 0>(mode, grid, s, p); break;
+  }
+}
+
+// BK=32 in vector mode needs Cin % 32 == 0
+static bool mode_needs_bk16(const ConvLayer& L, const Tensor&) { return L.Cin % 32 != 0 && L.Cin % 16 == 0; }
 
 int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8,
                 const float* lut, const Tensor& out) {
@@ -319,7 +401,10 @@ int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8
   p.relu = L.relu;
   p.Mtotal = (int)M;
   p.Kreal = L.Kreal;
-  p.nchunks = L.Kpad / 16;
+  int variant = conv_variant();
+  if (mode_needs_bk16(L, in) && variant < 4) variant &= 1;
+  const int bk = (variant == 2 || variant == 3) ? 32 : 16;
+  p.nchunks = (L.Kreal + bk - 1) / bk;  // weight rows are zero padded up to Kpad (multiple of 32)
   int mode;
   if (in_u8)
     mode = 2;
@@ -336,11 +421,11 @@ int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8
   const int mtiles = (int)((M + BM - 1) / BM);
   dim3 grid(mtiles * (L.Cout_pad / L.BN));
   if (L.BN == 128)
-    dispatch_mode<128, 128, 2, 2>(mode, grid, ctx->stream, p);
+    dispatch_variant<128, 128, 2, 2>(variant, mode, grid, ctx->stream, p);
   else if (L.BN == 64)
-    dispatch_mode<256, 64, 4, 1>(mode, grid, ctx->stream, p);
+    dispatch_variant<256, 64, 4, 1>(variant, mode, grid, ctx->stream, p);
   else
-    dispatch_mode<256, 32, 4, 1>(mode, grid, ctx->stream, p);
+    dispatch_variant<256, 32, 4, 1>(variant, mode, grid, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }

@@ -49,16 +49,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // MODE 0: Cin % 16 == 0, float4 gathers.  MODE 1: generic scalar gather (f32).
 // MODE 2: generic scalar gather from raw u8 RGB through the normalisation LUT.
 template <int BM, int BN, int WM, int WN, int MODE, int BK = 16, int PF = 0>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfma_kernel(ConvParams p) {
+  constexpr int NT = 64 * WM * WN;  // threads per block
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int QPR = BK / 4;             // float4 quads per pixel row of the K-step
-  constexpr int A_PER_T = BM * QPR / 256;
-  constexpr int A_MSTEP = 256 / QPR;      // pixels covered by one pass of the block
+  constexpr int A_PER_T = BM * QPR / NT;
+  constexpr int A_MSTEP = NT / QPR;      // pixels covered by one pass of the block
   constexpr int B_F4 = BK * BN / 4;
-  constexpr int B_PER_T = (B_F4 + 255) / 256;
-  static_assert(WM * WN == 4, "4 waves");
+  constexpr int B_PER_T = (B_F4 + NT - 1) / NT;
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
   static_assert(TM >= 1 && TN >= 1, "tile");
 
   __shared__ float As[2][BK][LDA];
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
   const float* b_ptr[B_PER_T];
 #pragma unroll
   for (int j = 0; j < B_PER_T; ++j) {
-    const int f = (B_F4 % 256 == 0) ? tid + 256 * j : (tid + 256 * j) % B_F4;  // wrap: duplicates are harmless
+    const int f = (B_F4 % NT == 0) ? tid + NT * j : (tid + NT * j) % B_F4;  // wrap: duplicates are harmless
     const int krow = f / (BN / 4), nc = f - krow * (BN / 4);
     b_ptr[j] = p.wgt + (size_t)krow * p.Cout_pad + n0 + nc * 4;
   }
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
     }
 #pragma unroll
     for (int j = 0; j < B_PER_T; ++j) {
-      const int f = (B_F4 % 256 == 0) ? tid + 256 * j : (tid + 256 * j) % B_F4;
+      const int f = (B_F4 % NT == 0) ? tid + NT * j : (tid + NT * j) % B_F4;
       const int krow = f / (BN / 4), nc = f - krow * (BN / 4);
       *reinterpret_cast<v4f*>(&Bs[buf][krow][nc * 4]) = rb[j];
     }
@@ -243,13 +244,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvParams p) {
   const int nch = p.nchunks;
   for (int ch = 0; ch + 1 < nch; ++ch) {
     const int buf = ch & 1;
-    if constexpr (PF < 2) load_chunk(ch + 1);
+    if constexpr (PF < 2 || PF >= 4) load_chunk(ch + 1);
     // keep the prefetch loads ahead of the MFMAs: without this fence hipcc sinks the weight-tile
     // loads to just before their LDS store and the wave eats the full L2 latency every K-step
     __builtin_amdgcn_sched_barrier(0);
     compute_chunk(buf);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (PF != 3) {
+    if constexpr (PF == 4) {  // ablation: loads + barrier, no LDS stores (keep the loads live)
+      for (int i = 0; i < A_PER_T; ++i) asm volatile("" ::"v"(ra[i]));
+      for (int j = 0; j < B_PER_T; ++j) asm volatile("" ::"v"(rb[j]));
+      __syncthreads();
+    } else if constexpr (PF == 5) {  // ablation: loads + LDS stores, no barrier
+      store_chunk(buf ^ 1);
+    } else if constexpr (PF != 3) {
       store_chunk(buf ^ 1);
       __syncthreads();
     }
@@ -333,11 +340,11 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
 template <int BM, int BN, int WM, int WN, int BK, int PF>
 static void dispatch_mode(int mode, dim3 grid, hipStream_t s, const ConvParams& p) {
   if (mode == 0)
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 0, BK, PF>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 0, BK, PF>), grid, dim3(64 * WM * WN), 0, s, p);
   else if (mode == 1)
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 1, BK, PF>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 1, BK, PF>), grid, dim3(64 * WM * WN), 0, s, p);
   else
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 2, BK, PF>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 2, BK, PF>), grid, dim3(64 * WM * WN), 0, s, p);
 }
 
 // developer A/B switch (KOCR_CONV_VARIANT): 0 = BK16, 1 = BK16 + fragment prefetch,
@@ -359,6 +366,8 @@ static void dispatch_variant(int variant, int mode, dim3 grid, hipStream_t s, co
     case 3: dispatch_mode<BM, BN, WM, WN, 32, 1>(mode, grid, s, p); break;
     case 4: dispatch_mode<BM, BN, WM, WN, 16, 2>(mode, grid, s, p); break;  // ablation: no global loads
     case 5: dispatch_mode<BM, BN, WM, WN, 16, 3>(mode, grid, s, p); break;  // ablation: MFMA + LDS reads only
+    case 6: dispatch_mode<BM, BN, WM, WN, 16, 4>(mode, grid, s, p); break;  // ablation: no LDS stores
+    case 7: dispatch_mode<BM, BN, WM, WN, 16, 5>(mode, grid, s, p); break;  // ablation: no barrier
     default: dispatch_mode<BM, BN, WM, WN, 16, 0>(mode, grid, s, p); break;
   }
 }
@@ -402,6 +411,7 @@ int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8
   p.Mtotal = (int)M;
   p.Kreal = L.Kreal;
   int variant = conv_variant();
+  if (variant == 8) variant = 0;
   if (mode_needs_bk16(L, in) && variant < 4) variant &= 1;
   const int bk = (variant == 2 || variant == 3) ? 32 : 16;
   p.nchunks = (L.Kreal + bk - 1) / bk;  // weight rows are zero padded up to Kpad (multiple of 32)
@@ -415,12 +425,15 @@ int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   char nm[64];
-  const int BM = (L.BN == 128) ? 128 : 256;
+  const bool big = (conv_variant() == 8) && L.BN == 128 && mode == 0 && M >= 256 * 1024;
+  const int BM = (L.BN == 128 && !big) ? 128 : 256;
   snprintf(nm, sizeof nm, "conv_mfma_%dx%d_m%d", BM, L.BN, mode);
   ProfScope ps(ctx, nm, flops, bytes);
   const int mtiles = (int)((M + BM - 1) / BM);
   dim3 grid(mtiles * (L.Cout_pad / L.BN));
-  if (L.BN == 128)
+  if (big)
+    dispatch_mode<256, 128, 4, 2, 16, 0>(mode, grid, ctx->stream, p);
+  else if (L.BN == 128)
     dispatch_variant<128, 128, 2, 2>(variant, mode, grid, ctx->stream, p);
   else if (L.BN == 64)
     dispatch_variant<256, 64, 4, 1>(variant, mode, grid, ctx->stream, p);

@@ -12,6 +12,8 @@ SHAPES = [  # N, H, W, Cin, Cout, k  — CRAFT layer classes at 8 x 768x768
     (8, 384, 384, 64, 32, 3),
     (8, 48, 48, 1536, 512, 1),
 ]
+if len(sys.argv) > 1:
+    SHAPES = [SHAPES[int(a)] for a in sys.argv[1:]]
 ctx = k.Context(0)
 rng = np.random.default_rng(0)
 for (n, h, w, cin, cout, kk) in SHAPES:

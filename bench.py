@@ -122,6 +122,10 @@ def main():
     def step():
         return pipe.recognize_device(d_pages.data_ptr(), n, h, w)
 
+    # the HIP-event profiler runs from here on (warm-up included) so that the per-kernel averages
+    # over the WHOLE process can be cross-checked against the rocprofv3 summary in profiles/
+    ctx.profile_reset()
+    ctx.profile_enable(True)
     out = None
     for _ in range(args.warmup):
         out = step()
@@ -132,8 +136,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    ctx.profile_reset()
-    ctx.profile_enable(True)
+    prof0 = ctx.profile_report()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -146,7 +149,13 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    prof = ctx.profile_report()
+    prof_all = ctx.profile_report()
+    prof = {}
+    for kk, v in prof_all.items():
+        b = prof0.get(kk, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        d = {f: v[f] - b[f] for f in ("launches", "ms", "flops", "bytes")}
+        if d["launches"]:
+            prof[kk] = d
 
     if rank == 0:
         dom = max((kv for kv in prof.items() if kv[0].startswith("conv_mfma")), key=lambda kv: kv[1]["ms"])
@@ -155,6 +164,18 @@ def main():
         conv_ms = sum(v["ms"] for kk, v in prof.items() if kk.startswith("conv_mfma"))
         conv_fl = sum(v["flops"] for kk, v in prof.items() if kk.startswith("conv_mfma"))
         stage_ms = {kk: round(v["ms"] / args.steps, 3) for kk, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        # HBM traffic of the dominant kernel: PMC passes cannot run inside this process; the number
+        # is read from the committed summary of scripts/pmc_bench.sh over this same command
+        traffic, traffic_src = None, "no profiles/*_pmc_traffic.json found"
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+        if cands:
+            pm = json.load(open(cands[-1]))
+            for kname, row in pm["kernels"].items():
+                if kname.startswith("void conv_mfma_kernel<128, 128") and "hbm_bytes_per_launch" in row:
+                    traffic = row["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/" + os.path.basename(cands[-1]) + f", average over {row['launches']} launches of the bench process"
+                    break
         res = {
             "metric": "images/sec end-to-end Pipeline.recognize() @768x768",
             "value": world * args.batch * args.steps / dt,
@@ -174,8 +195,12 @@ def main():
                        "global_batch": world * args.batch, "words_per_batch": n_words,
                        "parallelism": f"dp{world} (images sharded, no data-path collective)"},
             "roofline": {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": FP32_MFMA_PEAK_TF,
-                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TF, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TF, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE*2 + WRITE_SIZE, " + traffic_src + ")",
+                         "algorithmic_bytes_per_launch": prof_all[name]["bytes"] / prof_all[name]["launches"],
                          "avg_launch_ms": r["ms"] / r["launches"], "launches": r["launches"],
+                         "avg_launch_ms_process": prof_all[name]["ms"] / prof_all[name]["launches"],
+                         "launches_process": prof_all[name]["launches"],
                          "all_conv_tflops": conv_fl / (conv_ms * 1e-3) / 1e12},
             "stage_ms_per_step": stage_ms,
         }

@@ -427,7 +427,11 @@ int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8
   char nm[64];
   const bool big = (conv_variant() == 8) && L.BN == 128 && mode == 0 && M >= 256 * 1024;
   const int BM = (L.BN == 128 && !big) ? 128 : 256;
-  snprintf(nm, sizeof nm, "conv_mfma_%dx%d_m%d", BM, L.BN, mode);
+  static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;  // developer: one row per layer
+  if (per_layer)
+    snprintf(nm, sizeof nm, "conv_%dx%d_m%d:%s", BM, L.BN, mode, L.name.c_str());
+  else
+    snprintf(nm, sizeof nm, "conv_mfma_%dx%d_m%d", BM, L.BN, mode);
   ProfScope ps(ctx, nm, flops, bytes);
   const int mtiles = (int)((M + BM - 1) / BM);
   dim3 grid(mtiles * (L.Cout_pad / L.BN));

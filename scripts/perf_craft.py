@@ -26,6 +26,7 @@ ctx.profile_enable(True)
 ctx.craft_forward_device(img.data_ptr(), 0, N, H, W, heat.data_ptr())
 rep = ctx.profile_report()
 tot = sum(r["ms"] for r in rep.values())
+mb = 1
 for nm, r in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
     tf = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] else 0
     gb = r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] else 0

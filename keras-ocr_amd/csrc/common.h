@@ -151,6 +151,8 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
 // in_u8 != nullptr: first-layer mode, raw RGB bytes + LUT normalisation.
 int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8,
                 const float* lut, const Tensor& out);
+int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8,
+                     const float* lut, const Tensor& out, const Tensor* pool);
 // elementwise.hip
 int launch_maxpool2x2(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
 int launch_maxpool3x3s1(kocr_ctx* ctx, const Tensor& in, const Tensor& out);

@@ -38,6 +38,9 @@ struct ConvParams {
   int relu;
   int Mtotal;
   int Kreal, nchunks;
+  // fused 2x2/stride-2 max-pool epilogue (POOL kernels): tile = 2 image rows x BM/2 columns
+  float* pool_out;
+  int pool_cs, pool_co, write_full, tiles_per_row;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -48,7 +51,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // MODE 0: Cin % 16 == 0, float4 gathers.  MODE 1: generic scalar gather (f32).
 // MODE 2: generic scalar gather from raw u8 RGB through the normalisation LUT.
-template <int BM, int BN, int WM, int WN, int MODE, int BK = 16, int PF = 0>
+template <int BM, int BN, int WM, int WN, int MODE, int BK = 16, int PF = 0, int POOL = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfma_kernel(ConvParams p) {
   constexpr int NT = 64 * WM * WN;  // threads per block
   constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -84,21 +87,50 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
   // and no coordinate compares.
   int a_off[A_PER_T];
   unsigned a_mask[A_PER_T];
-  const float* blk_in = p.in + ((long)m0 * p.in_cs + p.in_co);
+  // tile -> pixels.  POOL == 0: BM consecutive pixels of the flattened (n,y,x) order.
+  // POOL == 1: 2 image rows x BM/2 columns in window-major order, local m = 4*q + 2*ry + cx, so
+  // that the four pixels of a 2x2 pooling window are MFMA rows 4q..4q+3 = registers r&3 of one lane.
+  long pm0;      // linear pixel index of local pixel 0
+  int y0t = 0, x0t = 0;
+  if constexpr (POOL) {
+    const int rp_lin = mt / p.tiles_per_row, cb = mt - rp_lin * p.tiles_per_row;
+    const int hh = p.H >> 1;
+    const int n = rp_lin / hh, rp = rp_lin - n * hh;
+    y0t = 2 * rp;
+    x0t = cb * (BM / 2);
+    pm0 = ((long)n * p.H + y0t) * p.W + x0t;
+  } else {
+    pm0 = m0;
+  }
+  const float* blk_in = p.in + (pm0 * p.in_cs + p.in_co);
 #pragma unroll
   for (int i = 0; i < A_PER_T; ++i) {
-    const int pm = m0 + tid / QPR + A_MSTEP * i;
+    const int ml = tid / QPR + A_MSTEP * i;
+    int rel;  // pixel index relative to pm0
+    bool inside;
+    int ox, oy;
+    if constexpr (POOL) {
+      const int ry = (ml >> 1) & 1;
+      rel = ry * p.W + 2 * (ml >> 2) + (ml & 1);
+      oy = y0t + ry;
+      ox = x0t + 2 * (ml >> 2) + (ml & 1);
+      inside = true;
+    } else {
+      rel = ml;
+      const int pm = m0 + ml;
+      inside = pm < p.Mtotal;
+      ox = pm % p.W;
+      oy = (pm / p.W) % p.H;
+    }
     unsigned mask = 0;
-    if (pm < p.Mtotal) {
-      const int ox = pm % p.W;
-      const int t = pm / p.W;
+    if (inside) {
       a_ox[i] = ox;
-      a_oy[i] = t % p.H;
-      a_pm[i] = pm;
+      a_oy[i] = oy;
+      a_pm[i] = pm0 + rel;
       if constexpr (MODE == 0) {
         for (int tap = 0; tap < p.KH * p.KW; ++tap) {
           const int ky = tap / p.KW, kx = tap - ky * p.KW;
-          const int iy = a_oy[i] + ky * p.dil - p.padh, ix = ox + kx * p.dil - p.padw;
+          const int iy = oy + ky * p.dil - p.padh, ix = ox + kx * p.dil - p.padw;
           if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << tap;
         }
       }
@@ -108,7 +140,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
       a_pm[i] = 0;
     }
     a_mask[i] = mask;
-    a_off[i] = (tid / QPR + A_MSTEP * i) * p.in_cs + quad * 4;
+    a_off[i] = rel * p.in_cs + quad * 4;
   }
   // weight-tile pointers advance by BK rows per K-step
   const float* b_ptr[B_PER_T];
@@ -274,15 +306,38 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
     const float qb = has_post ? p.post_b[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      if constexpr (POOL) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const int m = m0 + wm * WTM + i * 32 + row;
-        if (m < p.Mtotal) {
-          float v = acc[i][j][r] * pa + pb;
-          if (p.relu) v = fmaxf(v, 0.f);
-          if (has_post) v = v * qa + qb;
-          p.out[(size_t)m * p.out_cs + p.out_co + n] = v;
+        for (int g = 0; g < 4; ++g) {  // g = r>>2: one 2x2 window per register group
+          const int ml = wm * WTM + i * 32 + 8 * g + 4 * lk;  // local index of the window's first pixel
+          float best = -INFINITY;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][j][4 * g + e] * pa + pb;
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (has_post) v = v * qa + qb;
+            best = fmaxf(best, v);
+            if (p.write_full) {
+              const long pix = pm0 + (long)(e >> 1) * p.W + 2 * (ml >> 2) + (e & 1);
+              p.out[pix * p.out_cs + p.out_co + n] = v;
+            }
+          }
+          // pooled pixel: (n_img, y0t/2, x0t/2 + q)
+          const long nimg = pm0 / ((long)p.H * p.W);
+          const long pp = (nimg * (p.H >> 1) + (y0t >> 1)) * (p.W >> 1) + (x0t >> 1) + (ml >> 2);
+          p.pool_out[pp * p.pool_cs + p.pool_co + n] = best;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const int m = m0 + wm * WTM + i * 32 + row;
+          if (m < p.Mtotal) {
+            float v = acc[i][j][r] * pa + pb;
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (has_post) v = v * qa + qb;
+            p.out[(size_t)m * p.out_cs + p.out_co + n] = v;
+          }
         }
       }
     }
@@ -377,8 +432,17 @@ static bool mode_needs_bk16(const ConvLayer& L, const Tensor&) { return L.Cin % 
 
 int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8,
                 const float* lut, const Tensor& out) {
+  return launch_conv_pool(ctx, L, in, in_u8, lut, out, nullptr);
+}
+
+// Convolution with an optional fused 2x2/stride-2 max-pool epilogue.  `pool`: destination of the
+// pooled tensor (H/2 x W/2) or nullptr.  `out.p == nullptr` with a pool destination means the
+// full-resolution result is not needed.  Falls back to conv + maxpool kernel when the shape does not
+// tile (odd H, W not a multiple of 64, scalar-gather layers); the fallback needs out.p != nullptr.
+int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8,
+                     const float* lut, const Tensor& out, const Tensor* pool) {
   if (!L.ready()) KOCR_FAIL(ctx, KOCR_ENOWEIGHTS, "conv layer " + L.name + " has no weights");
-  if (in.C != L.Cin || out.C != L.Cout || in.N != out.N || in.H != out.H || in.W != out.W)
+  if (in.C != L.Cin || (out.p && (out.C != L.Cout || in.N != out.N || in.H != out.H || in.W != out.W)))
     KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": shape mismatch");
   const size_t M = in.pixels();
   if (M == 0) return KOCR_OK;
@@ -411,10 +475,12 @@ int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8
   p.Mtotal = (int)M;
   p.Kreal = L.Kreal;
   int variant = conv_variant();
-  if (variant == 8) variant = 0;
+  if (variant >= 8) variant = 0;
   if (mode_needs_bk16(L, in) && variant < 4) variant &= 1;
   const int bk = (variant == 2 || variant == 3) ? 32 : 16;
   p.nchunks = (L.Kreal + bk - 1) / bk;  // weight rows are zero padded up to Kpad (multiple of 32)
+  p.pool_out = nullptr;
+  p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
   int mode;
   if (in_u8)
     mode = 2;
@@ -422,23 +488,47 @@ int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8
     mode = 0;
   else
     mode = 1;
+  const bool fuse_pool = pool && mode == 0 && variant == 0 && L.BN >= 64 && (in.H % 2 == 0) && (in.W % 64 == 0) &&
+                         conv_variant() != 10;
+  if (pool && !fuse_pool) {  // unfused: conv to full resolution, then the pooling kernel
+    if (!out.p) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": unfused pooling needs a full-resolution buffer");
+    KOCR_TRY(launch_conv_pool(ctx, L, in, in_u8, lut, out, nullptr));
+    return launch_maxpool2x2(ctx, out, *pool);
+  }
+  if (!pool && !out.p) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": no output buffer");
+  if (fuse_pool) {
+    if (pool->H != in.H / 2 || pool->W != in.W / 2 || pool->C != L.Cout || pool->N != in.N)
+      KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": bad pooled shape");
+    p.pool_out = pool->p;
+    p.pool_cs = pool->cs;
+    p.pool_co = pool->co;
+    p.write_full = out.p != nullptr;
+    p.tiles_per_row = in.W / 64;
+  }
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   char nm[64];
   const bool big = (conv_variant() == 8) && L.BN == 128 && mode == 0 && M >= 256 * 1024;
-  const int BM = (L.BN == 128 && !big) ? 128 : 256;
+  const int BM = ((L.BN == 128 && !big) || (L.BN == 64 && conv_variant() != 9)) ? 128 : 256;
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;  // developer: one row per layer
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_%dx%d_m%d:%s", BM, L.BN, mode, L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_%dx%d_m%d%s:%s", BM, L.BN, mode, fuse_pool ? "p" : "", L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_mfma_%dx%d_m%d", BM, L.BN, mode);
+    snprintf(nm, sizeof nm, "conv_mfma_%dx%d_m%d%s", BM, L.BN, mode, fuse_pool ? "_pool" : "");
   ProfScope ps(ctx, nm, flops, bytes);
   const int mtiles = (int)((M + BM - 1) / BM);
   dim3 grid(mtiles * (L.Cout_pad / L.BN));
-  if (big)
+  if (fuse_pool) {  // BM == 128: tile = 2 rows x 64 columns; M is an exact multiple of 128
+    if (L.BN == 128)
+      hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 2, 2, 0, 16, 0, 1>), grid, dim3(256), 0, ctx->stream, p);
+    else
+      hipLaunchKernelGGL((conv_mfma_kernel<128, 64, 2, 2, 0, 16, 0, 1>), grid, dim3(256), 0, ctx->stream, p);
+  } else if (big)
     dispatch_mode<256, 128, 4, 2, 16, 0>(mode, grid, ctx->stream, p);
   else if (L.BN == 128)
     dispatch_variant<128, 128, 2, 2>(variant, mode, grid, ctx->stream, p);
+  else if (L.BN == 64 && conv_variant() != 9)
+    dispatch_mode<128, 64, 2, 2, 16, 0>(mode, grid, ctx->stream, p);
   else if (L.BN == 64)
     dispatch_variant<256, 64, 4, 1>(variant, mode, grid, ctx->stream, p);
   else

@@ -198,6 +198,16 @@ int craft_forward(kocr_ctx* ctx, const void* d_img, int dtype, int N, int H, int
     return launch_conv(ctx, net->L[name], in, nullptr, nullptr, out);
   };
 
+  // conv + 2x2 max-pool: fused epilogue when the shape tiles (even H, W % 64 == 0), else two kernels.
+  // need_full: the pre-pool tensor is consumed elsewhere (skip connection).
+  auto conv_pool = [&](const char* name, const Tensor& in, const Tensor& full, const Tensor& pooled,
+                       bool need_full) -> int {
+    const bool tiles = (in.H % 2 == 0) && (in.W % 64 == 0);
+    Tensor f = full;
+    if (tiles && !need_full) f.p = nullptr;  // the full-resolution tensor is never written
+    return launch_conv_pool(ctx, net->L[name], in, nullptr, nullptr, f, &pooled);
+  };
+
   Tensor x0;
   x0.N = N;
   x0.H = H;
@@ -230,22 +240,18 @@ int craft_forward(kocr_ctx* ctx, const void* d_img, int dtype, int N, int H, int
 
   // ---- backbone (detection.py:312-335) ------------------------------------------------
   KOCR_TRY(launch_conv(ctx, net->L["basenet.slice1.0"], x0, u8, net->d_lut, a1));
-  KOCR_TRY(conv("basenet.slice1.3", a1, a2));
-  KOCR_TRY(launch_maxpool2x2(ctx, a2, p1));
+  KOCR_TRY(conv_pool("basenet.slice1.3", a1, a2, p1, /*need_full=*/false));
   KOCR_TRY(conv("basenet.slice1.7", p1, b1));
   const Tensor s1 = cat4.slice(64, 128);
-  KOCR_TRY(conv("basenet.slice1.10", b1, s1));
-  KOCR_TRY(launch_maxpool2x2(ctx, s1, p2));
+  KOCR_TRY(conv_pool("basenet.slice1.10", b1, s1, p2, /*need_full=*/true));  // s1 is a skip tensor
   KOCR_TRY(conv("basenet.slice2.14", p2, c1));
   const Tensor s2 = cat3.slice(128, 256);
   KOCR_TRY(conv("basenet.slice2.17", c1, s2));
-  KOCR_TRY(conv("basenet.slice3.20", s2, c3));
-  KOCR_TRY(launch_maxpool2x2(ctx, c3, p3));
+  KOCR_TRY(conv_pool("basenet.slice3.20", s2, c3, p3, false));
   KOCR_TRY(conv("basenet.slice3.24", p3, e1));
   const Tensor s3 = cat2.slice(256, 512);
   KOCR_TRY(conv("basenet.slice3.27", e1, s3));
-  KOCR_TRY(conv("basenet.slice4.30", s3, f1));
-  KOCR_TRY(launch_maxpool2x2(ctx, f1, p4));
+  KOCR_TRY(conv_pool("basenet.slice4.30", s3, f1, p4, false));
   KOCR_TRY(conv("basenet.slice4.34", p4, g1));
   const Tensor s4 = cat1.slice(1024, 512);
   KOCR_TRY(conv("basenet.slice4.37", g1, s4));

@@ -18,7 +18,9 @@ def craft_ctx(ctx, craft_weights):
     return ctx
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 96, 80), (1, 50, 70), (3, 32, 48)])
+# (1, 64, 512): every pooled layer takes the fused conv+maxpool epilogue (W/8 = 64); the other
+# shapes mix fused and unfused levels, odd sizes exercise the floor-pooling fallback
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 96, 80), (1, 50, 70), (3, 32, 48), (1, 64, 512), (2, 32, 128)])
 def test_heatmap_f32_input(craft_ctx, craft_weights, shape):
     from oracle import craft as ocraft
 

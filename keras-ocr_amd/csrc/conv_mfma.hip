@@ -41,6 +41,7 @@ struct ConvParams {
   // fused 2x2/stride-2 max-pool epilogue (POOL kernels): tile = 2 image rows x BM/2 columns
   float* pool_out;
   int pool_cs, pool_co, write_full, tiles_per_row;
+  int stagger;  // s_sleep units per stagger step (0 = off)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -267,6 +268,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
     }
   };
 
+  if (p.stagger) {
+    // de-correlate the co-resident workgroups of a CU: identical blocks launched together otherwise
+    // run their MFMA and non-MFMA phases in lockstep and the matrix pipe idles in the gaps
+    const int s4 = (blockIdx.x >> 8) & 3;
+    for (int i = 0; i < s4 * p.stagger; ++i) __builtin_amdgcn_s_sleep(8);  // ~512 cycles per unit
+  }
   load_chunk(0);
   store_chunk(0);
   __syncthreads();
@@ -480,6 +487,10 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
   const int bk = (variant == 2 || variant == 3) ? 32 : 16;
   p.nchunks = (L.Kreal + bk - 1) / bk;  // weight rows are zero padded up to Kpad (multiple of 32)
   p.pool_out = nullptr;
+  {
+    static const int stg = getenv("KOCR_CONV_STAGGER") ? atoi(getenv("KOCR_CONV_STAGGER")) : 0;
+    p.stagger = stg;
+  }
   p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
   int mode;
   if (in_u8)

@@ -111,3 +111,39 @@ def test_recognizer_single_image_api(pipe):
     s2 = pipe.recognizer.recognize(img2)
     box = np.array([[0, 0], [200, 0], [200, 31], [0, 31]], np.float32)
     assert s2 == pipe.recognizer.recognize_from_boxes([img2], [box[None]])[0][0]
+
+
+def test_device_resident_batch_equals_host_batch(pipe):
+    """recognize_device (pointers into HBM, what bench.py times) == recognize (host arrays)."""
+    import torch
+
+    pages = np.stack([synth.text_page(96, 128, 5, seed=31), synth.text_page(96, 128, 6, seed=32)])
+    host = pipe.recognize(pages)
+    t = torch.from_numpy(pages).cuda()
+    dev = pipe.recognize_device(t.data_ptr(), 2, 96, 128)
+    assert len(host) == len(dev) == 2
+    for a, b in zip(host, dev):
+        assert [x[0] for x in a] == [x[0] for x in b]
+        assert all(np.array_equal(x[1], y[1]) for x, y in zip(a, b))
+
+
+def test_non_integer_scale_and_mixed_sizes(pipe, calibrated, crnn_weights):
+    """BASELINE cfg5's regime in miniature: scale capped by max_size (x4/3, the non-exact cv2.resize
+    path) and images of different sizes padded to the batch maximum with 255 (pipeline.py:48-57)."""
+    import keras_ocr_amd
+    from oracle import pipeline as opipe
+
+    p2 = keras_ocr_amd.pipeline.Pipeline(detector=pipe.detector, recognizer=pipe.recognizer, scale=3, max_size=160)
+    pages = [synth.text_page(120, 96, 5, seed=41), synth.text_page(90, 120, 4, seed=42)]
+    got = p2.recognize(pages)
+    want = opipe.recognize(calibrated, crnn_weights, pages, scale=3, max_size=160)
+    assert sum(abs(len(g) - len(w_)) for g, w_ in zip(got, want)) <= 1
+    n_match = n_total = 0
+    for g, w_ in zip(got, want):
+        for text, box in g:
+            n_total += 1
+            d = [float(np.abs(box - b).max()) for _, b in w_]
+            if d and min(d) <= 1e-3:
+                n_match += 1
+                assert text == w_[int(np.argmin(d))][0]
+    assert n_total == 0 or n_match >= 0.8 * n_total

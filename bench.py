@@ -171,8 +171,9 @@ def main():
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
         if cands:
             pm = json.load(open(cands[-1]))
+            want = "void conv_mfma_kernel<128, 128, 2, 2, 0, 16, 0, %d>" % (1 if name.endswith("_pool") else 0)
             for kname, row in pm["kernels"].items():
-                if kname.startswith("void conv_mfma_kernel<128, 128") and "hbm_bytes_per_launch" in row:
+                if kname.startswith(want) and "hbm_bytes_per_launch" in row:
                     traffic = row["hbm_bytes_per_launch"]
                     traffic_src = "profiles/" + os.path.basename(cands[-1]) + f", average over {row['launches']} launches of the bench process"
                     break

@@ -64,6 +64,7 @@ struct ConvLayer {
   float* d_post_a = nullptr;  // [Cout_pad] or nullptr: out = relu?(v)*post_a + post_b
   float* d_post_b = nullptr;
   int relu = 0;
+  bool tap_inner = false;  // K order [16-channel group][tap][16] (Cin % 16 == 0) instead of [tap][Cin]
   bool ready() const { return d_w != nullptr; }
 };
 

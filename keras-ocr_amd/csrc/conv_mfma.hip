@@ -42,6 +42,7 @@ struct ConvParams {
   float* pool_out;
   int pool_cs, pool_co, write_full, tiles_per_row;
   int stagger;  // s_sleep units per stagger step (0 = off)
+  int tap_inner, ntaps;  // K order: k = ((c/16)*ntaps + tap)*16 + c%16 (vector-gather layers)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -157,9 +158,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
 
   auto load_chunk = [&](int ch) {
     if constexpr (MODE == 0) {
-      const int cpt = p.Cin / BK;  // chunks per tap
-      const int tap = ch / cpt;
-      const int c0 = (ch - tap * cpt) * BK;
+      // K order = [16-channel group][tap][16]: the 9 taps of one channel group re-read (shifted by a
+      // pixel) the same 64-B pieces back to back, so taps 2..9 hit L1/L2 instead of HBM/MALL
+      const int cg = ch / p.ntaps;
+      const int tap = ch - cg * p.ntaps;
+      const int c0 = cg * BK;
       const int ky = tap / p.KW, kx = tap - ky * p.KW;
       const int dy = ky * p.dil - p.padh, dx = kx * p.dil - p.padw;
       const int tap_off = (dy * p.W + dx) * p.in_cs + c0;  // wave-uniform
@@ -179,8 +182,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
           const int k = ch * BK + quad * 4 + q;
           float v = 0.f;
           if (k < p.Kreal) {
-            const int tap = k / p.Cin;
-            const int c = k - tap * p.Cin;
+            int tap, c;
+            if (p.tap_inner) {
+              const int cg = k / (16 * p.ntaps), rem = k - cg * 16 * p.ntaps;
+              tap = rem >> 4;
+              c = cg * 16 + (rem & 15);
+            } else {
+              tap = k / p.Cin;
+              c = k - tap * p.Cin;
+            }
             const int ky = tap / p.KW, kx = tap - ky * p.KW;
             const int dy = ky * p.dil - p.padh, dx = kx * p.dil - p.padw;
             const int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
@@ -366,6 +376,7 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
   L.dil = dil;
   L.relu = relu;
   L.Kreal = KH * KW * Cin;
+  L.tap_inner = (Cin % 16 == 0);
   L.Kpad = round_up(L.Kreal, 32);
   L.BN = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
   L.Cout_pad = round_up(Cout, L.BN);
@@ -376,7 +387,9 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
         for (int o = 0; o < Cout; ++o) {
           const float v = w_is_oihw ? w[(((size_t)o * Cin + c) * KH + ky) * KW + kx]
                                     : w[(((size_t)ky * KW + kx) * Cin + c) * Cout + o];
-          wp[(size_t)((ky * KW + kx) * Cin + c) * L.Cout_pad + o] = v;
+          const int tap = ky * KW + kx;
+          const size_t row = L.tap_inner ? (size_t)((c / 16) * KH * KW + tap) * 16 + (c % 16) : (size_t)tap * Cin + c;
+          wp[row * L.Cout_pad + o] = v;
         }
   KOCR_TRY(ctx->upload(&L.d_w, wp));
   std::vector<float> a(L.Cout_pad, 1.f), b(L.Cout_pad, 0.f);
@@ -424,8 +437,6 @@ template <int BM, int BN, int WM, int WN>
 static void dispatch_variant(int variant, int mode, dim3 grid, hipStream_t s, const ConvParams& p) {
   switch (variant) {
     case 1: dispatch_mode<BM, BN, WM, WN, 16, 1>(mode, grid, s, p); break;
-    case 2: dispatch_mode<BM, BN, WM, WN, 32, 0>(mode, grid, s, p); break;
-    case 3: dispatch_mode<BM, BN, WM, WN, 32, 1>(mode, grid, s, p); break;
     case 4: dispatch_mode<BM, BN, WM, WN, 16, 2>(mode, grid, s, p); break;  // ablation: no global loads
     case 5: dispatch_mode<BM, BN, WM, WN, 16, 3>(mode, grid, s, p); break;  // ablation: MFMA + LDS reads only
     case 6: dispatch_mode<BM, BN, WM, WN, 16, 4>(mode, grid, s, p); break;  // ablation: no LDS stores
@@ -484,9 +495,12 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
   int variant = conv_variant();
   if (variant >= 8) variant = 0;
   if (mode_needs_bk16(L, in) && variant < 4) variant &= 1;
-  const int bk = (variant == 2 || variant == 3) ? 32 : 16;
+  if (variant == 2 || variant == 3) variant = 0;  // BK=32 retired: the K order is built on 16-channel groups
+  const int bk = 16;
   p.nchunks = (L.Kreal + bk - 1) / bk;  // weight rows are zero padded up to Kpad (multiple of 32)
   p.pool_out = nullptr;
+  p.tap_inner = L.tap_inner ? 1 : 0;
+  p.ntaps = L.KH * L.KW;
   {
     static const int stg = getenv("KOCR_CONV_STAGGER") ? atoi(getenv("KOCR_CONV_STAGGER")) : 0;
     p.stagger = stg;

@@ -61,3 +61,15 @@ def test_forward_before_load_fails_loudly():
     with pytest.raises(keras_ocr_amd.KocrError):
         c.craft_forward(np.zeros((1, 32, 32, 3), np.uint8))
     c.close()
+
+
+def test_heatmap_at_baseline_cfg2_size(craft_ctx, craft_weights):
+    """One 768x768 image (BASELINE configs[1] resolution) against the oracle."""
+    from oracle import craft as ocraft
+    from tests import synth
+
+    img = synth.text_page(768, 768, 25, seed=77)[None]
+    got = craft_ctx.craft_forward(img)
+    want = ocraft.detector_predict(craft_weights, img)
+    err = float(np.abs(got - want).max())
+    assert err <= HEAT_TOL, f"max abs heat-map error {err}"

@@ -156,22 +156,35 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
   v4f ra[A_PER_T];
   v4f rb[B_PER_T];
 
+  int ld_tap = 0, ld_kx = 0, ld_dy = -p.padh, ld_dx = -p.padw, ld_c0 = 0;
   auto load_chunk = [&](int ch) {
     if constexpr (MODE == 0) {
       // K order = [16-channel group][tap][16]: the 9 taps of one channel group re-read (shifted by a
       // pixel) the same 64-B pieces back to back, so taps 2..9 hit L1/L2 instead of HBM/MALL
-      const int cg = ch / p.ntaps;
-      const int tap = ch - cg * p.ntaps;
-      const int c0 = cg * BK;
-      const int ky = tap / p.KW, kx = tap - ky * p.KW;
-      const int dy = ky * p.dil - p.padh, dx = kx * p.dil - p.padw;
-      const int tap_off = (dy * p.W + dx) * p.in_cs + c0;  // wave-uniform
+      // (ld_tap, ld_kx, ld_dy, ld_dx, ld_c0) walk the K order incrementally: chunks are always
+      // requested in order 0,1,2,... so no division is needed in the steady state
+      (void)ch;
+      const int tap = ld_tap;
+      const int tap_off = (ld_dy * p.W + ld_dx) * p.in_cs + ld_c0;  // wave-uniform
 #pragma unroll
       for (int i = 0; i < A_PER_T; ++i) {
         const bool ok = (a_mask[i] >> tap) & 1u;
         const int off = ok ? a_off[i] + tap_off : 0;  // offset 0 = the block's first pixel: always mapped
         v4f v = *reinterpret_cast<const v4f*>(blk_in + off);
         ra[i] = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
+      }
+      if (++ld_tap == p.ntaps) {
+        ld_tap = 0;
+        ld_kx = 0;
+        ld_dy = -p.padh;
+        ld_dx = -p.padw;
+        ld_c0 += BK;
+      } else if (++ld_kx == p.KW) {
+        ld_kx = 0;
+        ld_dx = -p.padw;
+        ld_dy += p.dil;
+      } else {
+        ld_dx += p.dil;
       }
     } else {
 #pragma unroll

@@ -16,6 +16,7 @@
 // blockIdx -> tile mapping is XCD-aware: each XCD (private L2) gets a contiguous range of
 // tiles, n-tile fastest, so the A halo and the weight panel are re-read from the same L2.
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // native clang vector (HIP's float4 wrapper struct defeats SROA for arrays captured by lambdas
@@ -49,6 +50,28 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int xcd = bid & 7;
   const int q = nwg >> 3, r = nwg & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// Position in the K order [16-channel group][tap][16] of the vector-gather path, advanced one
+// K-step at a time (no divisions in the steady state).
+struct TapWalk {
+  int tap, kx, dy, dx, c0;
+};
+__device__ __forceinline__ TapWalk walk_next(TapWalk w, const ConvParams& p, int bk) {
+  if (++w.tap == p.ntaps) {
+    w.tap = 0;
+    w.kx = 0;
+    w.dy = -p.padh;
+    w.dx = -p.padw;
+    w.c0 += bk;
+  } else if (++w.kx == p.KW) {
+    w.kx = 0;
+    w.dx = -p.padw;
+    w.dy += p.dil;
+  } else {
+    w.dx += p.dil;
+  }
+  return w;
 }
 
 // MODE 0: Cin % 16 == 0, float4 gathers.  MODE 1: generic scalar gather (f32).
@@ -153,39 +176,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
     b_ptr[j] = p.wgt + (size_t)krow * p.Cout_pad + n0 + nc * 4;
   }
 
-  v4f ra[A_PER_T];
-  v4f rb[B_PER_T];
+  // staging registers; PF == 1 keeps two K-steps in flight (prefetch distance 2)
+  v4f ra0[A_PER_T], rb0[B_PER_T];
+  v4f ra1[(PF == 1) ? A_PER_T : 1], rb1[(PF == 1) ? B_PER_T : 1];
 
-  int ld_tap = 0, ld_kx = 0, ld_dy = -p.padh, ld_dx = -p.padw, ld_c0 = 0;
-  auto load_chunk = [&](int ch) {
+  TapWalk walk{0, 0, -p.padh, -p.padw, 0};
+  auto load_chunk = [&](int ch, v4f* __restrict__ ra, v4f* __restrict__ rb) __attribute__((always_inline)) {
     if constexpr (MODE == 0) {
       // K order = [16-channel group][tap][16]: the 9 taps of one channel group re-read (shifted by a
       // pixel) the same 64-B pieces back to back, so taps 2..9 hit L1/L2 instead of HBM/MALL
-      // (ld_tap, ld_kx, ld_dy, ld_dx, ld_c0) walk the K order incrementally: chunks are always
-      // requested in order 0,1,2,... so no division is needed in the steady state
+      // `walk` follows the K order incrementally: chunks are always requested in order 0,1,2,...
       (void)ch;
-      const int tap = ld_tap;
-      const int tap_off = (ld_dy * p.W + ld_dx) * p.in_cs + ld_c0;  // wave-uniform
+      const TapWalk w = walk;
+      const int tap_off = (w.dy * p.W + w.dx) * p.in_cs + w.c0;  // wave-uniform
 #pragma unroll
       for (int i = 0; i < A_PER_T; ++i) {
-        const bool ok = (a_mask[i] >> tap) & 1u;
+        const bool ok = (a_mask[i] >> w.tap) & 1u;
         const int off = ok ? a_off[i] + tap_off : 0;  // offset 0 = the block's first pixel: always mapped
         v4f v = *reinterpret_cast<const v4f*>(blk_in + off);
         ra[i] = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
       }
-      if (++ld_tap == p.ntaps) {
-        ld_tap = 0;
-        ld_kx = 0;
-        ld_dy = -p.padh;
-        ld_dx = -p.padw;
-        ld_c0 += BK;
-      } else if (++ld_kx == p.KW) {
-        ld_kx = 0;
-        ld_dx = -p.padw;
-        ld_dy += p.dil;
-      } else {
-        ld_dx += p.dil;
-      }
+      walk = walk_next(w, p, BK);
     } else {
 #pragma unroll
       for (int i = 0; i < A_PER_T; ++i) {
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
     }
   };
 
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, const v4f* __restrict__ ra, const v4f* __restrict__ rb) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
       const int m = tid / QPR + A_MSTEP * i;
@@ -252,7 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute_chunk = [&](int buf) {
-    if constexpr (PF == 1) {
+    if constexpr (PF == 99) {
       // operand fragments of k-pair kp+1 are fetched from LDS before the MFMAs of k-pair kp issue
       float a[2][TM], b[2][TN];
 #pragma unroll
@@ -297,30 +308,53 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
     const int s4 = (blockIdx.x >> 8) & 3;
     for (int i = 0; i < s4 * p.stagger; ++i) __builtin_amdgcn_s_sleep(8);  // ~512 cycles per unit
   }
-  load_chunk(0);
-  store_chunk(0);
+  load_chunk(0, ra0, rb0);
+  store_chunk(0, ra0, rb0);
   __syncthreads();
 
-  // steady state: no conditionals around the staging registers (a branch here makes hipcc park
-  // the prefetched B tile in scratch and wait for the loads before the MFMAs)
   const int nch = p.nchunks;
-  for (int ch = 0; ch + 1 < nch; ++ch) {
-    const int buf = ch & 1;
-    if constexpr (PF < 2 || PF >= 4) load_chunk(ch + 1);
-    // keep the prefetch loads ahead of the MFMAs: without this fence hipcc sinks the weight-tile
-    // loads to just before their LDS store and the wave eats the full L2 latency every K-step
-    __builtin_amdgcn_sched_barrier(0);
-    compute_chunk(buf);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (PF == 4) {  // ablation: loads + barrier, no LDS stores (keep the loads live)
-      for (int i = 0; i < A_PER_T; ++i) asm volatile("" ::"v"(ra[i]));
-      for (int j = 0; j < B_PER_T; ++j) asm volatile("" ::"v"(rb[j]));
+  if constexpr (PF == 1) {
+    // prefetch distance 2: while K-step ch is on the matrix cores, K-step ch+1 sits in one register
+    // set (stored to LDS at the end of the step) and K-step ch+2 is being loaded into the other
+    if (nch > 1) load_chunk(1, ra0, rb0);
+    int ch = 0;
+    while (ch + 1 < nch) {
+      if (ch + 2 < nch) load_chunk(ch + 2, ra1, rb1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_chunk(ch & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      store_chunk((ch + 1) & 1, ra0, rb0);
       __syncthreads();
-    } else if constexpr (PF == 5) {  // ablation: loads + LDS stores, no barrier
-      store_chunk(buf ^ 1);
-    } else if constexpr (PF != 3) {
-      store_chunk(buf ^ 1);
+      ++ch;
+      if (!(ch + 1 < nch)) break;
+      if (ch + 2 < nch) load_chunk(ch + 2, ra0, rb0);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_chunk(ch & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      store_chunk((ch + 1) & 1, ra1, rb1);
       __syncthreads();
+      ++ch;
+    }
+  } else {
+    // steady state: no conditionals around the staging registers
+    for (int ch = 0; ch + 1 < nch; ++ch) {
+      const int buf = ch & 1;
+      if constexpr (PF < 2 || PF >= 4) load_chunk(ch + 1, ra0, rb0);
+      // keep the prefetch loads ahead of the MFMAs: without this fence hipcc sinks the weight-tile
+      // loads to just before their LDS store and the wave eats the full L2 latency every K-step
+      __builtin_amdgcn_sched_barrier(0);
+      compute_chunk(buf);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (PF == 4) {  // ablation: loads + barrier, no LDS stores (keep the loads live)
+        for (int i = 0; i < A_PER_T; ++i) asm volatile("" ::"v"(ra0[i]));
+        for (int j = 0; j < B_PER_T; ++j) asm volatile("" ::"v"(rb0[j]));
+        __syncthreads();
+      } else if constexpr (PF == 5) {  // ablation: loads + LDS stores, no barrier
+        store_chunk(buf ^ 1, ra0, rb0);
+      } else if constexpr (PF != 3) {
+        store_chunk(buf ^ 1, ra0, rb0);
+        __syncthreads();
+      }
     }
   }
   compute_chunk((nch - 1) & 1);

@@ -157,6 +157,20 @@ def main():
         if d["launches"]:
             prof[kk] = d
 
+    # secondary BASELINE metric: ms/crop of the CRNN alone (configs[2]: 512 pre-cropped 31x200 strips)
+    crnn_us_per_crop = None
+    if rank == 0:
+        m = 512
+        crops = torch.rand((m, 31, 200), dtype=torch.float32, device="cuda")
+        labels = torch.empty((m, 48), dtype=torch.int32, device="cuda")
+        ctx.crnn_forward_device(crops.data_ptr(), m, labels.data_ptr())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ctx.crnn_forward_device(crops.data_ptr(), m, labels.data_ptr())
+        torch.cuda.synchronize()
+        crnn_us_per_crop = (time.perf_counter() - t1) / 3 / m * 1e6
+
     if rank == 0:
         dom = max((kv for kv in prof.items() if kv[0].startswith("conv_mfma")), key=lambda kv: kv[1]["ms"])
         name, r = dom
@@ -204,6 +218,9 @@ def main():
                          "launches_process": prof_all[name]["launches"],
                          "all_conv_tflops": conv_fl / (conv_ms * 1e-3) / 1e12},
             "stage_ms_per_step": stage_ms,
+            "crnn_only": {"metric": "ms/crop CRNN (BASELINE configs[2]: 512 crops 31x200, CTC greedy)",
+                          "value": crnn_us_per_crop / 1e3, "unit": "ms/crop",
+                          "fp32_mfma_floor_ms": 13.444e9 / (FP32_MFMA_PEAK_TF * 1e12) * 1e3},
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(craft_w, crnn_w, pages[0])

@@ -10,11 +10,22 @@
 //   D           v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD), fp32 accumulate
 //   epilogue    out = post_a * relu?(pre_a*acc + pre_b) + post_b   (bias + folded BN)
 //
-// Block = 256 threads = 4 waves; block tile BM x BN, K-step 16; register-staged global
-// loads (float4, 64 B contiguous per pixel) into a double-buffered k-major LDS image so
-// that both MFMA operand reads are conflict-free ds_read_b32 (lane -> consecutive m / n).
-// blockIdx -> tile mapping is XCD-aware: each XCD (private L2) gets a contiguous range of
-// tiles, n-tile fastest, so the A halo and the weight panel are re-read from the same L2.
+// Block = 256 threads = 4 waves; block tile 128x128 (Cout > 64), 128x64 (Cout <= 64) or 256x32
+// (Cout <= 32); K-step 16.  K order for Cin % 16 == 0: [16-channel group][tap][16] — the taps of
+// one channel group re-read the same 64-B pieces shifted by a pixel, so they hit L1/L2 (measured:
+// 2.7x less L2-miss traffic than tap-major).  A is gathered with float4 loads through 32-bit
+// block-relative offsets and a per-pixel tap-validity bit mask (no 64-bit multiplies, no coordinate
+// compares, no divisions in the K loop), register-staged one K-step ahead into a double-buffered
+// k-major LDS image so that both MFMA operand reads are conflict-free ds_read_b32 (lane ->
+// consecutive m / n); one barrier per K-step.  blockIdx -> tile mapping is XCD-aware: each XCD
+// (private L2) gets a contiguous range of tiles, n-tile fastest.  POOL kernels fuse the following
+// 2x2/stride-2 max-pool: the tile is 2 image rows x 64 columns in window-major order, so the four
+// pixels of a pooling window are the four r&3 accumulator registers of one lane.
+//
+// Measured on MI355X (profiles/): 125 TFLOP/s = 79 % of the 157.3 TF fp32 MFMA peak on the
+// 128x128 instances inside the pipeline, matrix pipe busy 80 % at 2.38 GHz, 3.8 waves/SIMD.
+// KOCR_CONV_VARIANT selects developer A/B variants (distance-2 prefetch, 8-wave 256x128 tile,
+// ablations); the default is variant 0.
 #include "common.h"
 #include <type_traits>
 
@@ -263,29 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute_chunk = [&](int buf) {
-    if constexpr (PF == 99) {
-      // operand fragments of k-pair kp+1 are fetched from LDS before the MFMAs of k-pair kp issue
-      float a[2][TM], b[2][TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[0][i] = As[buf][lk][wm * WTM + i * 32 + lr];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[0][j] = Bs[buf][lk][wn * WTN + j * 32 + lr];
-#pragma unroll
-      for (int kp = 0; kp < BK / 2; ++kp) {
-        const int cur = kp & 1, nxt = cur ^ 1;
-        if (kp + 1 < BK / 2) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i) a[nxt][i] = As[buf][2 * kp + 2 + lk][wm * WTM + i * 32 + lr];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) b[nxt][j] = Bs[buf][2 * kp + 2 + lk][wn * WTN + j * 32 + lr];
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
-      }
-    } else {
+    {
 #pragma unroll
       for (int kp = 0; kp < BK / 2; ++kp) {
         float a[TM], b[TN];

@@ -64,6 +64,8 @@ struct ConvLayer {
   float* d_post_a = nullptr;  // [Cout_pad] or nullptr: out = relu?(v)*post_a + post_b
   float* d_post_b = nullptr;
   int relu = 0;
+  float* d_wino = nullptr;    // Winograd F(2,3) weights U[Cin/16][3][4][16][wino_cout_pad] (3x3, dil 1, Cin%16==0)
+  int wino_cout_pad = 0;
   bool tap_inner = false;  // K order [16-channel group][tap][16] (Cin % 16 == 0) instead of [tap][Cin]
   bool ready() const { return d_w != nullptr; }
 };
@@ -153,7 +155,11 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
 int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8,
                 const float* lut, const Tensor& out);
 int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8,
-                     const float* lut, const Tensor& out, const Tensor* pool);
+                     const float* lut, const Tensor& out, const Tensor* pool, bool need_full = true);
+// conv_wino.hip
+int prepare_wino(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
+bool wino_applicable(const ConvLayer& L, const Tensor& in);
+int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out);
 // elementwise.hip
 int launch_maxpool2x2(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
 int launch_maxpool3x3s1(kocr_ctx* ctx, const Tensor& in, const Tensor& out);

@@ -428,6 +428,7 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
           wp[row * L.Cout_pad + o] = v;
         }
   KOCR_TRY(ctx->upload(&L.d_w, wp));
+  KOCR_TRY(prepare_wino(ctx, L, w, w_is_oihw));
   std::vector<float> a(L.Cout_pad, 1.f), b(L.Cout_pad, 0.f);
   for (int o = 0; o < Cout; ++o) {
     if (pre_a) a[o] = pre_a[o];
@@ -491,12 +492,13 @@ int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8
 
 // Convolution with an optional fused 2x2/stride-2 max-pool epilogue.  `pool`: destination of the
 // pooled tensor (H/2 x W/2) or nullptr.  `out.p == nullptr` with a pool destination means the
-// full-resolution result is not needed.  Falls back to conv + maxpool kernel when the shape does not
-// tile (odd H, W not a multiple of 64, scalar-gather layers); the fallback needs out.p != nullptr.
+// full-resolution result is not needed (need_full == false lets the fused epilogue skip writing it).
+// Falls back to conv + maxpool kernel when the shape does not tile (odd H, W not a multiple of 64,
+// scalar-gather layers); `out` must always be a real buffer.
 int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8,
-                     const float* lut, const Tensor& out, const Tensor* pool) {
+                     const float* lut, const Tensor& out, const Tensor* pool, bool need_full) {
   if (!L.ready()) KOCR_FAIL(ctx, KOCR_ENOWEIGHTS, "conv layer " + L.name + " has no weights");
-  if (in.C != L.Cin || (out.p && (out.C != L.Cout || in.N != out.N || in.H != out.H || in.W != out.W)))
+  if (in.C != L.Cin || out.C != L.Cout || in.N != out.N || in.H != out.H || in.W != out.W)
     KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": shape mismatch");
   const size_t M = in.pixels();
   if (M == 0) return KOCR_OK;
@@ -551,26 +553,30 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
     mode = 1;
   const bool fuse_pool = pool && mode == 0 && variant == 0 && L.BN >= 64 && (in.H % 2 == 0) && (in.W % 64 == 0) &&
                          conv_variant() != 10;
+  if (!out.p) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": no output buffer");
+  const bool wino = !in_u8 && variant == 0 && conv_variant() == 0 && wino_applicable(L, in);
+  if (wino) {  // 1-D Winograd F(2,3): 2/3 of the MFMA work; pooling (if any) as a separate pass
+    KOCR_TRY(launch_conv_wino(ctx, L, in, out));
+    return pool ? launch_maxpool2x2(ctx, out, *pool) : KOCR_OK;
+  }
   if (pool && !fuse_pool) {  // unfused: conv to full resolution, then the pooling kernel
-    if (!out.p) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": unfused pooling needs a full-resolution buffer");
     KOCR_TRY(launch_conv_pool(ctx, L, in, in_u8, lut, out, nullptr));
     return launch_maxpool2x2(ctx, out, *pool);
   }
-  if (!pool && !out.p) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": no output buffer");
   if (fuse_pool) {
     if (pool->H != in.H / 2 || pool->W != in.W / 2 || pool->C != L.Cout || pool->N != in.N)
       KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": bad pooled shape");
     p.pool_out = pool->p;
     p.pool_cs = pool->cs;
     p.pool_co = pool->co;
-    p.write_full = out.p != nullptr;
+    p.write_full = need_full ? 1 : 0;
     p.tiles_per_row = in.W / 64;
   }
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   char nm[64];
   const bool big = (conv_variant() == 8) && L.BN == 128 && mode == 0 && M >= 256 * 1024;
-  const int BM = ((L.BN == 128 && !big) || (L.BN == 64 && conv_variant() != 9)) ? 128 : 256;
+  const int BM = ((L.BN == 128 && !big) || (L.BN == 64 && conv_variant() != 9) || (L.BN == 32 && conv_variant() != 12)) ? 128 : 256;
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;  // developer: one row per layer
   if (per_layer)
     snprintf(nm, sizeof nm, "conv_%dx%d_m%d%s:%s", BM, L.BN, mode, fuse_pool ? "p" : "", L.name.c_str());
@@ -592,6 +598,8 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
     dispatch_mode<128, 64, 2, 2, 16, 0>(mode, grid, ctx->stream, p);
   else if (L.BN == 64)
     dispatch_variant<256, 64, 4, 1>(variant, mode, grid, ctx->stream, p);
+  else if (conv_variant() != 12)
+    dispatch_mode<128, 32, 4, 1, 16, 0>(mode, grid, ctx->stream, p);
   else
     dispatch_variant<256, 32, 4, 1>(variant, mode, grid, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());

@@ -1,0 +1,275 @@
+// conv_wino.hip — 3x3 / stride 1 / dilation 1 convolution with 1-D Winograd F(2,3) along image
+// rows, on the gfx950 matrix cores (fp32 MFMA 16x16x4).
+//
+// Same operator as conv_mfma.hip (keras Conv2D 3x3 'same' + folded BN + ReLU, detection.py:87-103)
+// with 2/3 of the matrix-core work: for an output pair (x0, x0+1) of row y and every (ky, c)
+//     d_i = in[y+ky-1][x0-1+i][c],  i = 0..3            (zero outside the image)
+//     m0 = (d0-d2) g0,  m1 = (d1+d2)(g0+g1+g2)/2,  m2 = (d2-d1)(g0-g1+g2)/2,  m3 = (d1-d3) g2
+//     out[x0] = sum(m0+m1+m2),  out[x0+1] = sum(m1-m2-m3)
+// i.e. four GEMMs  M_xi[pair][o] = sum_{ky,c} V_xi[pair][(ky,c)] * U_xi[(ky,c)][o]  instead of the
+// direct [pixel] x [9*Cin] x [Cout] one: 4 multiplies per 2 outputs instead of 6 per (ky,c,o).
+// The transform coefficients are +-1 and +-1/2, so the fp32 error stays at round-off level
+// (tests bound it with the same tolerance as the direct kernel).
+//
+// Block = 256 threads = 4 waves; tile = 128 consecutive pixels of one image row (64 pairs) x 64
+// output channels; K-step = one (16-channel group, ky) = 16 k.  The RAW input row piece (130 px x
+// 16 ch) is staged k-major in LDS; every wave reads two aligned 8-B pieces (d0,d1),(d2,d3) per pair
+// and forms the four V_xi values in registers (the transformed tile is never stored).  Wave w owns
+// output channels [16w,16w+16) for ALL four points, so the inverse transform in the epilogue is
+// register-only: the 16x16x4 MFMA C/D map puts M_0..M_3 of one (pair, channel) in the same lane.
+// U_xi is pre-transformed on the host, packed [16-channel group][ky][xi][16][Cout_pad], and staged
+// wave-private in LDS.  Requires W % 128 == 0 (a tile never crosses an image row).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct WinoParams {
+  const float* in;
+  const float* wgt;  // U: [Cin/16][3][4][16][Cout_pad]
+  float* out;
+  const float* pre_a;
+  const float* pre_b;
+  const float* post_a;
+  const float* post_b;
+  int H, W, Cin, in_cs, in_co;
+  int Cout, Cout_pad, out_cs, out_co;
+  int relu;
+  int nsteps;  // 3 * Cin / 16
+};
+
+namespace {
+constexpr int LDA = 160;  // floats per k row of the raw tile (130 used); 160*4 B = 128 mod 256 -> the two
+                          // k rows a 32-lane ds_read_b64 group touches fall into different bank halves
+}
+
+__device__ __forceinline__ int wino_xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
+  __shared__ float As[2][16][LDA];        // raw input: As[buf][k][1 + pixel], pixel = -1 .. 128
+  __shared__ float Bs[2][4][4][16][16];   // Bs[buf][wave][xi][k][n]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  const int nblk_n = p.Cout_pad >> 6;
+  const int tile = wino_xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = tile / nblk_n, nt = tile - mt * nblk_n;
+  const long pm0 = (long)mt * 128;  // first pixel (flattened n,y,x); W % 128 == 0 -> one image row
+  const int x0t = (int)(pm0 % p.W);
+  const int y0 = (int)((pm0 / p.W) % p.H);
+  const int n0 = nt * 64;
+
+  // ---- gather mapping: items = (pixel -1..128) x (4 channel quads): 520 float4 per K-step ----------
+  // items 0..511: pixel = item/4 - 1 + ... laid out so that a wave reads 16 pixels x 64 B
+  const int quad = tid & 3;
+  const int px_a = (tid >> 2);        // 0..63   -> pixels px_a - 1
+  const int px_b = (tid >> 2) + 64;   // 64..127 -> pixels px_b - 1
+  // the two right-most pixels (127, 128) x 4 quads are fetched by threads 0..7 as a third item
+  const int px_c = 128 + (tid >> 2);  // valid for tid < 8: indices 128, 129 -> pixels 127, 128
+  const bool has_c = tid < 8;
+  auto px_ok = [&](int idx) { const int x = x0t + idx - 1; return x >= 0 && x < p.W; };
+  const bool ok_a = px_ok(px_a), ok_b = px_ok(px_b), ok_c = has_c && px_ok(px_c);
+  const float* blk_in = p.in + (pm0 * p.in_cs + p.in_co);
+  const int off_a = (px_a - 1) * p.in_cs + quad * 4;
+  const int off_b = (px_b - 1) * p.in_cs + quad * 4;
+  const int off_c = (px_c - 1) * p.in_cs + quad * 4;
+  // weights: 4 xi x 16 k rows of 64 floats = 1024 float4 per step, 4 per thread
+  const float* b_ptr[4];
+  int b_lds[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int f = tid + 256 * j;       // 0..1023
+    const int row = f >> 4, nc = f & 15;  // row = xi*16 + k, nc = float4 column (4 couts)
+    b_ptr[j] = p.wgt + (size_t)row * p.Cout_pad + n0 + nc * 4;
+    const int xi = row >> 4, k = row & 15, w = nc >> 2, n = (nc & 3) * 4;
+    b_lds[j] = ((w * 4 + xi) * 16 + k) * 16 + n;
+  }
+
+  v4f ra, rb, rc, rw[4];
+  int st_ky = 0, st_cg = 0;  // position of the NEXT step to load
+  auto load_step = [&]() __attribute__((always_inline)) {
+    const int dy = st_ky - 1;
+    const bool yok = (y0 + dy >= 0) && (y0 + dy < p.H);
+    const int soff = dy * p.W * p.in_cs + st_cg * 16;
+    {
+      const bool ok = yok && ok_a;
+      v4f v = *reinterpret_cast<const v4f*>(blk_in + (ok ? off_a + soff : 0));
+      ra = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    {
+      const bool ok = yok && ok_b;
+      v4f v = *reinterpret_cast<const v4f*>(blk_in + (ok ? off_b + soff : 0));
+      rb = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    {
+      const bool ok = yok && ok_c;
+      v4f v = *reinterpret_cast<const v4f*>(blk_in + (ok ? off_c + soff : 0));
+      rc = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    const size_t wrow = (size_t)(st_cg * 3 + st_ky) * 64 * p.Cout_pad;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rw[j] = *reinterpret_cast<const v4f*>(b_ptr[j] + wrow);
+    if (++st_ky == 3) {
+      st_ky = 0;
+      ++st_cg;
+    }
+  };
+  auto store_step = [&](int buf) __attribute__((always_inline)) {
+    As[buf][quad * 4 + 0][px_a] = ra.x;
+    As[buf][quad * 4 + 1][px_a] = ra.y;
+    As[buf][quad * 4 + 2][px_a] = ra.z;
+    As[buf][quad * 4 + 3][px_a] = ra.w;
+    As[buf][quad * 4 + 0][px_b] = rb.x;
+    As[buf][quad * 4 + 1][px_b] = rb.y;
+    As[buf][quad * 4 + 2][px_b] = rb.z;
+    As[buf][quad * 4 + 3][px_b] = rb.w;
+    if (has_c) {
+      As[buf][quad * 4 + 0][px_c] = rc.x;
+      As[buf][quad * 4 + 1][px_c] = rc.y;
+      As[buf][quad * 4 + 2][px_c] = rc.z;
+      As[buf][quad * 4 + 3][px_c] = rc.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<v4f*>(&Bs[buf][0][0][0][0] + b_lds[j]) = rw[j];
+  };
+
+  f32x4 acc[4][4];  // [xi][m-tile of 16 pairs]
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[x][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute_step = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      const int k = kq * 4 + l4;  // 16x16x4: A[row = lane&15][k = lane>>4], B[k = lane>>4][col = lane&15]
+      float b[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) b[x] = Bs[buf][wave][x][k][l15];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pair = i * 16 + l15;
+        const v2f d01 = *reinterpret_cast<const v2f*>(&As[buf][k][2 * pair]);      // pixels 2t-1, 2t
+        const v2f d23 = *reinterpret_cast<const v2f*>(&As[buf][k][2 * pair + 2]);  // pixels 2t+1, 2t+2
+        const float v0 = d01.x - d23.x, v1 = d01.y + d23.x, v2 = d23.x - d01.y, v3 = d01.y - d23.y;
+        acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, b[0], acc[0][i], 0, 0, 0);
+        acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, b[1], acc[1][i], 0, 0, 0);
+        acc[2][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, b[2], acc[2][i], 0, 0, 0);
+        acc[3][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(v3, b[3], acc[3][i], 0, 0, 0);
+      }
+    }
+  };
+
+  load_step();
+  store_step(0);
+  __syncthreads();
+  const int ns = p.nsteps;
+  for (int s = 0; s + 1 < ns; ++s) {
+    load_step();
+    __builtin_amdgcn_sched_barrier(0);
+    compute_step(s & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_step((s + 1) & 1);
+    __syncthreads();
+  }
+  compute_step((ns - 1) & 1);
+
+  // ---- epilogue: 16x16x4 C/D map: col = lane&15, row = (lane>>4)*4 + reg --------------------------
+  const int n = n0 + wave * 16 + l15;
+  if (n < p.Cout) {
+    const float pa = p.pre_a[n], pb = p.pre_b[n];
+    const bool has_post = p.post_a != nullptr;
+    const float qa = has_post ? p.post_a[n] : 1.f, qb = has_post ? p.post_b[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int pair = i * 16 + l4 * 4 + r;
+        const float m0 = acc[0][i][r], m1 = acc[1][i][r], m2 = acc[2][i][r], m3 = acc[3][i][r];
+        float o0 = (m0 + m1) + m2, o1 = (m1 - m2) - m3;
+        o0 = o0 * pa + pb;
+        o1 = o1 * pa + pb;
+        if (p.relu) {
+          o0 = fmaxf(o0, 0.f);
+          o1 = fmaxf(o1, 0.f);
+        }
+        if (has_post) {
+          o0 = o0 * qa + qb;
+          o1 = o1 * qa + qb;
+        }
+        float* o = p.out + ((pm0 + 2 * pair) * p.out_cs + p.out_co + n);
+        o[0] = o0;
+        o[p.out_cs] = o1;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+// g: the layer's 3x3 kernel, OIHW or HWIO.  Builds U[cg][ky][xi][16][Cout_pad] (Cout_pad multiple of 64).
+int prepare_wino(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
+  if (L.KH != 3 || L.KW != 3 || L.dil != 1 || L.Cin % 16 != 0) return KOCR_OK;
+  const int Cin = L.Cin, Cout = L.Cout;
+  const int cp = (Cout + 63) / 64 * 64;
+  std::vector<float> u((size_t)(Cin / 16) * 3 * 4 * 16 * cp, 0.f);
+  for (int c = 0; c < Cin; ++c)
+    for (int ky = 0; ky < 3; ++ky)
+      for (int o = 0; o < Cout; ++o) {
+        float g[3];
+        for (int kx = 0; kx < 3; ++kx)
+          g[kx] = w_is_oihw ? w[(((size_t)o * Cin + c) * 3 + ky) * 3 + kx] : w[(((size_t)ky * 3 + kx) * Cin + c) * Cout + o];
+        const float U[4] = {g[0], 0.5f * ((g[0] + g[1]) + g[2]), 0.5f * ((g[0] - g[1]) + g[2]), g[2]};
+        for (int xi = 0; xi < 4; ++xi)
+          u[((((size_t)(c / 16) * 3 + ky) * 4 + xi) * 16 + (c % 16)) * cp + o] = U[xi];
+      }
+  L.wino_cout_pad = cp;
+  return ctx->upload(&L.d_wino, u);
+}
+
+bool wino_applicable(const ConvLayer& L, const Tensor& in) {
+  static const bool off = getenv("KOCR_WINO") && atoi(getenv("KOCR_WINO")) == 0;
+  return !off && L.d_wino && in.W % 128 == 0 && in.cs % 4 == 0 && in.co % 4 == 0 && ((uintptr_t)in.p & 15) == 0 &&
+         L.Cin % 16 == 0;
+}
+
+int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out) {
+  const size_t M = in.pixels();
+  WinoParams p;
+  p.in = in.p;
+  p.wgt = L.d_wino;
+  p.out = out.p;
+  p.pre_a = L.d_pre_a;
+  p.pre_b = L.d_pre_b;
+  p.post_a = L.d_post_a;
+  p.post_b = L.d_post_b;
+  p.H = in.H;
+  p.W = in.W;
+  p.Cin = L.Cin;
+  p.in_cs = in.cs;
+  p.in_co = in.co;
+  p.Cout = L.Cout;
+  p.Cout_pad = L.wino_cout_pad;
+  p.out_cs = out.cs;
+  p.out_co = out.co;
+  p.relu = L.relu;
+  p.nsteps = 3 * (L.Cin / 16);
+  static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
+  char nm[64];
+  if (per_layer)
+    snprintf(nm, sizeof nm, "conv_wino_128x64:%s", L.name.c_str());
+  else
+    snprintf(nm, sizeof nm, "conv_wino_128x64");
+  const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
+  const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
+  ProfScope ps(ctx, nm, flops, bytes);
+  dim3 grid((unsigned)((M / 128) * (p.Cout_pad / 64)));
+  hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), 0, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}

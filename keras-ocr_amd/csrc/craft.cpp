@@ -202,10 +202,7 @@ int craft_forward(kocr_ctx* ctx, const void* d_img, int dtype, int N, int H, int
   // need_full: the pre-pool tensor is consumed elsewhere (skip connection).
   auto conv_pool = [&](const char* name, const Tensor& in, const Tensor& full, const Tensor& pooled,
                        bool need_full) -> int {
-    const bool tiles = (in.H % 2 == 0) && (in.W % 64 == 0);
-    Tensor f = full;
-    if (tiles && !need_full) f.p = nullptr;  // the full-resolution tensor is never written
-    return launch_conv_pool(ctx, net->L[name], in, nullptr, nullptr, f, &pooled);
+    return launch_conv_pool(ctx, net->L[name], in, nullptr, nullptr, full, &pooled, need_full);
   };
 
   Tensor x0;

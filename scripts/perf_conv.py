@@ -11,6 +11,8 @@ SHAPES = [  # N, H, W, Cin, Cout, k  — CRAFT layer classes at 8 x 768x768
     (4, 768, 768, 64, 64, 3),
     (8, 384, 384, 64, 32, 3),
     (8, 48, 48, 1536, 512, 1),
+    (8, 384, 384, 32, 32, 3),
+    (8, 384, 384, 32, 16, 3),
 ]
 if len(sys.argv) > 1:
     SHAPES = [SHAPES[int(a)] for a in sys.argv[1:]]

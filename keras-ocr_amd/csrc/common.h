@@ -159,7 +159,8 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
 // conv_wino.hip
 int prepare_wino(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
 bool wino_applicable(const ConvLayer& L, const Tensor& in);
-int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out);
+int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
+                     bool need_full);
 // elementwise.hip
 int launch_maxpool2x2(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
 int launch_maxpool3x3s1(kocr_ctx* ctx, const Tensor& in, const Tensor& out);

@@ -556,8 +556,7 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
   if (!out.p) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": no output buffer");
   const bool wino = !in_u8 && variant == 0 && conv_variant() == 0 && wino_applicable(L, in);
   if (wino) {  // 1-D Winograd F(2,3): 2/3 of the MFMA work; pooling (if any) as a separate pass
-    KOCR_TRY(launch_conv_wino(ctx, L, in, out));
-    return pool ? launch_maxpool2x2(ctx, out, *pool) : KOCR_OK;
+    return launch_conv_wino(ctx, L, in, out, pool, need_full);
   }
   if (pool && !fuse_pool) {  // unfused: conv to full resolution, then the pooling kernel
     KOCR_TRY(launch_conv_pool(ctx, L, in, in_u8, lut, out, nullptr));

@@ -18,7 +18,8 @@
 // output channels [16w,16w+16) for ALL four points, so the inverse transform in the epilogue is
 // register-only: the 16x16x4 MFMA C/D map puts M_0..M_3 of one (pair, channel) in the same lane.
 // U_xi is pre-transformed on the host, packed [16-channel group][ky][xi][16][Cout_pad], and staged
-// wave-private in LDS.  Requires W % 128 == 0 (a tile never crosses an image row).
+// wave-private in LDS.  Requires W even (a pair never straddles an image row); a tile may cross rows
+// and images: the flattened neighbours that fall across a row end are zeroed per pair in registers.
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -37,6 +38,10 @@ struct WinoParams {
   int Cout, Cout_pad, out_cs, out_co;
   int relu;
   int nsteps;  // 3 * Cin / 16
+  int Mtotal;
+  // fused 2x2 max-pool (POOL kernel): tile = 2 image rows x 64 columns
+  float* pool_out;
+  int pool_cs, pool_co, write_full, tiles_per_row;
 };
 
 namespace {
@@ -50,6 +55,7 @@ __device__ __forceinline__ int wino_xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+template <int POOL>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
   __shared__ float As[2][16][LDA];        // raw input: As[buf][k][1 + pixel], pixel = -1 .. 128
   __shared__ float Bs[2][4][4][16][16];   // Bs[buf][wave][xi][k][n]
@@ -59,25 +65,55 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
   const int nblk_n = p.Cout_pad >> 6;
   const int tile = wino_xcd_remap(blockIdx.x, gridDim.x);
   const int mt = tile / nblk_n, nt = tile - mt * nblk_n;
-  const long pm0 = (long)mt * 128;  // first pixel (flattened n,y,x); W % 128 == 0 -> one image row
-  const int x0t = (int)(pm0 % p.W);
-  const int y0 = (int)((pm0 / p.W) % p.H);
   const int n0 = nt * 64;
-
-  // ---- gather mapping: items = (pixel -1..128) x (4 channel quads): 520 float4 per K-step ----------
-  // items 0..511: pixel = item/4 - 1 + ... laid out so that a wave reads 16 pixels x 64 B
   const int quad = tid & 3;
-  const int px_a = (tid >> 2);        // 0..63   -> pixels px_a - 1
-  const int px_b = (tid >> 2) + 64;   // 64..127 -> pixels px_b - 1
-  // the two right-most pixels (127, 128) x 4 quads are fetched by threads 0..7 as a third item
-  const int px_c = 128 + (tid >> 2);  // valid for tid < 8: indices 128, 129 -> pixels 127, 128
-  const bool has_c = tid < 8;
-  auto px_ok = [&](int idx) { const int x = x0t + idx - 1; return x >= 0 && x < p.W; };
-  const bool ok_a = px_ok(px_a), ok_b = px_ok(px_b), ok_c = has_c && px_ok(px_c);
+  // Tile -> pixels.  POOL == 0: 128 consecutive pixels of the flattened (n, y, x) order (64 pairs); LDS
+  // position = 1 + pixel (pixel = -1 .. 128).  POOL == 1: rows (y, y+1) x 64 columns (32 pairs each);
+  // LDS position = 80*row + 1 + pixel (pixel = -1 .. 64), so M-tiles 0,1 are row y and 2,3 row y+1.
+  long pm0;
+  int lpos[3], goff[3], yy[3];
+  bool ex[3];
+  unsigned lz = 0, rz = 0;
+  int y0t = 0, x0t = 0;
+  if constexpr (POOL) {
+    const int rp_lin = mt / p.tiles_per_row, cb = mt - rp_lin * p.tiles_per_row;
+    const int hh = p.H >> 1;
+    const int nimg = rp_lin / hh, rp = rp_lin - nimg * hh;
+    y0t = 2 * rp;
+    x0t = cb * 64;
+    pm0 = ((long)nimg * p.H + y0t) * p.W + x0t;
+    const int pidx[3] = {tid >> 2, tid >> 2, 64 + ((tid >> 2) & 1)};
+    const int prow[3] = {0, 1, (tid >> 3) & 1};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int x = x0t + pidx[j] - 1;
+      ex[j] = (j < 2 || tid < 16) && x >= 0 && x < p.W;
+      yy[j] = y0t + prow[j];
+      lpos[j] = prow[j] * 80 + pidx[j];
+      goff[j] = (prow[j] * p.W + pidx[j] - 1) * p.in_cs + quad * 4;
+    }
+  } else {
+    pm0 = (long)mt * 128;
+    const int pidx[3] = {tid >> 2, (tid >> 2) + 64, 128 + (tid >> 2)};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const long g = pm0 + pidx[j] - 1;
+      ex[j] = (j < 2 || tid < 8) && g >= 0 && g < p.Mtotal;
+      yy[j] = ex[j] ? (int)((g / p.W) % p.H) : 0;
+      lpos[j] = pidx[j];
+      goff[j] = (pidx[j] - 1) * p.in_cs + quad * 4;
+    }
+    // pair t = 16*i + (lane & 15) at x0 = (pm0 + 2t) % W; its d0 (pixel x0-1) is zero padding when
+    // x0 == 0, its d3 (pixel x0+2) when x0 + 2 == W (the flattened neighbour belongs to another row)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int x0 = (int)((pm0 + 2 * (i * 16 + l15)) % p.W);
+      if (x0 == 0) lz |= 1u << i;
+      if (x0 + 2 >= p.W) rz |= 1u << i;
+    }
+  }
+  const bool has_c = POOL ? (tid < 16) : (tid < 8);
   const float* blk_in = p.in + (pm0 * p.in_cs + p.in_co);
-  const int off_a = (px_a - 1) * p.in_cs + quad * 4;
-  const int off_b = (px_b - 1) * p.in_cs + quad * 4;
-  const int off_c = (px_c - 1) * p.in_cs + quad * 4;
   // weights: 4 xi x 16 k rows of 64 floats = 1024 float4 per step, 4 per thread
   const float* b_ptr[4];
   int b_lds[4];
@@ -90,26 +126,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
     b_lds[j] = ((w * 4 + xi) * 16 + k) * 16 + n;
   }
 
-  v4f ra, rb, rc, rw[4];
+  v4f rr[3], rw[4];
   int st_ky = 0, st_cg = 0;  // position of the NEXT step to load
   auto load_step = [&]() __attribute__((always_inline)) {
     const int dy = st_ky - 1;
-    const bool yok = (y0 + dy >= 0) && (y0 + dy < p.H);
     const int soff = dy * p.W * p.in_cs + st_cg * 16;
-    {
-      const bool ok = yok && ok_a;
-      v4f v = *reinterpret_cast<const v4f*>(blk_in + (ok ? off_a + soff : 0));
-      ra = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
-    }
-    {
-      const bool ok = yok && ok_b;
-      v4f v = *reinterpret_cast<const v4f*>(blk_in + (ok ? off_b + soff : 0));
-      rb = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
-    }
-    {
-      const bool ok = yok && ok_c;
-      v4f v = *reinterpret_cast<const v4f*>(blk_in + (ok ? off_c + soff : 0));
-      rc = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const bool ok = ex[j] && (unsigned)(yy[j] + dy) < (unsigned)p.H;
+      v4f v = *reinterpret_cast<const v4f*>(blk_in + (ok ? goff[j] + soff : 0));
+      rr[j] = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
     }
     const size_t wrow = (size_t)(st_cg * 3 + st_ky) * 64 * p.Cout_pad;
 #pragma unroll
@@ -120,19 +146,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
     }
   };
   auto store_step = [&](int buf) __attribute__((always_inline)) {
-    As[buf][quad * 4 + 0][px_a] = ra.x;
-    As[buf][quad * 4 + 1][px_a] = ra.y;
-    As[buf][quad * 4 + 2][px_a] = ra.z;
-    As[buf][quad * 4 + 3][px_a] = ra.w;
-    As[buf][quad * 4 + 0][px_b] = rb.x;
-    As[buf][quad * 4 + 1][px_b] = rb.y;
-    As[buf][quad * 4 + 2][px_b] = rb.z;
-    As[buf][quad * 4 + 3][px_b] = rb.w;
-    if (has_c) {
-      As[buf][quad * 4 + 0][px_c] = rc.x;
-      As[buf][quad * 4 + 1][px_c] = rc.y;
-      As[buf][quad * 4 + 2][px_c] = rc.z;
-      As[buf][quad * 4 + 3][px_c] = rc.w;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (j < 2 || has_c) {
+        As[buf][quad * 4 + 0][lpos[j]] = rr[j].x;
+        As[buf][quad * 4 + 1][lpos[j]] = rr[j].y;
+        As[buf][quad * 4 + 2][lpos[j]] = rr[j].z;
+        As[buf][quad * 4 + 3][lpos[j]] = rr[j].w;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<v4f*>(&Bs[buf][0][0][0][0] + b_lds[j]) = rw[j];
@@ -153,10 +174,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
       for (int x = 0; x < 4; ++x) b[x] = Bs[buf][wave][x][k][l15];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int pair = i * 16 + l15;
-        const v2f d01 = *reinterpret_cast<const v2f*>(&As[buf][k][2 * pair]);      // pixels 2t-1, 2t
-        const v2f d23 = *reinterpret_cast<const v2f*>(&As[buf][k][2 * pair + 2]);  // pixels 2t+1, 2t+2
-        const float v0 = d01.x - d23.x, v1 = d01.y + d23.x, v2 = d23.x - d01.y, v3 = d01.y - d23.y;
+        const int base = POOL ? (i >> 1) * 80 + 2 * ((i & 1) * 16 + l15) : 2 * (i * 16 + l15);
+        const v2f d01 = *reinterpret_cast<const v2f*>(&As[buf][k][base]);      // pixels 2t-1, 2t
+        const v2f d23 = *reinterpret_cast<const v2f*>(&As[buf][k][base + 2]);  // pixels 2t+1, 2t+2
+        const float d0 = ((lz >> i) & 1u) ? 0.f : d01.x;  // row start: left neighbour is padding
+        const float d3 = ((rz >> i) & 1u) ? 0.f : d23.y;  // row end: right neighbour is padding
+        const float v0 = d0 - d23.x, v1 = d01.y + d23.x, v2 = d23.x - d01.y, v3 = d01.y - d3;
         acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, b[0], acc[0][i], 0, 0, 0);
         acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, b[1], acc[1][i], 0, 0, 0);
         acc[2][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, b[2], acc[2][i], 0, 0, 0);
@@ -185,27 +208,55 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
     const float pa = p.pre_a[n], pb = p.pre_b[n];
     const bool has_post = p.post_a != nullptr;
     const float qa = has_post ? p.post_a[n] : 1.f, qb = has_post ? p.post_b[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int pair = i * 16 + l4 * 4 + r;
-        const float m0 = acc[0][i][r], m1 = acc[1][i][r], m2 = acc[2][i][r], m3 = acc[3][i][r];
-        float o0 = (m0 + m1) + m2, o1 = (m1 - m2) - m3;
-        o0 = o0 * pa + pb;
-        o1 = o1 * pa + pb;
-        if (p.relu) {
-          o0 = fmaxf(o0, 0.f);
-          o1 = fmaxf(o1, 0.f);
-        }
-        if (has_post) {
-          o0 = o0 * qa + qb;
-          o1 = o1 * qa + qb;
-        }
-        float* o = p.out + ((pm0 + 2 * pair) * p.out_cs + p.out_co + n);
-        o[0] = o0;
-        o[p.out_cs] = o1;
+    auto finish = [&](float m0, float m1, float m2, float m3, float& o0, float& o1) {
+      o0 = (m0 + m1) + m2;
+      o1 = (m1 - m2) - m3;
+      o0 = o0 * pa + pb;
+      o1 = o1 * pa + pb;
+      if (p.relu) {
+        o0 = fmaxf(o0, 0.f);
+        o1 = fmaxf(o1, 0.f);
       }
+      if (has_post) {
+        o0 = o0 * qa + qb;
+        o1 = o1 * qa + qb;
+      }
+    };
+    if constexpr (POOL) {
+      const long nimg = pm0 / ((long)p.H * p.W);
+      const long pp0 = (nimg * (p.H >> 1) + (y0t >> 1)) * (p.W >> 1) + (x0t >> 1);
+#pragma unroll
+      for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pp = ih * 16 + l4 * 4 + r;  // pair inside the row == pooled column
+          float a0, a1, b0, b1;
+          finish(acc[0][ih][r], acc[1][ih][r], acc[2][ih][r], acc[3][ih][r], a0, a1);                  // row y
+          finish(acc[0][ih + 2][r], acc[1][ih + 2][r], acc[2][ih + 2][r], acc[3][ih + 2][r], b0, b1);  // row y+1
+          if (p.write_full) {
+            float* o = p.out + ((pm0 + 2 * pp) * p.out_cs + p.out_co + n);
+            o[0] = a0;
+            o[p.out_cs] = a1;
+            o[(long)p.W * p.out_cs] = b0;
+            o[(long)p.W * p.out_cs + p.out_cs] = b1;
+          }
+          p.pool_out[(pp0 + pp) * p.pool_cs + p.pool_co + n] = fmaxf(fmaxf(a0, a1), fmaxf(b0, b1));
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pair = i * 16 + l4 * 4 + r;
+          float o0, o1;
+          finish(acc[0][i][r], acc[1][i][r], acc[2][i][r], acc[3][i][r], o0, o1);
+          if (pm0 + 2 * pair < p.Mtotal) {  // W even -> Mtotal even -> both pixels of the pair exist
+            float* o = p.out + ((pm0 + 2 * pair) * p.out_cs + p.out_co + n);
+            o[0] = o0;
+            o[p.out_cs] = o1;
+          }
+        }
+    }
   }
 }
 
@@ -234,11 +285,14 @@ int prepare_wino(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
 
 bool wino_applicable(const ConvLayer& L, const Tensor& in) {
   static const bool off = getenv("KOCR_WINO") && atoi(getenv("KOCR_WINO")) == 0;
-  return !off && L.d_wino && in.W % 128 == 0 && in.cs % 4 == 0 && in.co % 4 == 0 && ((uintptr_t)in.p & 15) == 0 &&
-         L.Cin % 16 == 0;
+  return !off && L.d_wino && in.W % 2 == 0 && in.cs % 4 == 0 && in.co % 4 == 0 && ((uintptr_t)in.p & 15) == 0 &&
+         L.Cin % 16 == 0 && L.Cout > 32;  // the 64-wide N tile would waste half the MFMAs on <= 32 couts
 }
 
-int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out) {
+int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
+                     bool need_full) {
+  // fused pooling needs exact 2-row x 64-column tiles
+  const bool fuse = pool && in.H % 2 == 0 && in.W % 64 == 0;
   const size_t M = in.pixels();
   WinoParams p;
   p.in = in.p;
@@ -259,17 +313,33 @@ int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
   p.out_co = out.co;
   p.relu = L.relu;
   p.nsteps = 3 * (L.Cin / 16);
+  p.Mtotal = (int)M;
+  p.pool_out = nullptr;
+  p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
+  if (fuse) {
+    p.pool_out = pool->p;
+    p.pool_cs = pool->cs;
+    p.pool_co = pool->co;
+    p.write_full = need_full ? 1 : 0;
+    p.tiles_per_row = in.W / 64;
+  }
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_wino_128x64:%s", L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_wino_128x64%s:%s", fuse ? "p" : "", L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_wino_128x64");
+    snprintf(nm, sizeof nm, "conv_wino_128x64%s", fuse ? "_pool" : "");
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
-  ProfScope ps(ctx, nm, flops, bytes);
-  dim3 grid((unsigned)((M / 128) * (p.Cout_pad / 64)));
-  hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), 0, ctx->stream, p);
-  KOCR_HIP(ctx, hipGetLastError());
+  {
+    ProfScope ps(ctx, nm, flops, bytes);
+    dim3 grid((unsigned)(((M + 127) / 128) * (p.Cout_pad / 64)));
+    if (fuse)
+      hipLaunchKernelGGL(conv_wino_kernel<1>, grid, dim3(256), 0, ctx->stream, p);
+    else
+      hipLaunchKernelGGL(conv_wino_kernel<0>, grid, dim3(256), 0, ctx->stream, p);
+    KOCR_HIP(ctx, hipGetLastError());
+  }
+  if (pool && !fuse) return launch_maxpool2x2(ctx, out, *pool);
   return KOCR_OK;
 }

@@ -30,6 +30,11 @@ CASES = [
     (2, 6, 256, 64, 64, 3, 1),
     (1, 5, 128, 128, 200, 3, 1),
     (1, 3, 384, 256, 64, 3, 1),
+    # even W, tiles crossing rows and images, ragged last tile (per-pair row-edge masks)
+    (2, 7, 10, 16, 32, 3, 1),
+    (1, 9, 96, 32, 64, 3, 1),
+    (3, 5, 6, 16, 16, 3, 1),
+    (1, 2, 2, 48, 70, 3, 1),
 ]
 
 

@@ -17,8 +17,10 @@
 // and forms the four V_xi values in registers (the transformed tile is never stored).  Wave w owns
 // output channels [16w,16w+16) for ALL four points, so the inverse transform in the epilogue is
 // register-only: the 16x16x4 MFMA C/D map puts M_0..M_3 of one (pair, channel) in the same lane.
-// U_xi is pre-transformed on the host, packed [16-channel group][ky][xi][16][Cout_pad], and staged
-// wave-private in LDS.  Requires W even (a pair never straddles an image row); a tile may cross rows
+// U_xi is pre-transformed on the host and packed in MFMA-operand order, [16-channel group][ky]
+// [16-cout tile][lane][xi*4+kq], so a lane fetches the 16 B-operand values of a K-step with four
+// 16-B loads straight into registers (4 KB contiguous per wave, prefetched one K-step ahead): the
+// weights never touch LDS.  Requires W even (a pair never straddles an image row); a tile may cross rows
 // and images: the flattened neighbours that fall across a row end are zeroed per pair in registers.
 #include "common.h"
 
@@ -28,7 +30,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct WinoParams {
   const float* in;
-  const float* wgt;  // U: [Cin/16][3][4][16][Cout_pad]
+  const float* wgt;  // U: [Cin/16][3][Cout_pad/16][64 lanes][16 = xi*4 + kq]
   float* out;
   const float* pre_a;
   const float* pre_b;
@@ -58,7 +60,6 @@ __device__ __forceinline__ int wino_xcd_remap(int bid, int nwg) {
 template <int POOL>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
   __shared__ float As[2][16][LDA];        // raw input: As[buf][k][1 + pixel], pixel = -1 .. 128
-  __shared__ float Bs[2][4][4][16][16];   // Bs[buf][wave][xi][k][n]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
 
@@ -114,19 +115,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
   }
   const bool has_c = POOL ? (tid < 16) : (tid < 8);
   const float* blk_in = p.in + (pm0 * p.in_cs + p.in_co);
-  // weights: 4 xi x 16 k rows of 64 floats = 1024 float4 per step, 4 per thread
-  const float* b_ptr[4];
-  int b_lds[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int f = tid + 256 * j;       // 0..1023
-    const int row = f >> 4, nc = f & 15;  // row = xi*16 + k, nc = float4 column (4 couts)
-    b_ptr[j] = p.wgt + (size_t)row * p.Cout_pad + n0 + nc * 4;
-    const int xi = row >> 4, k = row & 15, w = nc >> 2, n = (nc & 3) * 4;
-    b_lds[j] = ((w * 4 + xi) * 16 + k) * 16 + n;
-  }
+  // weights: this lane's 16 B-operand values of a K-step are 64 contiguous bytes
+  const int ntiles16 = p.Cout_pad >> 4;
+  const float* w_ptr = p.wgt + ((size_t)(nt * 4 + wave) * 64 + lane) * 16;
+  const size_t w_step = (size_t)ntiles16 * 64 * 16;  // floats per K-step
 
-  v4f rr[3], rw[4];
+  v4f rr[3];
+  v4f bw[2][4];  // B operands: [current / next K-step][xi] -> .x/.y/.z/.w = kq 0..3
   int st_ky = 0, st_cg = 0;  // position of the NEXT step to load
   auto load_step = [&]() __attribute__((always_inline)) {
     const int dy = st_ky - 1;
@@ -137,9 +132,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
       v4f v = *reinterpret_cast<const v4f*>(blk_in + (ok ? goff[j] + soff : 0));
       rr[j] = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
     }
-    const size_t wrow = (size_t)(st_cg * 3 + st_ky) * 64 * p.Cout_pad;
+    const float* wp = w_ptr + (size_t)(st_cg * 3 + st_ky) * w_step;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rw[j] = *reinterpret_cast<const v4f*>(b_ptr[j] + wrow);
+    for (int x = 0; x < 4; ++x) bw[1][x] = *reinterpret_cast<const v4f*>(wp + 4 * x);
     if (++st_ky == 3) {
       st_ky = 0;
       ++st_cg;
@@ -156,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<v4f*>(&Bs[buf][0][0][0][0] + b_lds[j]) = rw[j];
+    for (int x = 0; x < 4; ++x) bw[0][x] = bw[1][x];
   };
 
   f32x4 acc[4][4];  // [xi][m-tile of 16 pairs]
@@ -171,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
       const int k = kq * 4 + l4;  // 16x16x4: A[row = lane&15][k = lane>>4], B[k = lane>>4][col = lane&15]
       float b[4];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) b[x] = Bs[buf][wave][x][k][l15];
+      for (int x = 0; x < 4; ++x) b[x] = bw[0][x][kq];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int base = POOL ? (i >> 1) * 80 + 2 * ((i & 1) * 16 + l15) : 2 * (i * 16 + l15);
@@ -268,7 +263,8 @@ int prepare_wino(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
   if (L.KH != 3 || L.KW != 3 || L.dil != 1 || L.Cin % 16 != 0) return KOCR_OK;
   const int Cin = L.Cin, Cout = L.Cout;
   const int cp = (Cout + 63) / 64 * 64;
-  std::vector<float> u((size_t)(Cin / 16) * 3 * 4 * 16 * cp, 0.f);
+  const int nt16 = cp / 16;
+  std::vector<float> u((size_t)(Cin / 16) * 3 * nt16 * 64 * 16, 0.f);
   for (int c = 0; c < Cin; ++c)
     for (int ky = 0; ky < 3; ++ky)
       for (int o = 0; o < Cout; ++o) {
@@ -276,8 +272,10 @@ int prepare_wino(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
         for (int kx = 0; kx < 3; ++kx)
           g[kx] = w_is_oihw ? w[(((size_t)o * Cin + c) * 3 + ky) * 3 + kx] : w[(((size_t)ky * 3 + kx) * Cin + c) * Cout + o];
         const float U[4] = {g[0], 0.5f * ((g[0] + g[1]) + g[2]), 0.5f * ((g[0] - g[1]) + g[2]), g[2]};
+        // MFMA 16x16x4 B operand: lane = (k & 3) * 16 + (o & 15) holds k-quad kq = (k >> 2) of the step
+        const int k = c % 16, lane = (k & 3) * 16 + (o & 15), kq = k >> 2;
         for (int xi = 0; xi < 4; ++xi)
-          u[((((size_t)(c / 16) * 3 + ky) * 4 + xi) * 16 + (c % 16)) * cp + o] = U[xi];
+          u[((((size_t)(c / 16) * 3 + ky) * nt16 + o / 16) * 64 + lane) * 16 + xi * 4 + kq] = U[xi];
       }
   L.wino_cout_pad = cp;
   return ctx->upload(&L.d_wino, u);

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
   const size_t w_step = (size_t)ntiles16 * 64 * 16;  // floats per K-step
 
   v4f rr[3];
-  v4f bw[2][4];  // B operands: [current / next K-step][xi] -> .x/.y/.z/.w = kq 0..3
+  v4f bw[1][4];  // B operands of the current K-step: [xi] -> .x/.y/.z/.w = kq 0..3
+  const float* wp_next = nullptr;
   int st_ky = 0, st_cg = 0;  // position of the NEXT step to load
   auto load_step = [&]() __attribute__((always_inline)) {
     const int dy = st_ky - 1;
@@ -132,9 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
       v4f v = *reinterpret_cast<const v4f*>(blk_in + (ok ? goff[j] + soff : 0));
       rr[j] = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
     }
-    const float* wp = w_ptr + (size_t)(st_cg * 3 + st_ky) * w_step;
-#pragma unroll
-    for (int x = 0; x < 4; ++x) bw[1][x] = *reinterpret_cast<const v4f*>(wp + 4 * x);
+    wp_next = w_ptr + (size_t)(st_cg * 3 + st_ky) * w_step;
     if (++st_ky == 3) {
       st_ky = 0;
       ++st_cg;
@@ -151,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
       }
     }
 #pragma unroll
-    for (int x = 0; x < 4; ++x) bw[0][x] = bw[1][x];
+    for (int x = 0; x < 4; ++x) bw[0][x] = *reinterpret_cast<const v4f*>(wp_next + 4 * x);
   };
 
   f32x4 acc[4][4];  // [xi][m-tile of 16 pairs]

@@ -36,6 +36,14 @@ def load_library():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C keras-ocr_amd/csrc). "
             "keras-ocr_amd has no CPU fallback.")
+    # PyTorch's wheel bundles its own HIP/HSA runtime.  If libkocr (linked against the system ROCm)
+    # initialises HIP first, a later `import torch` finds "No HIP GPUs" in its private runtime; the
+    # other order works.  torch is only plumbing here (device buffers in bench.py, torch.distributed),
+    # so when it is installed it is imported before the library is loaded.
+    try:
+        import torch  # noqa: F401  pylint: disable=import-outside-toplevel,unused-import
+    except ImportError:  # pragma: no cover
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci = ctypes.c_void_p, ctypes.c_int
     sigs = {

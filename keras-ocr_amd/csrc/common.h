@@ -162,7 +162,9 @@ bool wino_applicable(const ConvLayer& L, const Tensor& in);
 int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
                      bool need_full);
 // elementwise.hip
-int launch_maxpool2x2(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
+// row_off: input row that starts output row 0 (0 = keras 'valid' pooling; 1 = the same pooling seen
+// through a vertical flip of an odd-height tensor, as in the CRNN's natural-orientation conv stack)
+int launch_maxpool2x2(kocr_ctx* ctx, const Tensor& in, const Tensor& out, int row_off = 0);
 int launch_maxpool3x3s1(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
 int launch_resize_bilinear(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
 int launch_copy_channels(kocr_ctx* ctx, const Tensor& in, const Tensor& out);

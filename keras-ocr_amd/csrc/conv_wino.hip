@@ -57,17 +57,19 @@ __device__ __forceinline__ int wino_xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int POOL>
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
+template <int POOL, int NW>  // NW waves per block: 4 (64 couts) or 8 (128 couts share one raw input tile)
+__global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(WinoParams p) {
+  constexpr int NT = 64 * NW;
   __shared__ float As[2][16][LDA];        // raw input: As[buf][k][1 + pixel], pixel = -1 .. 128
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
 
-  const int nblk_n = p.Cout_pad >> 6;
+  const int nblk_n = p.Cout_pad / (16 * NW);
   const int tile = wino_xcd_remap(blockIdx.x, gridDim.x);
   const int mt = tile / nblk_n, nt = tile - mt * nblk_n;
-  const int n0 = nt * 64;
+  const int n0 = nt * 16 * NW;
   const int quad = tid & 3;
+  constexpr int PPI = NT / 4;  // pixels covered by one gather item across the block
   // Tile -> pixels.  POOL == 0: 128 consecutive pixels of the flattened (n, y, x) order (64 pairs); LDS
   // position = 1 + pixel (pixel = -1 .. 128).  POOL == 1: rows (y, y+1) x 64 columns (32 pairs each);
   // LDS position = 80*row + 1 + pixel (pixel = -1 .. 64), so M-tiles 0,1 are row y and 2,3 row y+1.
@@ -83,23 +85,25 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
     y0t = 2 * rp;
     x0t = cb * 64;
     pm0 = ((long)nimg * p.H + y0t) * p.W + x0t;
-    const int pidx[3] = {tid >> 2, tid >> 2, 64 + ((tid >> 2) & 1)};
-    const int prow[3] = {0, 1, (tid >> 3) & 1};
+    // 2 rows x 66 positions: NW == 4: items {row 0, row 1} by all threads + 16 stragglers;
+    // NW == 8: one item per thread (row = tid >> 8) + 16 stragglers
+    const int pidx[3] = {(tid >> 2) & 63, (tid >> 2) & 63, 64 + ((tid >> 2) & 1)};
+    const int prow[3] = {NW == 8 ? (tid >> 8) : 0, 1, (tid >> 3) & 1};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int x = x0t + pidx[j] - 1;
-      ex[j] = (j < 2 || tid < 16) && x >= 0 && x < p.W;
+      ex[j] = ((j == 0) || (j == 1 && NW == 4) || (j == 2 && tid < 16)) && x >= 0 && x < p.W;
       yy[j] = y0t + prow[j];
       lpos[j] = prow[j] * 80 + pidx[j];
       goff[j] = (prow[j] * p.W + pidx[j] - 1) * p.in_cs + quad * 4;
     }
   } else {
     pm0 = (long)mt * 128;
-    const int pidx[3] = {tid >> 2, (tid >> 2) + 64, 128 + (tid >> 2)};
+    const int pidx[3] = {tid >> 2, (tid >> 2) + 64, 128 + ((tid >> 2) & 1)};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const long g = pm0 + pidx[j] - 1;
-      ex[j] = (j < 2 || tid < 8) && g >= 0 && g < p.Mtotal;
+      ex[j] = ((j == 0) || (j == 1 && NW == 4) || (j == 2 && tid < 8)) && g >= 0 && g < p.Mtotal;
       yy[j] = ex[j] ? (int)((g / p.W) % p.H) : 0;
       lpos[j] = pidx[j];
       goff[j] = (pidx[j] - 1) * p.in_cs + quad * 4;
@@ -114,10 +118,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
     }
   }
   const bool has_c = POOL ? (tid < 16) : (tid < 8);
+  (void)PPI;
   const float* blk_in = p.in + (pm0 * p.in_cs + p.in_co);
   // weights: this lane's 16 B-operand values of a K-step are 64 contiguous bytes
   const int ntiles16 = p.Cout_pad >> 4;
-  const float* w_ptr = p.wgt + ((size_t)(nt * 4 + wave) * 64 + lane) * 16;
+  const float* w_ptr = p.wgt + ((size_t)(nt * NW + wave) * 64 + lane) * 16;
   const size_t w_step = (size_t)ntiles16 * 64 * 16;  // floats per K-step
 
   v4f rr[3];
@@ -129,6 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
     const int soff = dy * p.W * p.in_cs + st_cg * 16;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
+      if (j == 1 && NW == 8) continue;
       const bool ok = ex[j] && (unsigned)(yy[j] + dy) < (unsigned)p.H;
       v4f v = *reinterpret_cast<const v4f*>(blk_in + (ok ? goff[j] + soff : 0));
       rr[j] = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams p) {
   auto store_step = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      if (j < 2 || has_c) {
+      if (j == 0 || (j == 1 && NW == 4) || (j == 2 && has_c)) {
         As[buf][quad * 4 + 0][lpos[j]] = rr[j].x;
         As[buf][quad * 4 + 1][lpos[j]] = rr[j].y;
         As[buf][quad * 4 + 2][lpos[j]] = rr[j].z;
@@ -330,11 +336,23 @@ int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   {
     ProfScope ps(ctx, nm, flops, bytes);
-    dim3 grid((unsigned)(((M + 127) / 128) * (p.Cout_pad / 64)));
-    if (fuse)
-      hipLaunchKernelGGL(conv_wino_kernel<1>, grid, dim3(256), 0, ctx->stream, p);
-    else
-      hipLaunchKernelGGL(conv_wino_kernel<0>, grid, dim3(256), 0, ctx->stream, p);
+    // 8-wave blocks (128 couts share one raw input tile) measured no faster than 4-wave ones;
+    // kept as a developer A/B switch
+    static const bool use8 = getenv("KOCR_WINO_NW8") != nullptr;
+    const bool wide = use8 && p.Cout_pad % 128 == 0;
+    if (wide) {
+      dim3 grid((unsigned)(((M + 127) / 128) * (p.Cout_pad / 128)));
+      if (fuse)
+        hipLaunchKernelGGL((conv_wino_kernel<1, 8>), grid, dim3(512), 0, ctx->stream, p);
+      else
+        hipLaunchKernelGGL((conv_wino_kernel<0, 8>), grid, dim3(512), 0, ctx->stream, p);
+    } else {
+      dim3 grid((unsigned)(((M + 127) / 128) * (p.Cout_pad / 64)));
+      if (fuse)
+        hipLaunchKernelGGL((conv_wino_kernel<1, 4>), grid, dim3(256), 0, ctx->stream, p);
+      else
+        hipLaunchKernelGGL((conv_wino_kernel<0, 4>), grid, dim3(256), 0, ctx->stream, p);
+    }
     KOCR_HIP(ctx, hipGetLastError());
   }
   if (pool && !fuse) return launch_maxpool2x2(ctx, out, *pool);

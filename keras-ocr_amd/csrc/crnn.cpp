@@ -6,6 +6,13 @@
 //   - every Conv2D / Dense runs on the MFMA implicit-GEMM kernel; conv bias + ReLU, and the
 //     BatchNorm that FOLLOWS the ReLU at conv_3/5/7 (Keras default eps = 1e-3,
 //     recognition.py:226-242), are the kernel's pre/post affine epilogue;
+//   - conv_1..conv_7 and the two poolings run in the crop's NATURAL orientation [M,31,200,C]: the
+//     reference first permutes to (200,31) and flips the 31-axis (recognition.py:215-216), i.e.
+//     x'[w][j] = x[30-j][w]; a 3x3 convolution on x' with kernel K[a][b] equals one on x with
+//     Knat[p][q] = K[q][2-p], and 'valid' 2x2 pooling of the flipped odd axis (31 -> 15 -> 7, last
+//     row dropped) equals pooling rows (2i+1, 2i+2) of the natural tensor (first row dropped).
+//     W = 200 / 100 / 50 is even, so the whole stack takes the Winograd F(2,3) kernel; one small
+//     transpose+flip kernel after bn_7 restores the Keras layout for the STN and the recurrent part;
 //   - Flatten / Reshape are free re-interpretations of the NHWC buffers;
 //   - the forward and backward LSTM input projections of a layer are one GEMM (N = 2*4*128);
 //     Add (recognition.py:305) is folded into the next projection by stacking its kernel over
@@ -14,6 +21,7 @@
 #include <cmath>
 
 int launch_crnn_input(kocr_ctx* ctx, const float* d_crops, float* d_x, int M, int Hc, int Wc);
+int launch_crnn_to_keras(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
 int launch_stn_sample(kocr_ctx* ctx, const Tensor& x, const float* d_theta, const Tensor& out);
 int launch_lstm(kocr_ctx* ctx, const float* d_xp, const float* d_Uf, const float* d_Ub, float* d_out, int M, int T);
 int launch_ctc(kocr_ctx* ctx, const float* d_logits, int M, int T, int C, int discard, int* d_labels, float* d_probs);
@@ -67,6 +75,13 @@ int crnn_load(kocr_ctx* ctx, int n, const char* const* names, const float* const
     const float *w, *b;
     KOCR_TRY(need(nm + "/kernel", (size_t)9 * cin * cout, &w));
     KOCR_TRY(need(nm + "/bias", cout, &b));
+    // natural-orientation kernel: Knat[p][q][c][o] = K[q][2-p][c][o]  (HWIO)
+    std::vector<float> wn((size_t)9 * cin * cout);
+    for (int pp = 0; pp < 3; ++pp)
+      for (int q = 0; q < 3; ++q)
+        memcpy(&wn[((size_t)pp * 3 + q) * cin * cout], &w[((size_t)q * 3 + (2 - pp)) * cin * cout],
+               sizeof(float) * cin * cout);
+    w = wn.data();
     std::vector<float> qa, qb;
     if (i == 3 || i == 5 || i == 7) {
       const std::string bn = "bn_" + std::to_string(i);
@@ -152,10 +167,9 @@ size_t crnn_workspace_bytes(int M, int n_classes) {
   const size_t m = (size_t)M, f = sizeof(float);
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   size_t t = 0;
-  t += al(m * WC * HC * f);                                       // x0
   t += al(m * WC * HC * 64 * f) + al(m * WC * HC * 128 * f) + al(m * WC * HC * 256 * f);
   t += al(m * 100 * 15 * 256 * f) * 2 + al(m * 100 * 15 * 512 * f);
-  t += al(m * 50 * 7 * 512 * f) * 4;                              // p5, c6, c7, stn
+  t += al(m * 50 * 7 * 512 * f) * 5;                              // p5, c6, c7 (both layouts), stn
   t += al(m * 50 * 7 * 16 * f) + al(m * 50 * 7 * 32 * f) + al(m * 64 * f) + al(m * 6 * f);
   t += al(m * T * UNITS * f) + al(m * T * 8 * UNITS * f) + al(m * T * 2 * UNITS * f) * 2;
   t += al(m * T * (size_t)n_classes * f);
@@ -191,27 +205,35 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
   auto conv = [&](const char* name, const Tensor& in, const Tensor& out) -> int {
     return launch_conv(ctx, net->L[name], in, nullptr, nullptr, out);
   };
-  Tensor x0, c1, c2, c3, p3, c4, c5, p5, c6, c7, s1, s2, d1, th, st, f9, xp, r1, r2, lg;
-  KOCR_TRY(mk(M, WC, HC, 1, &x0));
-  KOCR_TRY(launch_crnn_input(ctx, d_crops, x0.p, M, HC, WC));
-  KOCR_TRY(mk(M, WC, HC, 64, &c1));
+  Tensor x0, c1, c2, c3, p3, c4, c5, p5, c6, c7n, c7, s1, s2, d1, th, st, f9, xp, r1, r2, lg;
+  // conv stack in the crop's natural orientation (see the header): [M,31,200,C]
+  x0.N = M;
+  x0.H = HC;
+  x0.W = WC;
+  x0.C = x0.cs = 1;
+  x0.co = 0;
+  x0.p = const_cast<float*>(d_crops);
+  KOCR_TRY(mk(M, HC, WC, 64, &c1));
   KOCR_TRY(conv("conv_1", x0, c1));
-  KOCR_TRY(mk(M, WC, HC, 128, &c2));
+  KOCR_TRY(mk(M, HC, WC, 128, &c2));
   KOCR_TRY(conv("conv_2", c1, c2));
-  KOCR_TRY(mk(M, WC, HC, 256, &c3));
+  KOCR_TRY(mk(M, HC, WC, 256, &c3));
   KOCR_TRY(conv("conv_3", c2, c3));  // ReLU then bn_3
-  KOCR_TRY(mk(M, WC / 2, HC / 2, 256, &p3));
-  KOCR_TRY(launch_maxpool2x2(ctx, c3, p3));
-  KOCR_TRY(mk(M, WC / 2, HC / 2, 256, &c4));
+  KOCR_TRY(mk(M, HC / 2, WC / 2, 256, &p3));
+  KOCR_TRY(launch_maxpool2x2(ctx, c3, p3, /*row_off=*/1));
+  KOCR_TRY(mk(M, HC / 2, WC / 2, 256, &c4));
   KOCR_TRY(conv("conv_4", p3, c4));
-  KOCR_TRY(mk(M, WC / 2, HC / 2, 512, &c5));
+  KOCR_TRY(mk(M, HC / 2, WC / 2, 512, &c5));
   KOCR_TRY(conv("conv_5", c4, c5));
-  KOCR_TRY(mk(M, WC / 4, HC / 4, 512, &p5));
-  KOCR_TRY(launch_maxpool2x2(ctx, c5, p5));
-  KOCR_TRY(mk(M, WC / 4, HC / 4, 512, &c6));
+  KOCR_TRY(mk(M, HC / 4, WC / 4, 512, &p5));
+  KOCR_TRY(launch_maxpool2x2(ctx, c5, p5, /*row_off=*/1));
+  KOCR_TRY(mk(M, HC / 4, WC / 4, 512, &c6));
   KOCR_TRY(conv("conv_6", p5, c6));
+  KOCR_TRY(mk(M, HC / 4, WC / 4, 512, &c7n));
+  KOCR_TRY(conv("conv_7", c6, c7n));
+  // back to the Keras layout (M, 50, 7, 512) for the STN and everything after it
   KOCR_TRY(mk(M, WC / 4, HC / 4, 512, &c7));
-  KOCR_TRY(conv("conv_7", c6, c7));
+  KOCR_TRY(launch_crnn_to_keras(ctx, c7n, c7));
   // STN (recognition.py:268-281)
   KOCR_TRY(mk(M, WC / 4, HC / 4, 16, &s1));
   KOCR_TRY(conv("stn_conv_1", c7, s1));

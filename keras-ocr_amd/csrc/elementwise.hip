@@ -13,6 +13,7 @@ struct EwParams {
   int N, Hi, Wi, Ho, Wo, C4;  // C4 = channels / 4
   int in_cs, in_co, out_cs, out_co;
   float sy, sx;
+  int row_off;  // maxpool2x2: first input row of output row 0 (0, or 1 for the flipped CRNN layout)
 };
 
 __global__ void maxpool2x2_kernel(EwParams p) {
@@ -25,7 +26,7 @@ __global__ void maxpool2x2_kernel(EwParams p) {
     t /= p.Wo;
     const int oy = t % p.Ho;
     const int n = t / p.Ho;
-    const size_t base = (((size_t)n * p.Hi + 2 * oy) * p.Wi + 2 * ox) * p.in_cs + p.in_co + c4 * 4;
+    const size_t base = (((size_t)n * p.Hi + 2 * oy + p.row_off) * p.Wi + 2 * ox) * p.in_cs + p.in_co + c4 * 4;
     const float4 a = *reinterpret_cast<const float4*>(p.in + base);
     const float4 b = *reinterpret_cast<const float4*>(p.in + base + p.in_cs);
     const float4 c = *reinterpret_cast<const float4*>(p.in + base + (size_t)p.Wi * p.in_cs);
@@ -151,6 +152,7 @@ static EwParams make_params(const Tensor& in, const Tensor& out) {
   p.out_cs = out.cs;
   p.out_co = out.co;
   p.sy = p.sx = 1.f;
+  p.row_off = 0;
   return p;
 }
 
@@ -161,10 +163,11 @@ static dim3 ew_grid(size_t total) {
   return dim3((unsigned)b);
 }
 
-int launch_maxpool2x2(kocr_ctx* ctx, const Tensor& in, const Tensor& out) {
+int launch_maxpool2x2(kocr_ctx* ctx, const Tensor& in, const Tensor& out, int row_off) {
   KOCR_TRY(check_vec(ctx, in, out, "maxpool2x2"));
-  if (out.H != in.H / 2 || out.W != in.W / 2) KOCR_FAIL(ctx, KOCR_EINVAL, "maxpool2x2: bad output size");
+  if (out.H != (in.H - row_off) / 2 || out.W != in.W / 2) KOCR_FAIL(ctx, KOCR_EINVAL, "maxpool2x2: bad output size");
   EwParams p = make_params(in, out);
+  p.row_off = row_off;
   const size_t total = out.pixels() * p.C4;
   if (!total) return KOCR_OK;
   ProfScope ps(ctx, "maxpool2x2", 0, 4.0 * (in.pixels() + out.pixels()) * in.C);

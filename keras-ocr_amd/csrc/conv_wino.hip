@@ -57,17 +57,24 @@ __device__ __forceinline__ int wino_xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int POOL, int NW>  // NW waves per block: 4 (64 couts) or 8 (128 couts share one raw input tile)
+// NW waves per block, WC of them side by side along the output channels (16 couts each); the other
+// NW / WC = WP groups split the tile's four 16-pair M-tiles: wave (wp, wc) owns M-tiles wp, wp+WP, ...
+// <4,4>: 64 couts (default)   <8,8>: 128 couts   <4,2>: 32 couts   <4,1>: 16 couts (narrow head layers)
+template <int POOL, int NW, int WC>
 __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(WinoParams p) {
   constexpr int NT = 64 * NW;
+  constexpr int WP = NW / WC;   // pair groups
+  constexpr int MT = 4 / WP;    // M-tiles (16 pairs each) per wave
+  static_assert(WP * MT == 4 && (!POOL || WP <= 2), "tile split");
   __shared__ float As[2][16][LDA];        // raw input: As[buf][k][1 + pixel], pixel = -1 .. 128
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
 
-  const int nblk_n = p.Cout_pad / (16 * NW);
+  const int nblk_n = p.Cout_pad / (16 * WC);
+  const int wc = wave % WC, wp = wave / WC;
   const int tile = wino_xcd_remap(blockIdx.x, gridDim.x);
   const int mt = tile / nblk_n, nt = tile - mt * nblk_n;
-  const int n0 = nt * 16 * NW;
+  const int n0 = nt * 16 * WC;
   const int quad = tid & 3;
   constexpr int PPI = NT / 4;  // pixels covered by one gather item across the block
   // Tile -> pixels.  POOL == 0: 128 consecutive pixels of the flattened (n, y, x) order (64 pairs); LDS
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
   const float* blk_in = p.in + (pm0 * p.in_cs + p.in_co);
   // weights: this lane's 16 B-operand values of a K-step are 64 contiguous bytes
   const int ntiles16 = p.Cout_pad >> 4;
-  const float* w_ptr = p.wgt + ((size_t)(nt * NW + wave) * 64 + lane) * 16;
+  const float* w_ptr = p.wgt + ((size_t)(nt * WC + wc) * 64 + lane) * 16;
   const size_t w_step = (size_t)ntiles16 * 64 * 16;  // floats per K-step
 
   v4f rr[3];
@@ -159,11 +166,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
     for (int x = 0; x < 4; ++x) bw[0][x] = *reinterpret_cast<const v4f*>(wp_next + 4 * x);
   };
 
-  f32x4 acc[4][4];  // [xi][m-tile of 16 pairs]
+  f32x4 acc[4][MT];  // [xi][own m-tile]; own m-tile m <-> tile index i = wp + WP*m
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[x][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m) acc[x][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto compute_step = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -173,17 +180,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
 #pragma unroll
       for (int x = 0; x < 4; ++x) b[x] = bw[0][x][kq];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int m = 0; m < MT; ++m) {
+        const int i = wp + WP * m;
         const int base = POOL ? (i >> 1) * 80 + 2 * ((i & 1) * 16 + l15) : 2 * (i * 16 + l15);
         const v2f d01 = *reinterpret_cast<const v2f*>(&As[buf][k][base]);      // pixels 2t-1, 2t
         const v2f d23 = *reinterpret_cast<const v2f*>(&As[buf][k][base + 2]);  // pixels 2t+1, 2t+2
         const float d0 = ((lz >> i) & 1u) ? 0.f : d01.x;  // row start: left neighbour is padding
         const float d3 = ((rz >> i) & 1u) ? 0.f : d23.y;  // row end: right neighbour is padding
         const float v0 = d0 - d23.x, v1 = d01.y + d23.x, v2 = d23.x - d01.y, v3 = d01.y - d3;
-        acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, b[0], acc[0][i], 0, 0, 0);
-        acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, b[1], acc[1][i], 0, 0, 0);
-        acc[2][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, b[2], acc[2][i], 0, 0, 0);
-        acc[3][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(v3, b[3], acc[3][i], 0, 0, 0);
+        acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, b[0], acc[0][m], 0, 0, 0);
+        acc[1][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, b[1], acc[1][m], 0, 0, 0);
+        acc[2][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, b[2], acc[2][m], 0, 0, 0);
+        acc[3][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(v3, b[3], acc[3][m], 0, 0, 0);
       }
     }
   };
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
   compute_step((ns - 1) & 1);
 
   // ---- epilogue: 16x16x4 C/D map: col = lane&15, row = (lane>>4)*4 + reg --------------------------
-  const int n = n0 + wave * 16 + l15;
+  const int n = n0 + wc * 16 + l15;
   if (n < p.Cout) {
     const float pa = p.pre_a[n], pb = p.pre_b[n];
     const bool has_post = p.post_a != nullptr;
@@ -226,13 +234,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
       const long nimg = pm0 / ((long)p.H * p.W);
       const long pp0 = (nimg * (p.H >> 1) + (y0t >> 1)) * (p.W >> 1) + (x0t >> 1);
 #pragma unroll
-      for (int ih = 0; ih < 2; ++ih)
+      for (int mh = 0; mh < MT / 2; ++mh)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          const int ih = (WP == 1) ? mh : wp;   // tile index inside the row (0 or 1)
+          constexpr int MR = MT / 2;            // own m-tile of the same columns in row y+1
           const int pp = ih * 16 + l4 * 4 + r;  // pair inside the row == pooled column
           float a0, a1, b0, b1;
-          finish(acc[0][ih][r], acc[1][ih][r], acc[2][ih][r], acc[3][ih][r], a0, a1);                  // row y
-          finish(acc[0][ih + 2][r], acc[1][ih + 2][r], acc[2][ih + 2][r], acc[3][ih + 2][r], b0, b1);  // row y+1
+          finish(acc[0][mh][r], acc[1][mh][r], acc[2][mh][r], acc[3][mh][r], a0, a1);                          // row y
+          finish(acc[0][mh + MR][r], acc[1][mh + MR][r], acc[2][mh + MR][r], acc[3][mh + MR][r], b0, b1);      // row y+1
           if (p.write_full) {
             float* o = p.out + ((pm0 + 2 * pp) * p.out_cs + p.out_co + n);
             o[0] = a0;
@@ -244,12 +254,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
         }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int pair = i * 16 + l4 * 4 + r;
+          const int pair = (wp + WP * m) * 16 + l4 * 4 + r;
           float o0, o1;
-          finish(acc[0][i][r], acc[1][i][r], acc[2][i][r], acc[3][i][r], o0, o1);
+          finish(acc[0][m][r], acc[1][m][r], acc[2][m][r], acc[3][m][r], o0, o1);
           if (pm0 + 2 * pair < p.Mtotal) {  // W even -> Mtotal even -> both pixels of the pair exist
             float* o = p.out + ((pm0 + 2 * pair) * p.out_cs + p.out_co + n);
             o[0] = o0;
@@ -267,7 +277,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
 int prepare_wino(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
   if (L.KH != 3 || L.KW != 3 || L.dil != 1 || L.Cin % 16 != 0) return KOCR_OK;
   const int Cin = L.Cin, Cout = L.Cout;
-  const int cp = (Cout + 63) / 64 * 64;
+  const int wcls = Cout > 32 ? 64 : (Cout > 16 ? 32 : 16);  // couts per block: <4,4>, <4,2>, <4,1>
+  const int cp = (Cout + wcls - 1) / wcls * wcls;
   const int nt16 = cp / 16;
   std::vector<float> u((size_t)(Cin / 16) * 3 * nt16 * 64 * 16, 0.f);
   for (int c = 0; c < Cin; ++c)
@@ -289,13 +300,13 @@ int prepare_wino(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
 bool wino_applicable(const ConvLayer& L, const Tensor& in) {
   static const bool off = getenv("KOCR_WINO") && atoi(getenv("KOCR_WINO")) == 0;
   return !off && L.d_wino && in.W % 2 == 0 && in.cs % 4 == 0 && in.co % 4 == 0 && ((uintptr_t)in.p & 15) == 0 &&
-         L.Cin % 16 == 0 && L.Cout > 32;  // the 64-wide N tile would waste half the MFMAs on <= 32 couts
+         L.Cin % 16 == 0;
 }
 
 int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
                      bool need_full) {
   // fused pooling needs exact 2-row x 64-column tiles
-  const bool fuse = pool && in.H % 2 == 0 && in.W % 64 == 0;
+  const bool fuse = pool && in.H % 2 == 0 && in.W % 64 == 0 && L.Cout > 16;
   const size_t M = in.pixels();
   WinoParams p;
   p.in = in.p;
@@ -329,9 +340,9 @@ int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_wino_128x64%s:%s", fuse ? "p" : "", L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_wino_128x%d%s:%s", L.Cout > 32 ? 64 : (L.Cout > 16 ? 32 : 16), fuse ? "p" : "", L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_wino_128x64%s", fuse ? "_pool" : "");
+    snprintf(nm, sizeof nm, "conv_wino_128x%d%s", L.Cout > 32 ? 64 : (L.Cout > 16 ? 32 : 16), fuse ? "_pool" : "");
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   {
@@ -339,19 +350,31 @@ int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
     // 8-wave blocks (128 couts share one raw input tile) measured no faster than 4-wave ones;
     // kept as a developer A/B switch
     static const bool use8 = getenv("KOCR_WINO_NW8") != nullptr;
-    const bool wide = use8 && p.Cout_pad % 128 == 0;
-    if (wide) {
-      dim3 grid((unsigned)(((M + 127) / 128) * (p.Cout_pad / 128)));
+    const size_t mtiles = (M + 127) / 128;
+    if (L.Cout > 32) {
+      const bool wide = use8 && p.Cout_pad % 128 == 0;
+      if (wide) {
+        dim3 grid((unsigned)(mtiles * (p.Cout_pad / 128)));
+        if (fuse)
+          hipLaunchKernelGGL((conv_wino_kernel<1, 8, 8>), grid, dim3(512), 0, ctx->stream, p);
+        else
+          hipLaunchKernelGGL((conv_wino_kernel<0, 8, 8>), grid, dim3(512), 0, ctx->stream, p);
+      } else {
+        dim3 grid((unsigned)(mtiles * (p.Cout_pad / 64)));
+        if (fuse)
+          hipLaunchKernelGGL((conv_wino_kernel<1, 4, 4>), grid, dim3(256), 0, ctx->stream, p);
+        else
+          hipLaunchKernelGGL((conv_wino_kernel<0, 4, 4>), grid, dim3(256), 0, ctx->stream, p);
+      }
+    } else if (L.Cout > 16) {
+      dim3 grid((unsigned)(mtiles * (p.Cout_pad / 32)));
       if (fuse)
-        hipLaunchKernelGGL((conv_wino_kernel<1, 8>), grid, dim3(512), 0, ctx->stream, p);
+        hipLaunchKernelGGL((conv_wino_kernel<1, 4, 2>), grid, dim3(256), 0, ctx->stream, p);
       else
-        hipLaunchKernelGGL((conv_wino_kernel<0, 8>), grid, dim3(512), 0, ctx->stream, p);
+        hipLaunchKernelGGL((conv_wino_kernel<0, 4, 2>), grid, dim3(256), 0, ctx->stream, p);
     } else {
-      dim3 grid((unsigned)(((M + 127) / 128) * (p.Cout_pad / 64)));
-      if (fuse)
-        hipLaunchKernelGGL((conv_wino_kernel<1, 4>), grid, dim3(256), 0, ctx->stream, p);
-      else
-        hipLaunchKernelGGL((conv_wino_kernel<0, 4>), grid, dim3(256), 0, ctx->stream, p);
+      dim3 grid((unsigned)(mtiles * (p.Cout_pad / 16)));
+      hipLaunchKernelGGL((conv_wino_kernel<0, 4, 1>), grid, dim3(256), 0, ctx->stream, p);
     }
     KOCR_HIP(ctx, hipGetLastError());
   }

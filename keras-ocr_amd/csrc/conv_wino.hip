@@ -71,7 +71,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
   const int l15 = lane & 15, l4 = lane >> 4;
 
   const int nblk_n = p.Cout_pad / (16 * WC);
-  const int wc = wave % WC, wp = wave / WC;
+  // compile-time zero when there is a single pair group, so the M-tile indices stay constants
+  const int wc = (WC == NW) ? wave : wave % WC, wp = (WP == 1) ? 0 : wave / WC;
   const int tile = wino_xcd_remap(blockIdx.x, gridDim.x);
   const int mt = tile / nblk_n, nt = tile - mt * nblk_n;
   const int n0 = nt * 16 * WC;

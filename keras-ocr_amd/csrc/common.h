@@ -64,6 +64,7 @@ struct ConvLayer {
   float* d_post_a = nullptr;  // [Cout_pad] or nullptr: out = relu?(v)*post_a + post_b
   float* d_post_b = nullptr;
   int relu = 0;
+  float* d_w_rgb4 = nullptr;  // first layer on raw uint8: [9 taps][R,G,B,0][Cout_pad] (48 rows)
   float* d_wino = nullptr;    // Winograd F(2,3) weights U[Cin/16][3][4][16][wino_cout_pad] (3x3, dil 1, Cin%16==0)
   int wino_cout_pad = 0;
   bool tap_inner = false;  // K order [16-channel group][tap][16] (Cin % 16 == 0) instead of [tap][Cin]

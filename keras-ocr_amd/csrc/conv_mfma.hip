@@ -103,6 +103,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
 
   __shared__ float As[2][BK][LDA];
   __shared__ float Bs[2][BK][LDB];
+  __shared__ float lut_s[MODE == 2 ? 768 : 1];  // compute_input table (first layer, uint8 input)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -188,6 +189,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
   }
 
   // staging registers; PF == 1 keeps two K-steps in flight (prefetch distance 2)
+  if constexpr (MODE == 2) {
+    for (int i = tid; i < 768; i += NT) lut_s[i] = p.lut[i];
+    __syncthreads();
+  }
   v4f ra0[A_PER_T], rb0[B_PER_T];
   v4f ra1[(PF == 1) ? A_PER_T : 1], rb1[(PF == 1) ? B_PER_T : 1];
 
@@ -208,6 +213,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
         ra[i] = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
       }
       walk = walk_next(w, p, BK);
+    } else if constexpr (MODE == 2) {
+      // first layer, raw uint8 RGB: K order = [tap][R, G, B, 0], so one float4 of the K-step is one
+      // tap of one pixel: 3 byte loads + 3 LDS table look-ups, no divisions
+      const int tap = ch * (BK / 4) + quad;
+      const int ky = tap / 3, kx = tap - ky * 3;  // 3x3 only
+      const int dy = ky - 1, dx = kx - 1;
+#pragma unroll
+      for (int i = 0; i < A_PER_T; ++i) {
+        const int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        if (tap < 9 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+          const uint8_t* px = p.in_u8 + (a_pm[i] + (long)dy * p.W + dx) * 3;
+          v.x = lut_s[px[0]];
+          v.y = lut_s[256 + px[1]];
+          v.z = lut_s[512 + px[2]];
+        }
+        ra[i] = v;
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < A_PER_T; ++i) {
@@ -231,10 +254,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
             const int iy = a_oy[i] + dy, ix = a_ox[i] + dx;
             if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
               const long off = (a_pm[i] + (long)dy * p.W + dx) * p.in_cs + p.in_co + c;
-              if constexpr (MODE == 2)
-                v = p.lut[c * 256 + p.in_u8[off]];
-              else
-                v = p.in[off];
+              v = p.in[off];
             }
           }
           e[q] = v;
@@ -429,6 +449,15 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
         }
   KOCR_TRY(ctx->upload(&L.d_w, wp));
   KOCR_TRY(prepare_wino(ctx, L, w, w_is_oihw));
+  if (Cin == 3 && KH == 3 && KW == 3 && dil == 1) {  // uint8 first layer: K order [tap][R,G,B,0], 48 rows
+    std::vector<float> w4((size_t)48 * L.Cout_pad, 0.f);
+    for (int tap = 0; tap < 9; ++tap)
+      for (int c = 0; c < 3; ++c)
+        for (int o = 0; o < Cout; ++o)
+          w4[(size_t)(tap * 4 + c) * L.Cout_pad + o] =
+              w_is_oihw ? w[(((size_t)o * 3 + c) * 3 + tap / 3) * 3 + tap % 3] : w[((size_t)tap * 3 + c) * Cout + o];
+    KOCR_TRY(ctx->upload(&L.d_w_rgb4, w4));
+  }
   std::vector<float> a(L.Cout_pad, 1.f), b(L.Cout_pad, 0.f);
   for (int o = 0; o < Cout; ++o) {
     if (pre_a) a[o] = pre_a[o];
@@ -545,8 +574,12 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
   }
   p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
   int mode;
-  if (in_u8)
+  if (in_u8) {
+    if (!L.d_w_rgb4) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": uint8 input needs a 3x3, 3-channel layer");
     mode = 2;
+    p.wgt = L.d_w_rgb4;
+    p.nchunks = 3;
+  }
   else if (L.Cin % 16 == 0 && in.cs % 4 == 0 && in.co % 4 == 0 && ((uintptr_t)in.p & 15) == 0)
     mode = 0;
   else

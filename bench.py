@@ -188,7 +188,7 @@ def main():
         if cands:
             pm = json.load(open(cands[-1]))
             if name.startswith("conv_wino"):
-                want = "void conv_wino_kernel<%d>" % (1 if name.endswith("_pool") else 0)
+                want = "void conv_wino_kernel<%d, 4, 4>" % (1 if name.endswith("_pool") else 0)
             else:
                 want = "void conv_mfma_kernel<128, 128, 2, 2, 0, 16, 0, %d>" % (1 if name.endswith("_pool") else 0)
             for kname, row in pm["kernels"].items():

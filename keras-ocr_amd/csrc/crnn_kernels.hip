@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void lstm_kernel(const float* __restrict__ xp,
   }
 }
 
-// logits: [M][T][C] (C <= 64); labels: [M][T-discard] (-1 padded); probs (nullable): [M][T-discard][C]
+// logits: [M][T][C]; labels: [M][T-discard] (-1 padded); probs (nullable): [M][T-discard][C].
+// One wave per crop; lane l owns classes l, l+64, ... (any alphabet size).
 __global__ void ctc_kernel(const float* __restrict__ logits, int M, int T, int C, int discard, int* __restrict__ labels,
                            float* __restrict__ probs) {
   const int lane = threadIdx.x & 63;
@@ -145,10 +146,17 @@ __global__ void ctc_kernel(const float* __restrict__ logits, int M, int T, int C
   int prev = -1, k = 0;
   for (int t = 0; t < To; ++t) {
     const float* row = logits + ((size_t)m * T + t + discard) * C;
-    const float v = lane < C ? row[lane] : -INFINITY;
-    // argmax with lowest index on ties: reduce (value, index) pairs
-    float bv = v;
-    int bi = lane < C ? lane : 0x7fffffff;
+    // per-lane argmax over its classes (ascending class index: first maximum wins), then the
+    // wave-level reduction of (value, index) pairs with lowest index on ties
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+      const float v = row[c];
+      if (v > bv) {
+        bv = v;
+        bi = c;
+      }
+    }
     for (int o = 32; o; o >>= 1) {
       const float ov = __shfl_xor(bv, o);
       const int oi = __shfl_xor(bi, o);
@@ -158,10 +166,10 @@ __global__ void ctc_kernel(const float* __restrict__ logits, int M, int T, int C
       }
     }
     if (probs) {
-      const float e = lane < C ? expf(v - bv) : 0.f;
-      float s = e;
+      float s = 0.f;
+      for (int c = lane; c < C; c += 64) s += expf(row[c] - bv);
       for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
-      if (lane < C) probs[((size_t)m * To + t) * C + lane] = e / s;
+      for (int c = lane; c < C; c += 64) probs[((size_t)m * To + t) * C + c] = expf(row[c] - bv) / s;
     }
     if (lane == 0) {
       if (bi != prev && bi != blank) labels[(size_t)m * To + k++] = bi;
@@ -218,7 +226,6 @@ int launch_lstm(kocr_ctx* ctx, const float* d_xp, const float* d_Uf, const float
 
 int launch_ctc(kocr_ctx* ctx, const float* d_logits, int M, int T, int C, int discard, int* d_labels, float* d_probs) {
   if (M <= 0) return KOCR_OK;
-  if (C > 64) KOCR_FAIL(ctx, KOCR_EINVAL, "ctc: alphabet larger than 63 symbols is not supported by the wave decoder");
   ProfScope ps(ctx, "ctc_greedy", 0, 4.0 * M * T * C);
   hipLaunchKernelGGL(ctc_kernel, dim3((M + 3) / 4), dim3(256), 0, ctx->stream, d_logits, M, T, C, discard, d_labels,
                      d_probs);

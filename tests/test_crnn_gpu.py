@@ -68,3 +68,25 @@ def test_ctc_collapse_rules(crnn_ctx):
             prev = c
         want = want + [-1] * (48 - len(want))
         assert list(row) == want
+
+
+def test_large_custom_alphabet(ctx):
+    """Recognizer(alphabet=...) with more symbols than a wavefront has lanes (recognition.py:365-404
+    builds fc_12 with len(alphabet)+1 classes): the wave decoder strides classes over lanes."""
+    import keras_ocr_amd
+    from oracle import crnn as ocrnn
+
+    n_classes = 96
+    w = keras_ocr_amd.weights.synthetic_crnn_weights(4321, n_classes=n_classes)
+    c2 = keras_ocr_amd.Context(0)
+    c2.load_crnn(w)
+    assert c2.crnn_classes() == n_classes
+    x = _crops(6, seed=7)
+    labels, probs = c2.crnn_forward(x, return_probs=True)
+    want_p = ocrnn.crnn_forward(w, x[..., None])
+    assert float(np.abs(probs - want_p).max()) <= PROB_TOL
+    srt = np.sort(want_p, -1)
+    safe = ((srt[..., -1] - srt[..., -2]) > MARGIN).all(1)
+    assert np.array_equal(labels[safe], ocrnn.ctc_greedy_decode(want_p)[safe])
+    assert labels.max() < n_classes - 1
+    c2.close()

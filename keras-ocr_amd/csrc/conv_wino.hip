@@ -18,9 +18,10 @@
 // output channels [16w,16w+16) for ALL four points, so the inverse transform in the epilogue is
 // register-only: the 16x16x4 MFMA C/D map puts M_0..M_3 of one (pair, channel) in the same lane.
 // U_xi is pre-transformed on the host and packed in MFMA-operand order, [16-channel group][ky]
-// [16-cout tile][lane][xi*4+kq], so a lane fetches the 16 B-operand values of a K-step with four
-// 16-B loads straight into registers (4 KB contiguous per wave, prefetched one K-step ahead): the
-// weights never touch LDS.  Requires W even (a pair never straddles an image row); a tile may cross rows
+// [16-cout tile][lane][kq*4+xi], so a lane fetches the four B operands of a k-quad with one 16-B load
+// straight into registers (4 KB contiguous per wave and K-step); the load for the NEXT K-step's
+// k-quad is issued right after the MFMAs that consumed the current one (rolling prefetch, no second
+// register set): the weights never touch LDS.  Requires W even (a pair never straddles an image row); a tile may cross rows
 // and images: the flattened neighbours that fall across a row end are zeroed per pair in registers.
 #include "common.h"
 
@@ -30,7 +31,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct WinoParams {
   const float* in;
-  const float* wgt;  // U: [Cin/16][3][Cout_pad/16][64 lanes][16 = xi*4 + kq]
+  const float* wgt;  // U: [Cin/16][3][Cout_pad/16][64 lanes][16 = kq*4 + xi]
   float* out;
   const float* pre_a;
   const float* pre_b;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
   const size_t w_step = (size_t)ntiles16 * 64 * 16;  // floats per K-step
 
   v4f rr[3];
-  v4f bw[1][4];  // B operands of the current K-step: [xi] -> .x/.y/.z/.w = kq 0..3
+  v4f bw[4];  // B operands of the current K-step: [kq] -> .x/.y/.z/.w = xi 0..3
   const float* wp_next = nullptr;
   int st_ky = 0, st_cg = 0;  // position of the NEXT step to load
   auto load_step = [&]() __attribute__((always_inline)) {
@@ -163,8 +164,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
         As[buf][quad * 4 + 3][lpos[j]] = rr[j].w;
       }
     }
-#pragma unroll
-    for (int x = 0; x < 4; ++x) bw[0][x] = *reinterpret_cast<const v4f*>(wp_next + 4 * x);
   };
 
   f32x4 acc[4][MT];  // [xi][own m-tile]; own m-tile m <-> tile index i = wp + WP*m
@@ -177,9 +176,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) {
       const int k = kq * 4 + l4;  // 16x16x4: A[row = lane&15][k = lane>>4], B[k = lane>>4][col = lane&15]
-      float b[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) b[x] = bw[0][x][kq];
+      const v4f b = bw[kq];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int i = wp + WP * m;
@@ -194,15 +191,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
         acc[2][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, b[2], acc[2][m], 0, 0, 0);
         acc[3][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(v3, b[3], acc[3][m], 0, 0, 0);
       }
+      // this k-quad's operands are consumed: fetch the same k-quad of the next K-step into them
+      bw[kq] = *reinterpret_cast<const v4f*>(wp_next + 4 * kq);
     }
   };
 
   load_step();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bw[q] = *reinterpret_cast<const v4f*>(wp_next + 4 * q);  // K-step 0
   store_step(0);
   __syncthreads();
   const int ns = p.nsteps;
   for (int s = 0; s + 1 < ns; ++s) {
-    load_step();
+    load_step();  // also points wp_next at K-step s+1
     __builtin_amdgcn_sched_barrier(0);
     compute_step(s & 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -292,7 +293,7 @@ int prepare_wino(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
         // MFMA 16x16x4 B operand: lane = (k & 3) * 16 + (o & 15) holds k-quad kq = (k >> 2) of the step
         const int k = c % 16, lane = (k & 3) * 16 + (o & 15), kq = k >> 2;
         for (int xi = 0; xi < 4; ++xi)
-          u[((((size_t)(c / 16) * 3 + ky) * nt16 + o / 16) * 64 + lane) * 16 + xi * 4 + kq] = U[xi];
+          u[((((size_t)(c / 16) * 3 + ky) * nt16 + o / 16) * 64 + lane) * 16 + kq * 4 + xi] = U[xi];
       }
   L.wino_cout_pad = cp;
   return ctx->upload(&L.d_wino, u);

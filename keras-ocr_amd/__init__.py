@@ -5,5 +5,5 @@ directory, whose name is not a valid Python identifier).  Same surface as the re
 ``keras_ocr`` for the inference path: ``pipeline.Pipeline``, ``detection.Detector``,
 ``recognition.Recognizer``, ``tools``.
 """
-from . import _lib, weights, tools, detection, recognition, pipeline, dist  # noqa: F401
+from . import _lib, weights, tools, detection, recognition, pipeline, dist, evaluation  # noqa: F401
 from ._lib import Context, KocrError, load_library, default_context  # noqa: F401

@@ -1,0 +1,165 @@
+"""Host-side mirror of ``keras_ocr.evaluation`` (reference ``keras_ocr/evaluation.py:13-147``):
+polygon IoU and precision/recall scoring of pipeline output.  SURVEY.md §8(f) item 4 — off the hot
+path, pure numpy/Python: pyclipper, cv2.contourArea and editdistance are re-stated (simple polygons
+are triangulated by ear clipping and intersected triangle by triangle with Sutherland-Hodgman)."""
+import copy
+import typing
+import warnings
+
+import numpy as np
+
+
+def _area2(poly):
+    x, y = poly[:, 0], poly[:, 1]
+    return float(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1)))
+
+
+def _ccw(poly):
+    return poly if _area2(poly) > 0 else poly[::-1]
+
+
+def _triangulate(poly):
+    """Ear clipping of a simple polygon (counter-clockwise) -> list of (3,2) triangles."""
+    pts = [tuple(map(float, p)) for p in _ccw(np.asarray(poly, dtype=np.float64))]
+    pts = [p for i, p in enumerate(pts) if p != pts[i - 1]]
+    tris = []
+
+    def cross(o, a, b):
+        return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+
+    guard = 0
+    while len(pts) > 3 and guard < 10000:
+        guard += 1
+        n = len(pts)
+        for i in range(n):
+            a, b, c = pts[i - 1], pts[i], pts[(i + 1) % n]
+            if cross(a, b, c) <= 0:
+                continue  # reflex or degenerate corner
+            if any(cross(a, b, q) >= 0 and cross(b, c, q) >= 0 and cross(c, a, q) >= 0
+                   for q in pts if q not in (a, b, c)):
+                continue
+            tris.append(np.array([a, b, c]))
+            del pts[i]
+            break
+        else:
+            break  # numerically degenerate: stop with what is left
+    if len(pts) == 3:
+        tris.append(np.array(pts))
+    return tris
+
+
+def _clip_convex(subject, clip):
+    """Sutherland-Hodgman: subject polygon clipped by a CONVEX counter-clockwise clip polygon."""
+    out = [tuple(p) for p in subject]
+    n = len(clip)
+    for i in range(n):
+        a, b = clip[i], clip[(i + 1) % n]
+        inp, out = out, []
+        if not inp:
+            break
+
+        def inside(p):
+            return (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0]) >= 0
+
+        def inter(p, q):
+            d1 = (b[0] - a[0], b[1] - a[1])
+            d2 = (q[0] - p[0], q[1] - p[1])
+            den = d1[0] * d2[1] - d1[1] * d2[0]
+            t = ((p[0] - a[0]) * d2[1] - (p[1] - a[1]) * d2[0]) / den
+            return (a[0] + t * d1[0], a[1] + t * d1[1])
+
+        s = inp[-1]
+        for e in inp:
+            if inside(e):
+                if not inside(s):
+                    out.append(inter(s, e))
+                out.append(e)
+            elif inside(s):
+                out.append(inter(s, e))
+            s = e
+    return np.array(out, dtype=np.float64) if len(out) >= 3 else None
+
+
+def iou_score(box1, box2):
+    """evaluation.iou_score (evaluation.py:13-53): IoU of two polygons given as lists of (x, y);
+    a 2-point box is an axis-aligned (x1,y1),(x2,y2) rectangle; coordinates are truncated to int32
+    like the reference does before clipping."""
+    if len(box1) == 2:
+        (x1, y1), (x2, y2) = box1
+        box1 = np.array([[x1, y1], [x2, y1], [x2, y2], [x1, y2]])
+    if len(box2) == 2:
+        (x1, y1), (x2, y2) = box2
+        box2 = np.array([[x1, y1], [x2, y1], [x2, y2], [x1, y2]])
+    p1 = np.array(box1, dtype="int32").astype(np.float64)
+    p2 = np.array(box2, dtype="int32").astype(np.float64)
+    a1, a2 = abs(_area2(p1)) / 2, abs(_area2(p2)) / 2
+    if a1 == 0 or a2 == 0:
+        warnings.warn("A box with zero area was detected.")
+        return 0
+    intersection = 0.0
+    for t1 in _triangulate(p1):
+        for t2 in _triangulate(p2):
+            c = _clip_convex(_ccw(t1), _ccw(t2))
+            if c is not None:
+                intersection += abs(_area2(c)) / 2
+    union = a1 + a2 - intersection
+    return intersection / union
+
+
+def _edit_distance(a, b):
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def score(true, pred, iou_threshold=0.5, similarity_threshold=0.5, translator=None):
+    """evaluation.score (evaluation.py:56-147): same arguments, same return value
+    ``(results, (precision, recall))``."""
+    true_ids = sorted(true)
+    pred_ids = sorted(pred)
+    assert all(true_id == pred_id for true_id, pred_id in zip(true_ids, pred_ids)), \
+        "true and pred dictionaries must have the same keys"
+    results: typing.Dict[str, typing.List[dict]] = {
+        "true_positives": [], "false_positives": [], "near_true_positives": [], "false_negatives": []}
+    for image_id in true_ids:
+        true_anns = true[image_id]
+        pred_anns = copy.deepcopy(pred[image_id])
+        pred_matched = set()
+        for true_index, true_ann in enumerate(true_anns):
+            match = None
+            for pred_index, pred_ann in enumerate(pred_anns):
+                iou = iou_score(true_ann["vertices"], pred_ann["vertices"])
+                if iou >= iou_threshold:
+                    match = {"true_idx": true_index, "pred_idx": pred_index, "image_id": image_id}
+                    pred_matched.add(pred_index)
+                    true_text = true_ann["text"]
+                    pred_text = pred_ann["text"]
+                    if true_ann.get("ignore", False):
+                        continue
+                    if translator is not None:
+                        true_text = true_text.translate(translator)
+                        pred_text = pred_text.translate(translator)
+                    edit_distance_norm = max(len(true_text), len(pred_text))
+                    if edit_distance_norm == 0:
+                        similarity = 1
+                    else:
+                        similarity = 1 - (_edit_distance(true_text, pred_text) / edit_distance_norm)
+                    if similarity >= similarity_threshold:
+                        results["true_positives"].append(match)
+                    else:
+                        results["near_true_positives"].append(match)
+            if match is None and not true_ann.get("ignore", False):
+                results["false_negatives"].append({"image_id": image_id, "true_idx": true_index})
+        results["false_positives"].extend(
+            {"pred_index": pred_index, "image_id": image_id}
+            for pred_index, _ in enumerate(pred_anns) if pred_index not in pred_matched)
+    fns = len(results["false_negatives"])
+    fps = len(results["false_positives"])
+    tps = len(set((tp["image_id"], tp["true_idx"]) for tp in results["true_positives"]))
+    precision = tps / (tps + fps)
+    recall = tps / (tps + fns)
+    return results, (precision, recall)

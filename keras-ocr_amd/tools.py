@@ -152,3 +152,45 @@ def download_and_verify(url, sha256=None, cache_dir=None, verbose=True, filename
         urllib.request.urlretrieve(url, filepath)
     assert sha256 is None or sha256 == sha256sum(filepath), "Error occurred verifying sha256."
     return filepath
+
+
+def drawBoxes(image, boxes, color=(255, 0, 0), thickness=5, boxes_format="boxes"):  # pylint: disable=invalid-name
+    """tools.drawBoxes (tools.py:189-229) on PIL instead of cv2.polylines (visual helper)."""
+    from PIL import Image, ImageDraw  # pylint: disable=import-outside-toplevel
+
+    if len(boxes) == 0:
+        return image
+    if boxes_format == "lines":
+        boxes = [box for line in boxes for box, _ in line]
+    if boxes_format == "predictions":
+        boxes = [box for _, box in boxes]
+    canvas = Image.fromarray(np.ascontiguousarray(image))
+    draw = ImageDraw.Draw(canvas)
+    for box in boxes:
+        pts = [tuple(int(v) for v in p) for p in np.asarray(box)]
+        draw.line(pts + [pts[0]], fill=tuple(color), width=int(thickness), joint="curve")
+    return np.asarray(canvas)
+
+
+def drawAnnotations(image, predictions, ax=None):  # pylint: disable=invalid-name
+    """tools.drawAnnotations (tools.py:150-186): boxes + arrowed text labels on a matplotlib axis."""
+    import matplotlib.pyplot as plt  # pylint: disable=import-outside-toplevel
+
+    if ax is None:
+        _, ax = plt.subplots()
+    ax.imshow(drawBoxes(image=image, boxes=predictions, boxes_format="predictions"))
+    predictions = sorted(predictions, key=lambda p: p[1][:, 1].min())
+    left, right = [], []
+    for word, box in predictions:
+        (left if box[:, 0].min() < image.shape[1] / 2 else right).append((word, box))
+    ax.set_yticks([])
+    ax.set_xticks([])
+    for side, group in zip(["left", "right"], [left, right]):
+        for index, (text, box) in enumerate(group):
+            y = 1 - (index / len(group))
+            xy = box[0] / np.array([image.shape[1], image.shape[0]])
+            xy[1] = 1 - xy[1]
+            ax.annotate(text=text, xy=xy, xytext=(-0.05 if side == "left" else 1.05, y), xycoords="axes fraction",
+                        arrowprops={"arrowstyle": "->", "color": "r"}, color="r", fontsize=14,
+                        horizontalalignment="right" if side == "left" else "left")
+    return ax

@@ -116,6 +116,19 @@ int kocr_crnn_forward(kocr_ctx* ctx, const float* crops, int M, int32_t* labels,
 /* len(alphabet) + 1 of the loaded recogniser (recognition.py:323), 0 if none is loaded. */
 int kocr_crnn_classes(kocr_ctx* ctx);
 
+/* ---- Detector.detect (detection.py:745-785): compute_input + predict + getBoxes in one call; the
+ * heat-maps stay in HBM.  Arguments as kocr_craft_forward + kocr_get_boxes; counts is a HOST array. */
+int kocr_detect(kocr_ctx* ctx, const void* img, int dtype, int N, int H, int W,
+                float detection_threshold, float text_threshold, float link_threshold,
+                int size_threshold, int micro_batch, float* boxes, int32_t* counts, int cap,
+                int on_device);
+
+/* ---- Recognizer.recognize_from_boxes (recognition.py:491-537) for N same-sized images: gray
+ * conversion + warpBox crops + prediction_model.predict without leaving HBM.  boxes [M][4][2],
+ * counts [N] and labels [M][48] are HOST buffers; img_rgb is a device pointer if on_device. */
+int kocr_recognize_boxes(kocr_ctx* ctx, const uint8_t* img_rgb, int N, int H, int W,
+                         const float* boxes, const int32_t* counts, int32_t* labels, int on_device);
+
 /* ---- tools.resize_image + tools.pad (tools.py:356-398; pipeline.py:44-57) -------------- */
 /* src: n x sh x sw x 3 uint8 (n images of one size); each is resized to dh x dw exactly as
  * cv2.resize(image, dsize=(dw, dh)) (INTER_LINEAR, uint8 fixed point) and written to the

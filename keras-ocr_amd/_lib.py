@@ -63,6 +63,8 @@ def load_library():
         "kocr_crnn_classes": (ci, [vp]),
         "kocr_get_boxes": (ci, [vp, vp, ci, ci, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, vp, vp, ci, ci]),
         "kocr_warp_crops": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, ci, vp, ci]),
+        "kocr_detect": (ci, [vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, ci, ci]),
+        "kocr_recognize_boxes": (ci, [vp, vp, ci, ci, ci, vp, vp, vp, ci]),
         "kocr_resize_pad": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci]),
         "kocr_pipeline": (ci, [vp, ci, ctypes.POINTER(vp), _c_int_p, _c_int_p, _c_int_p, _c_int_p, ci, ci,
                                ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, ci, vp, ci, vp, ci]),
@@ -218,6 +220,49 @@ class Context:
             self._check(rc)
             break
         return [boxes[i, :counts[i]].copy() if counts[i] else np.array([]) for i in range(n)]
+
+    # -- Detector.detect, device-resident heat-maps -----------------------------------------------
+    def detect(self, images, detection_threshold=0.7, text_threshold=0.4, link_threshold=0.4, size_threshold=10,
+               micro_batch=0, cap=None):
+        """images: (N,H,W,3) uint8 (raw RGB) or float32 (normalised).  Returns list of (n_i,4,2) boxes."""
+        x = np.ascontiguousarray(images)
+        dt = KOCR_U8 if x.dtype == np.uint8 else KOCR_F32
+        if dt == KOCR_F32:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+        n, h, w, _ = x.shape
+        cap = int(cap) if cap else 1024
+        while True:
+            boxes = np.zeros((n, cap, 4, 2), dtype=np.float32)
+            counts = np.zeros(n, dtype=np.int32)
+            rc = self._lib.kocr_detect(self._h, _ptr(x), dt, n, h, w, float(detection_threshold), float(text_threshold),
+                                       float(link_threshold), int(size_threshold), int(micro_batch), _ptr(boxes),
+                                       _ptr(counts), cap, 0)
+            if rc == -4 and n and counts.max() > cap:
+                cap = int(counts.max())
+                continue
+            if rc == -6:
+                raise IndexError("list index out of range")
+            self._check(rc)
+            break
+        return [boxes[i, :counts[i]].copy() if counts[i] else np.array([]) for i in range(n)]
+
+    # -- Recognizer.recognize_from_boxes, device-resident crops ---------------------------------------
+    def recognize_boxes(self, images, box_groups):
+        """images: (N,H,W,3) uint8; box_groups: list of (n_i,4,2).  Returns labels (M,48) int32."""
+        x = np.ascontiguousarray(images, dtype=np.uint8)
+        n, h, w, _ = x.shape
+        counts = np.array([len(b) for b in box_groups], dtype=np.int32)
+        m = int(counts.sum())
+        labels = np.full((m, 48), -1, dtype=np.int32)
+        if m == 0:
+            return labels
+        flat = np.ascontiguousarray(
+            np.concatenate([np.asarray(b, dtype=np.float32).reshape(-1, 4, 2) for b in box_groups if len(b)]))
+        rc = self._lib.kocr_recognize_boxes(self._h, _ptr(x), n, h, w, _ptr(flat), _ptr(counts), _ptr(labels), 0)
+        if rc == -7:
+            raise ZeroDivisionError("division by zero")
+        self._check(rc)
+        return labels
 
     # -- crops --------------------------------------------------------------------------------
     def warp_crops(self, images, box_groups, target_height=31, target_width=200):

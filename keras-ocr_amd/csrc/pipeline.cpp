@@ -32,6 +32,107 @@ extern "C" int kocr_resize_pad(kocr_ctx* ctx, const uint8_t* src, int n, int sh,
   return KOCR_OK;
 }
 
+// Detector.detect's device half in one call: CRAFT forward + getBoxes, heat-maps never leave HBM.
+extern "C" int kocr_detect(kocr_ctx* ctx, const void* img, int dtype, int N, int H, int W, float detection_threshold,
+                           float text_threshold, float link_threshold, int size_threshold, int micro_batch,
+                           float* boxes, int32_t* counts, int cap, int on_device) {
+  if (!ctx) return KOCR_EINVAL;
+  if (N < 0 || (N > 0 && (!img || !boxes || !counts))) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_detect: null buffer");
+  if (dtype != KOCR_U8 && dtype != KOCR_F32) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_detect: bad dtype");
+  if (N == 0) return KOCR_OK;
+  if (cap <= 0) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_detect: cap must be positive");
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  const int h2 = H / 2, w2 = W / 2;
+  const size_t esz = dtype == KOCR_U8 ? 1 : 4;
+  const size_t in_b = (size_t)N * H * W * 3 * esz;
+  const size_t heat_b = (size_t)N * h2 * w2 * 2 * sizeof(float);
+  const size_t box_b = (size_t)N * cap * 8 * sizeof(float);
+  KOCR_TRY(arena_reserve(ctx, ctx->pl, heat_b + box_b + (on_device ? 0 : in_b) + 4096));
+  ctx->pl.off = 0;
+  float* d_heat = (float*)arena_alloc(ctx->pl, heat_b);
+  float* d_boxes = on_device ? boxes : (float*)arena_alloc(ctx->pl, box_b);
+  const char* d_in = (const char*)img;
+  if (!on_device) {
+    char* di = (char*)arena_alloc(ctx->pl, in_b);
+    if (!di) KOCR_FAIL(ctx, KOCR_ENOMEM, "kocr_detect: arena exhausted");
+    KOCR_HIP(ctx, hipMemcpyAsync(di, img, in_b, hipMemcpyHostToDevice, ctx->stream));
+    d_in = di;
+  }
+  if (!d_heat || !d_boxes) KOCR_FAIL(ctx, KOCR_ENOMEM, "kocr_detect: arena exhausted");
+  int mb = micro_batch > 0 ? micro_batch : 32;
+  while (mb > 1 && craft_workspace_bytes(mb, H, W) > ((size_t)64 << 30)) mb = (mb + 1) / 2;
+  mb = std::min(mb, N);
+  KOCR_TRY(ctx->ws_reserve(craft_workspace_bytes(mb, H, W)));
+  for (int s = 0; s < N; s += mb) {
+    const int nb = std::min(mb, N - s);
+    ctx->ws_reset();
+    KOCR_TRY(craft_forward(ctx, d_in + (size_t)s * H * W * 3 * esz, dtype, nb, H, W, d_heat + (size_t)s * h2 * w2 * 2));
+  }
+  int n_empty = 0;
+  KOCR_TRY(postproc_get_boxes(ctx, d_heat, N, h2, w2, detection_threshold, text_threshold, link_threshold,
+                              size_threshold, d_boxes, cap, counts, &n_empty));
+  if (!on_device) {
+    KOCR_HIP(ctx, hipMemcpyAsync(boxes, d_boxes, box_b, hipMemcpyDeviceToHost, ctx->stream));
+    KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (n_empty > 0)
+    KOCR_FAIL(ctx, KOCR_EEMPTYCONTOUR, "kocr_detect: empty contour list (IndexError at detection.py:272)");
+  return KOCR_OK;
+}
+
+// Recognizer.recognize_from_boxes' device half in one call: crops are warped and recognised without
+// leaving HBM.  All N images share one size; boxes/counts/labels are HOST buffers.
+extern "C" int kocr_recognize_boxes(kocr_ctx* ctx, const uint8_t* img_rgb, int N, int H, int W, const float* boxes,
+                                    const int32_t* counts, int32_t* labels, int on_device) {
+  if (!ctx) return KOCR_EINVAL;
+  if (N < 0 || (N > 0 && (!img_rgb || !counts))) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_recognize_boxes: null buffer");
+  const int C = crnn_classes(ctx);
+  if (C == 0) KOCR_FAIL(ctx, KOCR_ENOWEIGHTS, "kocr_recognize_boxes: call kocr_load_crnn first");
+  long M = 0;
+  for (int i = 0; i < N; ++i) {
+    if (counts[i] < 0) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_recognize_boxes: negative count");
+    M += counts[i];
+  }
+  if (M == 0) return KOCR_OK;
+  if (!boxes || !labels) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_recognize_boxes: null buffer");
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<WarpParam> prm((size_t)M);
+  long m = 0;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < counts[i]; ++j, ++m) {
+      const int rc = warp_prepare(boxes + m * 8, 31, 200, &prm[m], nullptr);
+      if (rc == 1) KOCR_FAIL(ctx, KOCR_EZERODIV, "kocr_recognize_boxes: box with zero width or height (tools.py:95)");
+      if (rc != 0) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_recognize_boxes: singular perspective transform");
+      prm[m].img = i;
+    }
+  const size_t ib = (size_t)N * H * W * 3, crop_b = (size_t)M * 31 * 200 * sizeof(float);
+  const size_t lab_b = (size_t)M * 48 * sizeof(int32_t), pb = (size_t)M * sizeof(WarpParam);
+  KOCR_TRY(arena_reserve(ctx, ctx->io, pb + crop_b + lab_b + (on_device ? 0 : ib) + 4096));
+  ctx->io.off = 0;
+  WarpParam* d_prm = (WarpParam*)arena_alloc(ctx->io, pb);
+  float* d_crops = (float*)arena_alloc(ctx->io, crop_b);
+  int32_t* d_lab = (int32_t*)arena_alloc(ctx->io, lab_b);
+  const uint8_t* d_img = img_rgb;
+  if (!on_device) {
+    uint8_t* di = (uint8_t*)arena_alloc(ctx->io, ib);
+    if (!di) KOCR_FAIL(ctx, KOCR_ENOMEM, "kocr_recognize_boxes: arena exhausted");
+    KOCR_HIP(ctx, hipMemcpyAsync(di, img_rgb, ib, hipMemcpyHostToDevice, ctx->stream));
+    d_img = di;
+  }
+  KOCR_HIP(ctx, hipMemcpyAsync(d_prm, prm.data(), pb, hipMemcpyHostToDevice, ctx->stream));
+  KOCR_TRY(launch_warp(ctx, d_img, H, W, d_prm, (int)M, 31, 200, d_crops));
+  const int cmb = (int)std::min<long>(M, 1024);
+  KOCR_TRY(ctx->ws_reserve(crnn_workspace_bytes(cmb, C)));
+  for (long s = 0; s < M; s += cmb) {
+    const int nb = (int)std::min<long>(cmb, M - s);
+    ctx->ws_reset();
+    KOCR_TRY(crnn_forward(ctx, d_crops + (size_t)s * 31 * 200, nb, d_lab + (size_t)s * 48, nullptr));
+  }
+  KOCR_HIP(ctx, hipMemcpyAsync(labels, d_lab, lab_b, hipMemcpyDeviceToHost, ctx->stream));
+  KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KOCR_OK;
+}
+
 extern "C" int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, const int32_t* hs, const int32_t* ws,
                              const int32_t* dhs, const int32_t* dws, int Hmax, int Wmax, float detection_threshold,
                              float text_threshold, float link_threshold, int size_threshold, int micro_batch,

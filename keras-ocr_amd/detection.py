@@ -88,6 +88,6 @@ class Detector:
             batch = batch.astype("float32")
             batch -= mean * 255
             batch /= variance * 255
-        heat = self._ctx.craft_forward(batch, micro_batch=kwargs.get("batch_size", 0) or 0)
-        return self._ctx.get_boxes(heat, detection_threshold=detection_threshold, text_threshold=text_threshold,
-                                   link_threshold=link_threshold, size_threshold=size_threshold)
+        return self._ctx.detect(batch, detection_threshold=detection_threshold, text_threshold=text_threshold,
+                                link_threshold=link_threshold, size_threshold=size_threshold,
+                                micro_batch=kwargs.get("batch_size", 0) or 0)

@@ -122,12 +122,16 @@ class Recognizer:
         if not sum(len(b) for b in box_groups):
             return [[]] * len(images)
         start_end: typing.List[typing.Tuple[int, int]] = []
-        crops = []
-        # images may differ in size here (the reference loops per image): warp per size group
-        for image, boxes in zip(images, box_groups):
-            if len(boxes):
-                crops.append(self._ctx.warp_crops(np.asarray(image)[np.newaxis], [boxes], 31, 200))
+        for boxes in box_groups:
             start = 0 if not start_end else start_end[-1][1]
             start_end.append((start, start + len(boxes)))
-        predictions = self._decode(self._ctx.crnn_forward(np.concatenate(crops)))
+        images = [np.asarray(image) for image in images]
+        if len({im.shape for im in images}) == 1:
+            # one size (what Pipeline / Detector hand over): crops never leave HBM
+            labels = self._ctx.recognize_boxes(np.stack(images), box_groups)
+        else:
+            # the reference loops per image, so sizes may differ: one call per image
+            labels = np.concatenate([self._ctx.recognize_boxes(image[np.newaxis], [boxes])
+                                     for image, boxes in zip(images, box_groups) if len(boxes)])
+        predictions = self._decode(labels)
         return [predictions[start:end] for start, end in start_end]

@@ -77,3 +77,32 @@ def test_full_size_properties(ctx):
     x, yy = bx[..., 0], bx[..., 1]
     area2 = (x * np.roll(yy, -1, 1) - np.roll(x, -1, 1) * yy).sum(1)
     assert (area2 > 0).all()
+
+
+def test_large_noisy_field_vs_oracle(ctx):
+    """400x400 blob soup with thousands of sub-threshold specks: stresses the union-find across
+    many workgroups / XCDs, the ordered compaction and the canvas packing."""
+    from scipy import ndimage
+    from oracle import postproc
+
+    rng = np.random.default_rng(123)
+    f = ndimage.gaussian_filter(rng.standard_normal((2, 400, 400)), (0, 4.0, 4.0))
+    f = f / np.abs(f).max() * 1.5 + rng.normal(0, 0.08, f.shape)
+    y = np.moveaxis(f, 0, -1)[None].astype(np.float32)
+    want = postproc.get_boxes(y)
+    got = ctx.get_boxes(y)
+    assert len(want[0]) > 20
+    _check(got, want)
+
+
+def test_detect_entry_point_equals_two_step(ctx, craft_weights):
+    """kocr_detect (heat-maps stay in HBM) == kocr_craft_forward + kocr_get_boxes."""
+    ctx.load_craft(craft_weights)
+    img = synth.text_page(96, 128, 6, seed=8)[None]
+    heat = ctx.craft_forward(img)
+    # thresholds chosen inside the random-init head's output range so that boxes exist
+    t = float(np.quantile(heat[..., 0], 0.9))
+    kw = dict(detection_threshold=t, text_threshold=t * 0.9, link_threshold=1e9, size_threshold=4)
+    a = ctx.get_boxes(heat, **kw)
+    b = ctx.detect(img, **kw)
+    assert len(a[0]) > 0 and len(a[0]) == len(b[0]) and np.array_equal(a[0], b[0])

@@ -147,3 +147,37 @@ def test_non_integer_scale_and_mixed_sizes(pipe, calibrated, crnn_weights):
                 n_match += 1
                 assert text == w_[int(np.argmin(d))][0]
     assert n_total == 0 or n_match >= 0.8 * n_total
+
+
+def test_mixed_empty_and_nonempty_images_and_file_paths(pipe, tmp_path):
+    """An all-white page (no boxes) next to a text page; inputs given as file paths
+    (tools.read, tools.py:19-38) must equal the same images given as arrays."""
+    from PIL import Image
+
+    white = np.full((96, 128, 3), 255, np.uint8)
+    page = synth.text_page(96, 128, 5, seed=21)
+    out = pipe.recognize([white, page])
+    assert len(out) == 2 and isinstance(out[0], list) and len(out[1]) > 0
+    paths = []
+    for i, im in enumerate((white, page)):
+        pth = str(tmp_path / f"im{i}.png")
+        Image.fromarray(im).save(pth)
+        paths.append(pth)
+    out2 = pipe.recognize(paths)
+    assert [[t for t, _ in g] for g in out2] == [[t for t, _ in g] for g in out]
+    assert pipe.recognize([]) == []
+
+
+def test_recognize_from_boxes_contract(pipe):
+    """AssertionError on mismatched groups (recognition.py:501-503); [[]]*N without boxes (:522-523);
+    images of different sizes are allowed (the reference loops per image)."""
+    a = synth.text_page(60, 100, 3, seed=1)
+    b = synth.text_page(80, 90, 3, seed=2)
+    with pytest.raises(AssertionError):
+        pipe.recognizer.recognize_from_boxes([a, b], [np.array([])])
+    assert pipe.recognizer.recognize_from_boxes([a, b], [np.array([]), np.array([])]) == [[], []]
+    box = np.array([[[5, 5], [60, 5], [60, 25], [5, 25]]], np.float32)
+    res = pipe.recognizer.recognize_from_boxes([a, b], [box, box])
+    assert len(res) == 2 and len(res[0]) == 1 and len(res[1]) == 1
+    same = pipe.recognizer.recognize_from_boxes([a], [box])
+    assert same[0] == res[0]

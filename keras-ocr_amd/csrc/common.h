@@ -67,6 +67,8 @@ struct ConvLayer {
   float* d_w_rgb4 = nullptr;  // first layer on raw uint8: [9 taps][R,G,B,0][Cout_pad] (48 rows)
   float* d_wino = nullptr;    // Winograd F(2,3) weights U[Cin/16][3][4][16][wino_cout_pad] (3x3, dil 1, Cin%16==0)
   int wino_cout_pad = 0;
+  unsigned short* d_ws = nullptr;  // Winograd F(2,3) weights, 3-way bf16 split, conv_wsplit.hip order (Cout > 32)
+  int ws_cout_pad = 0;
   bool tap_inner = false;  // K order [16-channel group][tap][16] (Cin % 16 == 0) instead of [tap][Cin]
   bool ready() const { return d_w != nullptr; }
 };
@@ -162,6 +164,11 @@ int prepare_wino(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
 bool wino_applicable(const ConvLayer& L, const Tensor& in);
 int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
                      bool need_full);
+// conv_wsplit.hip
+int prepare_wsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
+bool wsplit_applicable(const ConvLayer& L, const Tensor& in);
+int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
+                       bool need_full);
 // elementwise.hip
 // row_off: input row that starts output row 0 (0 = keras 'valid' pooling; 1 = the same pooling seen
 // through a vertical flip of an odd-height tensor, as in the CRNN's natural-orientation conv stack)

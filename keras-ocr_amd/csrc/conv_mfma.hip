@@ -449,6 +449,7 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
         }
   KOCR_TRY(ctx->upload(&L.d_w, wp));
   KOCR_TRY(prepare_wino(ctx, L, w, w_is_oihw));
+  KOCR_TRY(prepare_wsplit(ctx, L, w, w_is_oihw));
   if (Cin == 3 && KH == 3 && KW == 3 && dil == 1) {  // uint8 first layer: K order [tap][R,G,B,0], 48 rows
     std::vector<float> w4((size_t)48 * L.Cout_pad, 0.f);
     for (int tap = 0; tap < 9; ++tap)
@@ -587,6 +588,9 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
   const bool fuse_pool = pool && mode == 0 && variant == 0 && L.BN >= 64 && (in.H % 2 == 0) && (in.W % 64 == 0) &&
                          conv_variant() != 10;
   if (!out.p) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": no output buffer");
+  // bf16x3-split Winograd on the bf16 matrix cores (fp32-class accuracy, see conv_wsplit.hip)
+  if (!in_u8 && variant == 0 && conv_variant() == 0 && wsplit_applicable(L, in))
+    return launch_conv_wsplit(ctx, L, in, out, pool, need_full);
   const bool wino = !in_u8 && variant == 0 && conv_variant() == 0 && wino_applicable(L, in);
   if (wino) {  // 1-D Winograd F(2,3): 2/3 of the MFMA work; pooling (if any) as a separate pass
     return launch_conv_wino(ctx, L, in, out, pool, need_full);

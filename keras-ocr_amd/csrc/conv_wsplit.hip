@@ -1,0 +1,415 @@
+// conv_wsplit.hip — 3x3 / stride 1 / dilation 1 convolution, 1-D Winograd F(2,3) along image rows,
+// with the fp32 products carried out on the gfx950 BF16 matrix cores by a 3-way operand split.
+//
+// Why: on CDNA4 the fp32 MFMA runs at the vector rate (157 TF), the bf16 MFMA 16x faster.  Every
+// fp32 value v is cut EXACTLY into three bf16 pieces v = h + m + l (8 significand bits each, by
+// truncation: h = top 8 bits of v, m = top 8 bits of v-h, l = v-h-m), and
+//     a*b = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh)  [+ am*bl + al*bm + al*bl <= 2^-23 |ab|]
+// is evaluated with SIX v_mfma_f32_32x32x16_bf16 (products exact, fp32 accumulation inside the
+// matrix core) instead of eight fp32 MFMAs of the same shape-equivalent: 6 x 32 cycles against
+// 16 x 32 for a 32x32x16 block.  The dropped terms are below one fp32 ulp of the product; measured
+// on hardware (scripts/probes/probe_bf16x3.hip, K = 4608 dot products of post-ReLU-like data):
+// max error 1.56e-7 / rms 3.4e-8 of sum|ab| against 1.76e-7 / 2.9e-8 for the fp32 MFMA (== fmaf
+// chain) — the same accuracy class, which tests/test_conv_gpu.py asserts against an fp64 oracle.
+//
+// Same operator and Winograd algebra as conv_wino.hip (keras Conv2D 3x3 'same' + folded BN + ReLU,
+// detection.py:87-103): for the output pair (x0, x0+1) of a row and every (ky, c)
+//     d_i = in[y+ky-1][x0-1+i][c],   V = (d0-d2, d1+d2, d2-d1, d1-d3),   U = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)
+//     M_xi[pair][o] = sum_{ky,c} V_xi U_xi,   out[x0] = M0+M1+M2,   out[x0+1] = M1-M2-M3.
+//
+// Block = WN waves; tile = 64 pairs (128 pixels) x 32*WN output channels; K-step = one (16-channel
+// group, ky).  The block transforms its input piece ONCE: thread (pair, channel quad) loads the four
+// raw pixels, forms V (fp32, as conv_wino.hip does), splits and writes bf16 operands to LDS in MFMA
+// A-operand order As[buf][xi][piece][pair][16 ch] (32-B rows: a 32x32x16 A fetch is one contiguous
+// 1-KB ds_read_b128).  Every wave owns 32 output channels for ALL pairs and all four points, so the
+// inverse transform is register-only.  U is pre-transformed and pre-split on the host and packed in
+// B-operand order [16-ch group][ky][32-cout tile][xi][piece][lane][8], fetched straight into
+// registers with a rolling per-point prefetch; weights never touch LDS.
+// Requires W even.  POOL variant: tile = 2 image rows x 64 columns with the 2x2 max taken in-lane.
+#include "common.h"
+
+typedef short bf8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+
+struct WsParams {
+  const float* in;
+  const unsigned short* wgt;  // [Cin/16][3][Cout_pad/32][4 xi][3 pieces][64 lanes][8] bf16
+  float* out;
+  const float* pre_a;
+  const float* pre_b;
+  const float* post_a;
+  const float* post_b;
+  int H, W, Cin, in_cs, in_co;
+  int Cout, Cout_pad, out_cs, out_co;
+  int relu;
+  int nsteps;  // 3 * Cin / 16
+  int Mtotal;
+  float* pool_out;
+  int pool_cs, pool_co, write_full, tiles_per_row;
+};
+
+__device__ __forceinline__ int ws_xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// exact 3-way truncation split of four fp32 values, packed as 4 bf16 (8 bytes) per piece
+__device__ __forceinline__ void ws_split4(const v4f v, u2v& h, u2v& m, u2v& l) {
+  unsigned uh[4], um[4], ul[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    uh[c] = __float_as_uint(v[c]) & 0xFFFF0000u;
+    const float r = v[c] - __uint_as_float(uh[c]);
+    um[c] = __float_as_uint(r) & 0xFFFF0000u;
+    ul[c] = __float_as_uint(r - __uint_as_float(um[c]));
+  }
+  // perm(a, b, 0x07060302) = (a & 0xFFFF0000) | (b >> 16)
+  h = u2v{__builtin_amdgcn_perm(uh[1], uh[0], 0x07060302u), __builtin_amdgcn_perm(uh[3], uh[2], 0x07060302u)};
+  m = u2v{__builtin_amdgcn_perm(um[1], um[0], 0x07060302u), __builtin_amdgcn_perm(um[3], um[2], 0x07060302u)};
+  l = u2v{__builtin_amdgcn_perm(ul[1], ul[0], 0x07060302u), __builtin_amdgcn_perm(ul[3], ul[2], 0x07060302u)};
+}
+
+template <int POOL, int WN>
+__global__ __launch_bounds__(64 * WN, 2) void conv_ws_kernel(WsParams p) {
+  constexpr int NT = 64 * WN;
+  constexpr int IPT = 256 / NT;  // gather items (pair, channel quad) per thread
+  // As[buf][xi][piece][pair row 0..63][16 ch] bf16 = 2 x 24 KB
+  __shared__ __attribute__((aligned(16))) unsigned short As[2][4][3][64][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, l5 = lane >> 5;
+
+  const int nblk_n = p.Cout_pad / (32 * WN);
+  const int tile = ws_xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = tile / nblk_n, nt = tile - mt * nblk_n;
+  const int n0 = nt * 32 * WN + wave * 32;
+
+  // ---- tile geometry ---------------------------------------------------------------------------
+  // LDS row idx (0..63) -> pair.  POOL == 0: idx = pair number in the flattened (n, y, x) order.
+  // POOL == 1: M-tile = idx >> 5 covers columns [32*Mt, 32*Mt+32) of BOTH rows: i = idx & 31,
+  // image row = y0t + (i >> 4), pair in row = 16*Mt + (i & 15): registers r and r+8 of the 32x32 C/D
+  // map then hold the two rows of one column pair in the same lane.
+  long pm0;
+  int y0t = 0, x0t = 0;
+  if constexpr (POOL) {
+    const int rp_lin = mt / p.tiles_per_row, cb = mt - rp_lin * p.tiles_per_row;
+    const int hh = p.H >> 1;
+    const int nimg = rp_lin / hh, rp = rp_lin - nimg * hh;
+    y0t = 2 * rp;
+    x0t = cb * 64;
+    pm0 = ((long)nimg * p.H + y0t) * p.W + x0t;
+  } else {
+    pm0 = (long)mt * 128;
+  }
+  const float* blk_in = p.in + (pm0 * p.in_cs + p.in_co);
+
+  // gather items of this thread
+  int goff[IPT][4], gy[IPT], lrow[IPT];
+  bool gok[IPT], glz[IPT], grz[IPT];
+  const int quad = tid & 3;
+#pragma unroll
+  for (int it = 0; it < IPT; ++it) {
+    const int idx = (tid >> 2) + it * (NT / 4);
+    lrow[it] = idx;
+    int rel;  // pixel offset of the pair's first pixel from pm0
+    int x0;
+    if constexpr (POOL) {
+      const int i = idx & 31, row = i >> 4, pr = (idx >> 5) * 16 + (i & 15);
+      rel = row * p.W + 2 * pr;
+      x0 = x0t + 2 * pr;
+      gy[it] = y0t + row;
+      gok[it] = true;
+    } else {
+      rel = 2 * idx;
+      const long g = pm0 + rel;
+      gok[it] = g < p.Mtotal;
+      x0 = (int)(g % p.W);
+      gy[it] = gok[it] ? (int)((g / p.W) % p.H) : 0;
+    }
+    glz[it] = x0 == 0;          // d0 is left zero padding
+    grz[it] = x0 + 2 >= p.W;    // d3 is right zero padding
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int px = rel - 1 + i;
+      if (i == 0 && glz[it]) px = rel;       // never dereference a pixel that is masked anyway
+      if (i == 3 && grz[it]) px = rel + 1;
+      goff[it][i] = px * p.in_cs + quad * 4;
+    }
+  }
+
+  // weights: [step][ntile32][xi][piece][lane][8 bf16]; 16 B per lane and (xi, piece)
+  const int ntiles32 = p.Cout_pad >> 5;
+  const unsigned short* w_ptr = p.wgt + ((size_t)(nt * WN + wave) * 12 * 64 + lane) * 8;
+  const size_t w_step = (size_t)ntiles32 * 12 * 64 * 8;  // ushorts per K-step
+
+  v4f raw[IPT][4];
+  bf8 bw[4][3];
+  const unsigned short* wp_next = nullptr;
+  int st_ky = 0, st_cg = 0;
+  auto load_step = [&]() __attribute__((always_inline)) {
+    const int dy = st_ky - 1;
+    const int soff = dy * p.W * p.in_cs + st_cg * 16;
+#pragma unroll
+    for (int it = 0; it < IPT; ++it) {
+      const bool ok = gok[it] && (unsigned)(gy[it] + dy) < (unsigned)p.H;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const v4f v = *reinterpret_cast<const v4f*>(blk_in + (ok ? goff[it][i] + soff : 0));
+        raw[it][i] = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    wp_next = w_ptr + (size_t)(st_cg * 3 + st_ky) * w_step;
+    if (++st_ky == 3) {
+      st_ky = 0;
+      ++st_cg;
+    }
+  };
+  auto store_step = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < IPT; ++it) {
+      const v4f z = v4f{0.f, 0.f, 0.f, 0.f};
+      const v4f d0 = glz[it] ? z : raw[it][0], d1 = raw[it][1], d2 = raw[it][2], d3 = grz[it] ? z : raw[it][3];
+      const v4f V[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        u2v h, m, l;
+        ws_split4(V[xi], h, m, l);
+        *reinterpret_cast<u2v*>(&As[buf][xi][0][lrow[it]][quad * 4]) = h;
+        *reinterpret_cast<u2v*>(&As[buf][xi][1][lrow[it]][quad * 4]) = m;
+        *reinterpret_cast<u2v*>(&As[buf][xi][2][lrow[it]][quad * 4]) = l;
+      }
+    }
+  };
+
+  f16v acc[4][2];  // [xi][M-tile]
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][m][r] = 0.f;
+
+  auto compute_step = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      const bf8 b0 = bw[xi][0], b1 = bw[xi][1], b2 = bw[xi][2];
+      bf8 a[2][3];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a[m][s] = *reinterpret_cast<const bf8*>(&As[buf][xi][s][m * 32 + l31][l5 * 8]);
+      // smallest terms first; the two M-tiles alternate so consecutive MFMAs are independent
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b0, acc[xi][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b2, acc[xi][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b1, acc[xi][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b0, acc[xi][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b1, acc[xi][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b0, acc[xi][m], 0, 0, 0);
+      // this point's operands are consumed: fetch the same point of the next K-step into them
+#pragma unroll
+      for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(wp_next + (size_t)(xi * 3 + s) * 64 * 8);
+    }
+  };
+
+  load_step();
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(wp_next + (size_t)(xi * 3 + s) * 64 * 8);
+  store_step(0);
+  __syncthreads();
+  const int ns = p.nsteps;
+  for (int s = 0; s + 1 < ns; ++s) {
+    load_step();  // also points wp_next at K-step s+1
+    __builtin_amdgcn_sched_barrier(0);
+    compute_step(s & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_step((s + 1) & 1);
+    __syncthreads();
+  }
+  // last step: the rolling prefetch re-reads the last step's weights (in bounds, unused)
+  compute_step((ns - 1) & 1);
+
+  // ---- epilogue: 32x32 C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ---------------
+  const int n = n0 + l31;
+  if (n < p.Cout) {
+    const float pa = p.pre_a[n], pb = p.pre_b[n];
+    const bool has_post = p.post_a != nullptr;
+    const float qa = has_post ? p.post_a[n] : 1.f, qb = has_post ? p.post_b[n] : 0.f;
+    auto finish = [&](float m0, float m1, float m2, float m3, float& o0, float& o1) {
+      o0 = (m0 + m1) + m2;
+      o1 = (m1 - m2) - m3;
+      o0 = o0 * pa + pb;
+      o1 = o1 * pa + pb;
+      if (p.relu) {
+        o0 = fmaxf(o0, 0.f);
+        o1 = fmaxf(o1, 0.f);
+      }
+      if (has_post) {
+        o0 = o0 * qa + qb;
+        o1 = o1 * qa + qb;
+      }
+    };
+    if constexpr (POOL) {
+      const long nimg = pm0 / ((long)p.H * p.W);
+      const long pp0 = (nimg * (p.H >> 1) + (y0t >> 1)) * (p.W >> 1) + (x0t >> 1);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * l5;  // 0..15: pair inside the M-tile
+          const int pp = m * 16 + i;                      // pair inside the row == pooled column
+          float a0, a1, b0, b1;
+          finish(acc[0][m][r], acc[1][m][r], acc[2][m][r], acc[3][m][r], a0, a1);                  // row y
+          finish(acc[0][m][r + 8], acc[1][m][r + 8], acc[2][m][r + 8], acc[3][m][r + 8], b0, b1);  // row y+1
+          if (p.write_full) {
+            float* o = p.out + ((pm0 + 2 * pp) * p.out_cs + p.out_co + n);
+            o[0] = a0;
+            o[p.out_cs] = a1;
+            o[(long)p.W * p.out_cs] = b0;
+            o[(long)p.W * p.out_cs + p.out_cs] = b1;
+          }
+          p.pool_out[(pp0 + pp) * p.pool_cs + p.pool_co + n] = fmaxf(fmaxf(a0, a1), fmaxf(b0, b1));
+        }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int pair = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * l5;
+          float o0, o1;
+          finish(acc[0][m][r], acc[1][m][r], acc[2][m][r], acc[3][m][r], o0, o1);
+          if (pm0 + 2 * pair < p.Mtotal) {  // W even -> Mtotal even -> both pixels of the pair exist
+            float* o = p.out + ((pm0 + 2 * pair) * p.out_cs + p.out_co + n);
+            o[0] = o0;
+            o[p.out_cs] = o1;
+          }
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+static inline void split3_host(float v, unsigned short out[3]) {
+  float r = v;
+  for (int s = 0; s < 3; ++s) {
+    uint32_t u;
+    memcpy(&u, &r, 4);
+    u &= 0xFFFF0000u;
+    float h;
+    memcpy(&h, &u, 4);
+    out[s] = (unsigned short)(u >> 16);
+    r = r - h;
+  }
+}
+
+int prepare_wsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
+  if (L.KH != 3 || L.KW != 3 || L.dil != 1 || L.Cin % 16 != 0 || L.Cout <= 32) return KOCR_OK;
+  const int Cin = L.Cin, Cout = L.Cout;
+  const int wcls = Cout > 64 ? 128 : 64;  // couts per block: 4 waves / 2 waves
+  const int cp = (Cout + wcls - 1) / wcls * wcls;
+  const int nt32 = cp / 32;
+  std::vector<unsigned short> u((size_t)(Cin / 16) * 3 * nt32 * 12 * 64 * 8, 0);
+  for (int c = 0; c < Cin; ++c)
+    for (int ky = 0; ky < 3; ++ky)
+      for (int o = 0; o < Cout; ++o) {
+        float g[3];
+        for (int kx = 0; kx < 3; ++kx)
+          g[kx] = w_is_oihw ? w[(((size_t)o * Cin + c) * 3 + ky) * 3 + kx] : w[(((size_t)ky * 3 + kx) * Cin + c) * Cout + o];
+        const float U[4] = {g[0], 0.5f * ((g[0] + g[1]) + g[2]), 0.5f * ((g[0] - g[1]) + g[2]), g[2]};
+        // MFMA 32x32x16 B operand: lane = (k >> 3) * 32 + (o & 31) holds k = 8*(lane>>5) + j, j = 0..7
+        const int k = c % 16, lane = (k >> 3) * 32 + (o & 31), j = k & 7;
+        const size_t step = (size_t)(c / 16) * 3 + ky;
+        for (int xi = 0; xi < 4; ++xi) {
+          unsigned short pc[3];
+          split3_host(U[xi], pc);
+          for (int s = 0; s < 3; ++s)
+            u[((((step * nt32 + o / 32) * 4 + xi) * 3 + s) * 64 + lane) * 8 + j] = pc[s];
+        }
+      }
+  L.ws_cout_pad = cp;
+  void* d = nullptr;
+  KOCR_TRY(ctx->dev_alloc(&d, u.size() * sizeof(unsigned short)));
+  KOCR_HIP(ctx, hipMemcpy(d, u.data(), u.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  L.d_ws = (unsigned short*)d;
+  return KOCR_OK;
+}
+
+bool wsplit_applicable(const ConvLayer& L, const Tensor& in) {
+  static const bool off = getenv("KOCR_WSPLIT") && atoi(getenv("KOCR_WSPLIT")) == 0;
+  return !off && L.d_ws && in.W % 2 == 0 && in.cs % 4 == 0 && in.co % 4 == 0 && ((uintptr_t)in.p & 15) == 0 &&
+         L.Cin % 16 == 0;
+}
+
+int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
+                       bool need_full) {
+  const bool fuse = pool && in.H % 2 == 0 && in.W % 64 == 0;
+  const size_t M = in.pixels();
+  WsParams p;
+  p.in = in.p;
+  p.wgt = L.d_ws;
+  p.out = out.p;
+  p.pre_a = L.d_pre_a;
+  p.pre_b = L.d_pre_b;
+  p.post_a = L.d_post_a;
+  p.post_b = L.d_post_b;
+  p.H = in.H;
+  p.W = in.W;
+  p.Cin = L.Cin;
+  p.in_cs = in.cs;
+  p.in_co = in.co;
+  p.Cout = L.Cout;
+  p.Cout_pad = L.ws_cout_pad;
+  p.out_cs = out.cs;
+  p.out_co = out.co;
+  p.relu = L.relu;
+  p.nsteps = 3 * (L.Cin / 16);
+  p.Mtotal = (int)M;
+  p.pool_out = nullptr;
+  p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
+  if (fuse) {
+    p.pool_out = pool->p;
+    p.pool_cs = pool->cs;
+    p.pool_co = pool->co;
+    p.write_full = need_full ? 1 : 0;
+    p.tiles_per_row = in.W / 64;
+  }
+  const int wcls = L.Cout > 64 ? 128 : 64;
+  static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
+  char nm[64];
+  if (per_layer)
+    snprintf(nm, sizeof nm, "conv_ws_128x%d%s:%s", wcls, fuse ? "p" : "", L.name.c_str());
+  else
+    snprintf(nm, sizeof nm, "conv_ws_128x%d%s", wcls, fuse ? "_pool" : "");
+  const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
+  const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
+  {
+    ProfScope ps(ctx, nm, flops, bytes);
+    const size_t mtiles = (M + 127) / 128;
+    dim3 grid((unsigned)(mtiles * (p.Cout_pad / wcls)));
+    if (wcls == 128) {
+      if (fuse)
+        hipLaunchKernelGGL((conv_ws_kernel<1, 4>), grid, dim3(256), 0, ctx->stream, p);
+      else
+        hipLaunchKernelGGL((conv_ws_kernel<0, 4>), grid, dim3(256), 0, ctx->stream, p);
+    } else {
+      if (fuse)
+        hipLaunchKernelGGL((conv_ws_kernel<1, 2>), grid, dim3(128), 0, ctx->stream, p);
+      else
+        hipLaunchKernelGGL((conv_ws_kernel<0, 2>), grid, dim3(128), 0, ctx->stream, p);
+    }
+    KOCR_HIP(ctx, hipGetLastError());
+  }
+  if (pool && !fuse) return launch_maxpool2x2(ctx, out, *pool);
+  return KOCR_OK;
+}

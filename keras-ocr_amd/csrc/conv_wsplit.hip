@@ -20,8 +20,8 @@
 // Block = WN waves; tile = 64 pairs (128 pixels) x 32*WN output channels; K-step = one (16-channel
 // group, ky).  The block transforms its input piece ONCE: thread (pair, channel quad) loads the four
 // raw pixels, forms V (fp32, as conv_wino.hip does), splits and writes bf16 operands to LDS in MFMA
-// A-operand order As[buf][xi][piece][pair][16 ch] (32-B rows: a 32x32x16 A fetch is one contiguous
-// 1-KB ds_read_b128).  Every wave owns 32 output channels for ALL pairs and all four points, so the
+// A-operand order As[buf][xi][piece][M-tile][k half][32 pairs][8 ch] (a 32x32x16 A fetch is two
+// contiguous 512-B runs, bank-conflict free).  Every wave owns 32 output channels for ALL pairs and all four points, so the
 // inverse transform is register-only.  U is pre-transformed and pre-split on the host and packed in
 // B-operand order [16-ch group][ky][32-cout tile][xi][piece][lane][8], fetched straight into
 // registers with a rolling per-point prefetch; weights never touch LDS.
@@ -48,6 +48,7 @@ struct WsParams {
   int Mtotal;
   float* pool_out;
   int pool_cs, pool_co, write_full, tiles_per_row;
+  int dbg;  // developer timing experiments (wrong results): 1 = weights of one K-step only, 2 = one input row only
 };
 
 __device__ __forceinline__ int ws_xcd_remap(int bid, int nwg) {
@@ -73,18 +74,20 @@ __device__ __forceinline__ void ws_split4(const v4f v, u2v& h, u2v& m, u2v& l) {
 }
 
 template <int POOL, int WN>
-__global__ __launch_bounds__(64 * WN, 2) void conv_ws_kernel(WsParams p) {
-  constexpr int NT = 64 * WN;
-  constexpr int IPT = 256 / NT;  // gather items (pair, channel quad) per thread
-  // As[buf][xi][piece][pair row 0..63][16 ch] bf16 = 2 x 24 KB
-  __shared__ __attribute__((aligned(16))) unsigned short As[2][4][3][64][16];
+__global__ __launch_bounds__(128 * WN) void conv_ws_kernel(WsParams p) {
+  constexpr int NPT = 64 * WN;    // producer threads
+  constexpr int IPT = 256 / NPT;  // gather items (pair, channel quad) per producer thread
+  // As[buf][xi][piece][M-tile][k half][32 rows x 8 ch bf16 = 512 B]: a 32x32x16 A fetch reads 2 x 512
+  // contiguous bytes (16 B per lane, conflict-free); the rows of k half 1 are XOR-ed with 64 B so the two
+  // k halves a 16-lane ds_write_b64 group touches fall into different halves of the 32 store banks.
+  constexpr int KH_STRIDE = 256;  // ushorts
+  __shared__ __attribute__((aligned(16))) unsigned short As[2][4][3][2][2][KH_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, l5 = lane >> 5;
 
   const int nblk_n = p.Cout_pad / (32 * WN);
   const int tile = ws_xcd_remap(blockIdx.x, gridDim.x);
   const int mt = tile / nblk_n, nt = tile - mt * nblk_n;
-  const int n0 = nt * 32 * WN + wave * 32;
 
   // ---- tile geometry ---------------------------------------------------------------------------
   // LDS row idx (0..63) -> pair.  POOL == 0: idx = pair number in the flattened (n, y, x) order.
@@ -103,85 +106,119 @@ __global__ __launch_bounds__(64 * WN, 2) void conv_ws_kernel(WsParams p) {
   } else {
     pm0 = (long)mt * 128;
   }
-  const float* blk_in = p.in + (pm0 * p.in_cs + p.in_co);
+  const int ns = p.nsteps;
 
-  // gather items of this thread
-  int goff[IPT][4], gy[IPT], lrow[IPT];
-  bool gok[IPT], glz[IPT], grz[IPT];
-  const int quad = tid & 3;
+  // ==================================================================================================
+  // producer waves [WN, 2*WN): raw pixels -> Winograd input transform -> bf16x3 split -> LDS
+  // ==================================================================================================
+  if (wave >= WN) {
+    const int ptid = tid - NPT;
+    const int quad = ptid & 3;
+    // Raw buffer resource over the input, based one image row + one pixel BEFORE the tile so that every
+    // byte offset below is >= 0; an offset of 0x80000000 is out of range and the load returns 0, which is
+    // how row/column zero padding and tiles past the end are expressed (no value masking, no 64-bit
+    // address arithmetic in the loop).
+    const float* bbase_v = p.in + (pm0 * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
+    // block-uniform by construction; readfirstlane tells the compiler (no waterfall loop around the loads)
+    const unsigned long long bb = (unsigned long long)bbase_v;
+    const unsigned long long bbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((int)bb);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)bbu, 0, 0x80000000, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned goff[IPT][4];
+    int gy[IPT], ldst[IPT];
+    bool gok[IPT];
 #pragma unroll
-  for (int it = 0; it < IPT; ++it) {
-    const int idx = (tid >> 2) + it * (NT / 4);
-    lrow[it] = idx;
-    int rel;  // pixel offset of the pair's first pixel from pm0
-    int x0;
-    if constexpr (POOL) {
-      const int i = idx & 31, row = i >> 4, pr = (idx >> 5) * 16 + (i & 15);
-      rel = row * p.W + 2 * pr;
-      x0 = x0t + 2 * pr;
-      gy[it] = y0t + row;
-      gok[it] = true;
-    } else {
-      rel = 2 * idx;
-      const long g = pm0 + rel;
-      gok[it] = g < p.Mtotal;
-      x0 = (int)(g % p.W);
-      gy[it] = gok[it] ? (int)((g / p.W) % p.H) : 0;
-    }
-    glz[it] = x0 == 0;          // d0 is left zero padding
-    grz[it] = x0 + 2 >= p.W;    // d3 is right zero padding
+    for (int it = 0; it < IPT; ++it) {
+      const int idx = (ptid >> 2) + it * (NPT / 4);
+      ldst[it] = ((idx >> 5) * 2 + (quad >> 1)) * KH_STRIDE + ((((idx & 31) * 8) ^ ((quad >> 1) * 32)) + (quad & 1) * 4);
+      int rel;  // pixel offset of the pair's first pixel from pm0
+      int x0;
+      if constexpr (POOL) {
+        const int i = idx & 31, row = i >> 4, pr = (idx >> 5) * 16 + (i & 15);
+        rel = row * p.W + 2 * pr;
+        x0 = x0t + 2 * pr;
+        gy[it] = y0t + row;
+        gok[it] = true;
+      } else {
+        rel = 2 * idx;
+        const long g = pm0 + rel;
+        gok[it] = g < p.Mtotal;
+        x0 = (int)(g % p.W);
+        gy[it] = gok[it] ? (int)((g / p.W) % p.H) : 0;
+      }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int px = rel - 1 + i;
-      if (i == 0 && glz[it]) px = rel;       // never dereference a pixel that is masked anyway
-      if (i == 3 && grz[it]) px = rel + 1;
-      goff[it][i] = px * p.in_cs + quad * 4;
+      for (int i = 0; i < 4; ++i) {
+        const bool pad = (i == 0 && x0 == 0) || (i == 3 && x0 + 2 >= p.W);  // d0 / d3 is column zero padding
+        goff[it][i] = pad ? OOB : (unsigned)(((rel + i) * p.in_cs + quad * 4) * 4);
+      }
     }
+    int st_ky = 0, st_cg = 0;
+    auto load_raw = [&](v4f (&raw)[IPT][4], bool live) __attribute__((always_inline)) {
+      const int soff = (p.dbg & 2) ? 0 : (st_ky * p.W * p.in_cs + st_cg * 16) * 4;
+#pragma unroll
+      for (int it = 0; it < IPT; ++it) {
+        const bool ok = live && gok[it] && (unsigned)(gy[it] + st_ky - 1) < (unsigned)p.H;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          raw[it][i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? goff[it][i] : OOB, soff, 0));
+      }
+      if (++st_ky == 3) {
+        st_ky = 0;
+        ++st_cg;
+      }
+    };
+    auto produce = [&](const v4f (&raw)[IPT][4], int buf) __attribute__((always_inline)) {
+      unsigned short* base = &As[buf][0][0][0][0][0];
+#pragma unroll
+      for (int it = 0; it < IPT; ++it) {
+        const v4f d0 = raw[it][0], d1 = raw[it][1], d2 = raw[it][2], d3 = raw[it][3];
+        const v4f V[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+          u2v h, m, l;
+          ws_split4(V[xi], h, m, l);
+          unsigned short* dst = base + xi * 12 * KH_STRIDE + ldst[it];
+          *reinterpret_cast<u2v*>(dst) = h;
+          *reinterpret_cast<u2v*>(dst + 4 * KH_STRIDE) = m;
+          *reinterpret_cast<u2v*>(dst + 8 * KH_STRIDE) = l;
+        }
+      }
+    };
+    // branch-free pipeline (a conditional load would force s_waitcnt vmcnt(0) at the join): the loads of
+    // K-step s+1 are always issued before K-step s is transformed; past the last step they are masked
+    v4f rawA[IPT][4], rawB[IPT][4];
+    load_raw(rawA, true);
+    int s = 0;
+    for (; s + 2 <= ns; s += 2) {
+      load_raw(rawB, true);
+      if (!(p.dbg & 4)) produce(rawA, 0);
+      __syncthreads();
+      load_raw(rawA, s + 2 < ns);
+      if (!(p.dbg & 4)) produce(rawB, 1);
+      __syncthreads();
+    }
+    if (s < ns) {  // odd number of K-steps: the last one is already in rawA
+      produce(rawA, 0);
+      __syncthreads();
+    }
+    return;
   }
 
+  // ==================================================================================================
+  // consumer waves [0, WN): 32 output channels x 64 pairs x 4 points each; MFMA + weight stream only
+  // ==================================================================================================
+  const int n0 = nt * 32 * WN + wave * 32;
   // weights: [step][ntile32][xi][piece][lane][8 bf16]; 16 B per lane and (xi, piece)
   const int ntiles32 = p.Cout_pad >> 5;
   const unsigned short* w_ptr = p.wgt + ((size_t)(nt * WN + wave) * 12 * 64 + lane) * 8;
-  const size_t w_step = (size_t)ntiles32 * 12 * 64 * 8;  // ushorts per K-step
+  const size_t w_step = (p.dbg & 1) ? 0 : (size_t)ntiles32 * 12 * 64 * 8;  // ushorts per K-step
 
-  v4f raw[IPT][4];
   bf8 bw[4][3];
-  const unsigned short* wp_next = nullptr;
-  int st_ky = 0, st_cg = 0;
-  auto load_step = [&]() __attribute__((always_inline)) {
-    const int dy = st_ky - 1;
-    const int soff = dy * p.W * p.in_cs + st_cg * 16;
 #pragma unroll
-    for (int it = 0; it < IPT; ++it) {
-      const bool ok = gok[it] && (unsigned)(gy[it] + dy) < (unsigned)p.H;
+  for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const v4f v = *reinterpret_cast<const v4f*>(blk_in + (ok ? goff[it][i] + soff : 0));
-        raw[it][i] = ok ? v : v4f{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-    wp_next = w_ptr + (size_t)(st_cg * 3 + st_ky) * w_step;
-    if (++st_ky == 3) {
-      st_ky = 0;
-      ++st_cg;
-    }
-  };
-  auto store_step = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int it = 0; it < IPT; ++it) {
-      const v4f z = v4f{0.f, 0.f, 0.f, 0.f};
-      const v4f d0 = glz[it] ? z : raw[it][0], d1 = raw[it][1], d2 = raw[it][2], d3 = grz[it] ? z : raw[it][3];
-      const v4f V[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
-#pragma unroll
-      for (int xi = 0; xi < 4; ++xi) {
-        u2v h, m, l;
-        ws_split4(V[xi], h, m, l);
-        *reinterpret_cast<u2v*>(&As[buf][xi][0][lrow[it]][quad * 4]) = h;
-        *reinterpret_cast<u2v*>(&As[buf][xi][1][lrow[it]][quad * 4]) = m;
-        *reinterpret_cast<u2v*>(&As[buf][xi][2][lrow[it]][quad * 4]) = l;
-      }
-    }
-  };
+    for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w_ptr + (size_t)(xi * 3 + s) * 64 * 8);
 
   f16v acc[4][2];  // [xi][M-tile]
 #pragma unroll
@@ -191,52 +228,69 @@ __global__ __launch_bounds__(64 * WN, 2) void conv_ws_kernel(WsParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][m][r] = 0.f;
 
-  auto compute_step = [&](int buf) __attribute__((always_inline)) {
+  const int a_lane = l5 * KH_STRIDE + ((l31 * 8) ^ (l5 * 32));
+  auto load_a = [&](bf8 (&a)[2][3], int buf, int xi) __attribute__((always_inline)) {
+    const unsigned short* base = &As[buf][xi][0][0][0][0] + a_lane;
 #pragma unroll
-    for (int xi = 0; xi < 4; ++xi) {
-      const bf8 b0 = bw[xi][0], b1 = bw[xi][1], b2 = bw[xi][2];
-      bf8 a[2][3];
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int s = 0; s < 3; ++s) a[m][s] = *reinterpret_cast<const bf8*>(base + (s * 4 + m * 2) * KH_STRIDE);
+  };
+  auto mfma6 = [&](const bf8 (&a)[2][3], int xi) __attribute__((always_inline)) {
+    const bf8 b0 = bw[xi][0], b1 = bw[xi][1], b2 = bw[xi][2];
+    // smallest terms first; the two M-tiles alternate so consecutive MFMAs are independent
 #pragma unroll
-        for (int s = 0; s < 3; ++s) a[m][s] = *reinterpret_cast<const bf8*>(&As[buf][xi][s][m * 32 + l31][l5 * 8]);
-      // smallest terms first; the two M-tiles alternate so consecutive MFMAs are independent
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b0, acc[xi][m], 0, 0, 0);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b0, acc[xi][m], 0, 0, 0);
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b2, acc[xi][m], 0, 0, 0);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b2, acc[xi][m], 0, 0, 0);
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b1, acc[xi][m], 0, 0, 0);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b1, acc[xi][m], 0, 0, 0);
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b0, acc[xi][m], 0, 0, 0);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b0, acc[xi][m], 0, 0, 0);
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b1, acc[xi][m], 0, 0, 0);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b1, acc[xi][m], 0, 0, 0);
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b0, acc[xi][m], 0, 0, 0);
+  };
+  // one K-step: A operands of point xi+1 are fetched from LDS while the 12 MFMAs of point xi run;
+  // a point's weights are re-fetched (next K-step) as soon as its MFMAs are issued
+  auto compute_step = [&](int buf, const unsigned short* w_next) __attribute__((always_inline)) {
+    bf8 a0[2][3], a1[2][3];
+    auto load_b = [&](int xi) __attribute__((always_inline)) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b0, acc[xi][m], 0, 0, 0);
-      // this point's operands are consumed: fetch the same point of the next K-step into them
-#pragma unroll
-      for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(wp_next + (size_t)(xi * 3 + s) * 64 * 8);
-    }
+      for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w_next + (size_t)(xi * 3 + s) * 64 * 8);
+    };
+    // the fences pin the issue order: LDS fetch of the next point, 12 MFMAs, weight fetch
+    load_a(a0, buf, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(a1, buf, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(a0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(0);
+    load_a(a0, buf, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(a1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(1);
+    load_a(a1, buf, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(a0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(a1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(3);
   };
 
-  load_step();
-#pragma unroll
-  for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-    for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(wp_next + (size_t)(xi * 3 + s) * 64 * 8);
-  store_step(0);
-  __syncthreads();
-  const int ns = p.nsteps;
+  __syncthreads();  // K-step 0 is in LDS
   for (int s = 0; s + 1 < ns; ++s) {
-    load_step();  // also points wp_next at K-step s+1
-    __builtin_amdgcn_sched_barrier(0);
-    compute_step(s & 1);
-    __builtin_amdgcn_sched_barrier(0);
-    store_step((s + 1) & 1);
+    if (!(p.dbg & 8)) compute_step(s & 1, w_ptr + (size_t)(s + 1) * w_step);
     __syncthreads();
   }
   // last step: the rolling prefetch re-reads the last step's weights (in bounds, unused)
-  compute_step((ns - 1) & 1);
+  compute_step((ns - 1) & 1, w_ptr + (size_t)(ns - 1) * w_step);
 
   // ---- epilogue: 32x32 C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ---------------
   const int n = n0 + l31;
@@ -377,6 +431,8 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   p.Mtotal = (int)M;
   p.pool_out = nullptr;
   p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
+  static const int dbg = getenv("KOCR_WS_DBG") ? atoi(getenv("KOCR_WS_DBG")) : 0;
+  p.dbg = dbg;
   if (fuse) {
     p.pool_out = pool->p;
     p.pool_cs = pool->cs;
@@ -399,14 +455,14 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
     dim3 grid((unsigned)(mtiles * (p.Cout_pad / wcls)));
     if (wcls == 128) {
       if (fuse)
-        hipLaunchKernelGGL((conv_ws_kernel<1, 4>), grid, dim3(256), 0, ctx->stream, p);
+        hipLaunchKernelGGL((conv_ws_kernel<1, 4>), grid, dim3(512), 0, ctx->stream, p);
       else
-        hipLaunchKernelGGL((conv_ws_kernel<0, 4>), grid, dim3(256), 0, ctx->stream, p);
+        hipLaunchKernelGGL((conv_ws_kernel<0, 4>), grid, dim3(512), 0, ctx->stream, p);
     } else {
       if (fuse)
-        hipLaunchKernelGGL((conv_ws_kernel<1, 2>), grid, dim3(128), 0, ctx->stream, p);
+        hipLaunchKernelGGL((conv_ws_kernel<1, 2>), grid, dim3(256), 0, ctx->stream, p);
       else
-        hipLaunchKernelGGL((conv_ws_kernel<0, 2>), grid, dim3(128), 0, ctx->stream, p);
+        hipLaunchKernelGGL((conv_ws_kernel<0, 2>), grid, dim3(256), 0, ctx->stream, p);
     }
     KOCR_HIP(ctx, hipGetLastError());
   }

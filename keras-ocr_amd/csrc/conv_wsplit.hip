@@ -48,7 +48,7 @@ struct WsParams {
   int Mtotal;
   float* pool_out;
   int pool_cs, pool_co, write_full, tiles_per_row;
-  int dbg;  // developer timing experiments (wrong results): 1 = weights of one K-step only, 2 = one input row only
+  int total_tiles;
 };
 
 __device__ __forceinline__ int ws_xcd_remap(int bid, int nwg) {
@@ -73,103 +73,135 @@ __device__ __forceinline__ void ws_split4(const v4f v, u2v& h, u2v& m, u2v& l) {
   l = u2v{__builtin_amdgcn_perm(ul[1], ul[0], 0x07060302u), __builtin_amdgcn_perm(ul[3], ul[2], 0x07060302u)};
 }
 
-template <int POOL, int WN>
-__global__ __launch_bounds__(128 * WN) void conv_ws_kernel(WsParams p) {
-  constexpr int NPT = 64 * WN;    // producer threads
-  constexpr int IPT = 256 / NPT;  // gather items (pair, channel quad) per producer thread
-  // As[buf][xi][piece][M-tile][k half][32 rows x 8 ch bf16 = 512 B]: a 32x32x16 A fetch reads 2 x 512
-  // contiguous bytes (16 B per lane, conflict-free); the rows of k half 1 are XOR-ed with 64 B so the two
-  // k halves a 16-lane ds_write_b64 group touches fall into different halves of the 32 store banks.
-  constexpr int KH_STRIDE = 256;  // ushorts
-  __shared__ __attribute__((aligned(16))) unsigned short As[2][4][3][2][2][KH_STRIDE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, l5 = lane >> 5;
+// Tile geometry shared by both roles.  POOL == 0: 128*WM consecutive pixels of the flattened (n, y, x)
+// order.  POOL == 1: 2 image rows x 64*WM columns.
+struct WsTile {
+  long pm0;      // flattened index of the tile's first pixel
+  int y0t, x0t;  // POOL: top row / left column
+  int nt;        // output-channel tile
+};
 
-  const int nblk_n = p.Cout_pad / (32 * WN);
-  const int tile = ws_xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = tile / nblk_n, nt = tile - mt * nblk_n;
-
-  // ---- tile geometry ---------------------------------------------------------------------------
-  // LDS row idx (0..63) -> pair.  POOL == 0: idx = pair number in the flattened (n, y, x) order.
-  // POOL == 1: M-tile = idx >> 5 covers columns [32*Mt, 32*Mt+32) of BOTH rows: i = idx & 31,
-  // image row = y0t + (i >> 4), pair in row = 16*Mt + (i & 15): registers r and r+8 of the 32x32 C/D
-  // map then hold the two rows of one column pair in the same lane.
-  long pm0;
-  int y0t = 0, x0t = 0;
+template <int POOL, int WM, int WN>
+__device__ __forceinline__ WsTile ws_tile(const WsParams& p, int L, int total, int nblk_n) {
+  WsTile t;
+  const int tile = ws_xcd_remap(L, total);
+  const int mt = tile / nblk_n;
+  t.nt = tile - mt * nblk_n;
+  t.y0t = t.x0t = 0;
   if constexpr (POOL) {
     const int rp_lin = mt / p.tiles_per_row, cb = mt - rp_lin * p.tiles_per_row;
     const int hh = p.H >> 1;
     const int nimg = rp_lin / hh, rp = rp_lin - nimg * hh;
-    y0t = 2 * rp;
-    x0t = cb * 64;
-    pm0 = ((long)nimg * p.H + y0t) * p.W + x0t;
+    t.y0t = 2 * rp;
+    t.x0t = cb * 64 * WM;
+    t.pm0 = ((long)nimg * p.H + t.y0t) * p.W + t.x0t;
   } else {
-    pm0 = (long)mt * 128;
+    t.pm0 = (long)mt * (128 * WM);
   }
+  return t;
+}
+
+// Persistent, wave-specialised kernel: 512 threads = 4 consumer waves (MFMA + weight stream) and
+// 4 producer waves (input gather, Winograd input transform, bf16x3 split, LDS fill); one block per CU
+// walks over tiles L = blockIdx.x, blockIdx.x + gridDim.x, ...  The K-steps of consecutive tiles form
+// ONE pipeline (LDS double buffer indexed by the global step parity), so a tile's first operands are
+// already in LDS when the consumers finish the previous tile's epilogue.
+//   WM x WN = 4 consumer waves: wave (wm, wn) owns M-tiles {2wm, 2wm+1} (64 pairs) x 32 couts.
+//   <1,4>: tile 128 px x 128 couts      <2,2>: tile 256 px x 64 couts (weights shared by two waves)
+template <int POOL, int WM, int WN>
+__global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
+  constexpr int NMT = 2 * WM;                        // 32-pair M-tiles per block tile
+  constexpr int IPT = WM;                            // gather items (pair, channel quad) per producer thread
+  constexpr int KH_STRIDE = 256;                     // ushorts: 32 rows x 8 channels
+  constexpr int PLANE = NMT * 2 * KH_STRIDE;         // one (xi, piece) plane
+  constexpr int BUF = 12 * PLANE;                    // one K-step: 24 KB * WM
+  // As[buf][xi][piece][M-tile][k half][32 rows x 8 ch bf16 = 512 B]: a 32x32x16 A fetch reads 2 x 512
+  // contiguous bytes (16 B per lane, conflict-free); the rows of k half 1 are XOR-ed with 64 B so the two
+  // k halves a 16-lane ds_write_b64 group touches fall into different halves of the 32 store banks.
+  extern __shared__ __attribute__((aligned(16))) unsigned short As[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, l5 = lane >> 5;
+  const int nblk_n = p.Cout_pad / (32 * WN);
+  const int total = p.total_tiles;
   const int ns = p.nsteps;
+  const int G = gridDim.x;
 
   // ==================================================================================================
-  // producer waves [WN, 2*WN): raw pixels -> Winograd input transform -> bf16x3 split -> LDS
+  // producer waves 4..7: raw pixels -> Winograd input transform -> bf16x3 split -> LDS
   // ==================================================================================================
-  if (wave >= WN) {
-    const int ptid = tid - NPT;
+  if (wave >= 4) {
+    const int ptid = tid - 256;
     const int quad = ptid & 3;
-    // Raw buffer resource over the input, based one image row + one pixel BEFORE the tile so that every
-    // byte offset below is >= 0; an offset of 0x80000000 is out of range and the load returns 0, which is
-    // how row/column zero padding and tiles past the end are expressed (no value masking, no 64-bit
-    // address arithmetic in the loop).
-    const float* bbase_v = p.in + (pm0 * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
-    // block-uniform by construction; readfirstlane tells the compiler (no waterfall loop around the loads)
-    const unsigned long long bb = (unsigned long long)bbase_v;
-    const unsigned long long bbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)) << 32) |
-                                   (unsigned)__builtin_amdgcn_readfirstlane((int)bb);
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)bbu, 0, 0x80000000, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    unsigned goff[IPT][4];
-    int gy[IPT], ldst[IPT];
-    bool gok[IPT];
+    int ldst[IPT];
 #pragma unroll
     for (int it = 0; it < IPT; ++it) {
-      const int idx = (ptid >> 2) + it * (NPT / 4);
+      const int idx = (ptid >> 2) + it * 64;
       ldst[it] = ((idx >> 5) * 2 + (quad >> 1)) * KH_STRIDE + ((((idx & 31) * 8) ^ ((quad >> 1) * 32)) + (quad & 1) * 4);
-      int rel;  // pixel offset of the pair's first pixel from pm0
-      int x0;
-      if constexpr (POOL) {
-        const int i = idx & 31, row = i >> 4, pr = (idx >> 5) * 16 + (i & 15);
-        rel = row * p.W + 2 * pr;
-        x0 = x0t + 2 * pr;
-        gy[it] = y0t + row;
-        gok[it] = true;
-      } else {
-        rel = 2 * idx;
-        const long g = pm0 + rel;
-        gok[it] = g < p.Mtotal;
-        x0 = (int)(g % p.W);
-        gy[it] = gok[it] ? (int)((g / p.W) % p.H) : 0;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool pad = (i == 0 && x0 == 0) || (i == 3 && x0 + 2 >= p.W);  // d0 / d3 is column zero padding
-        goff[it][i] = pad ? OOB : (unsigned)(((rel + i) * p.in_cs + quad * 4) * 4);
-      }
     }
-    int st_ky = 0, st_cg = 0;
-    auto load_raw = [&](v4f (&raw)[IPT][4], bool live) __attribute__((always_inline)) {
-      const int soff = (p.dbg & 2) ? 0 : (st_ky * p.W * p.in_cs + st_cg * 16) * 4;
+    // position of the NEXT K-step to load: tile L_ld, step (ld_cg, ld_ky)
+    int L_ld = blockIdx.x, ld_ky = 0, ld_cg = 0;
+    unsigned goff[IPT][4];
+    int gy[IPT];
+    bool gok[IPT];
+    __amdgpu_buffer_rsrc_t rsrc;
+    // Raw buffer resource over the input, based one image row + one pixel BEFORE the tile so that every
+    // byte offset is >= 0; an offset of 0x80000000 is out of range and the load returns 0, which is how
+    // row/column zero padding and tiles past the end are expressed (no value masking, no 64-bit address
+    // arithmetic in the loop).
+    auto tile_geometry = [&]() __attribute__((always_inline)) {
+      const WsTile t = ws_tile<POOL, WM, WN>(p, L_ld < total ? L_ld : 0, total, nblk_n);
+      const float* bbase_v = p.in + (t.pm0 * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
+      // block-uniform by construction; readfirstlane tells the compiler (no waterfall loop around the loads)
+      const unsigned long long bb = (unsigned long long)bbase_v;
+      const unsigned long long bbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)bb);
+      rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)bbu, 0, 0x80000000, 0x00020000);
 #pragma unroll
       for (int it = 0; it < IPT; ++it) {
-        const bool ok = live && gok[it] && (unsigned)(gy[it] + st_ky - 1) < (unsigned)p.H;
+        const int idx = (ptid >> 2) + it * 64;
+        int rel;  // pixel offset of the pair's first pixel from pm0
+        int x0;
+        if constexpr (POOL) {
+          const int i = idx & 31, row = i >> 4, pr = (idx >> 5) * 16 + (i & 15);
+          rel = row * p.W + 2 * pr;
+          x0 = t.x0t + 2 * pr;
+          gy[it] = t.y0t + row;
+          gok[it] = L_ld < total;
+        } else {
+          rel = 2 * idx;
+          const long g = t.pm0 + rel;
+          gok[it] = g < p.Mtotal && L_ld < total;
+          x0 = (int)(g % p.W);
+          gy[it] = (int)((g / p.W) % p.H);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool pad = (i == 0 && x0 == 0) || (i == 3 && x0 + 2 >= p.W);  // d0 / d3 is column zero padding
+          goff[it][i] = pad ? OOB : (unsigned)(((rel + i) * p.in_cs + quad * 4) * 4);
+        }
+      }
+    };
+    auto load_raw = [&](v4f (&raw)[IPT][4]) __attribute__((always_inline)) {
+      const int soff = (ld_ky * p.W * p.in_cs + ld_cg * 16) * 4;
+#pragma unroll
+      for (int it = 0; it < IPT; ++it) {
+        const bool ok = gok[it] && (unsigned)(gy[it] + ld_ky - 1) < (unsigned)p.H;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           raw[it][i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? goff[it][i] : OOB, soff, 0));
       }
-      if (++st_ky == 3) {
-        st_ky = 0;
-        ++st_cg;
+      if (++ld_ky == 3) {
+        ld_ky = 0;
+        if (++ld_cg == p.Cin / 16) {  // next tile
+          ld_cg = 0;
+          L_ld += G;
+          tile_geometry();
+        }
       }
     };
     auto produce = [&](const v4f (&raw)[IPT][4], int buf) __attribute__((always_inline)) {
-      unsigned short* base = &As[buf][0][0][0][0][0];
+      unsigned short* base = As + buf * BUF;
 #pragma unroll
       for (int it = 0; it < IPT; ++it) {
         const v4f d0 = raw[it][0], d1 = raw[it][1], d2 = raw[it][2], d3 = raw[it][3];
@@ -178,63 +210,56 @@ __global__ __launch_bounds__(128 * WN) void conv_ws_kernel(WsParams p) {
         for (int xi = 0; xi < 4; ++xi) {
           u2v h, m, l;
           ws_split4(V[xi], h, m, l);
-          unsigned short* dst = base + xi * 12 * KH_STRIDE + ldst[it];
+          unsigned short* dst = base + xi * 3 * PLANE + ldst[it];
           *reinterpret_cast<u2v*>(dst) = h;
-          *reinterpret_cast<u2v*>(dst + 4 * KH_STRIDE) = m;
-          *reinterpret_cast<u2v*>(dst + 8 * KH_STRIDE) = l;
+          *reinterpret_cast<u2v*>(dst + PLANE) = m;
+          *reinterpret_cast<u2v*>(dst + 2 * PLANE) = l;
         }
       }
     };
-    // branch-free pipeline (a conditional load would force s_waitcnt vmcnt(0) at the join): the loads of
-    // K-step s+1 are always issued before K-step s is transformed; past the last step they are masked
+    // K-steps this block will run in total
+    const int my_tiles = (total - (int)blockIdx.x + G - 1) / G;
+    const int T = my_tiles * ns;
+    tile_geometry();
+    // branch-free two-step pipeline (a conditional load would force s_waitcnt vmcnt(0) at the join): the
+    // loads of global step k+1 are always in flight while step k is transformed; past the end they are masked
     v4f rawA[IPT][4], rawB[IPT][4];
-    load_raw(rawA, true);
-    int s = 0;
-    for (; s + 2 <= ns; s += 2) {
-      load_raw(rawB, true);
-      if (!(p.dbg & 4)) produce(rawA, 0);
+    load_raw(rawA);
+    int k = 0;
+    for (; k + 2 <= T; k += 2) {
+      load_raw(rawB);
+      produce(rawA, 0);
       __syncthreads();
-      load_raw(rawA, s + 2 < ns);
-      if (!(p.dbg & 4)) produce(rawB, 1);
+      load_raw(rawA);
+      produce(rawB, 1);
       __syncthreads();
     }
-    if (s < ns) {  // odd number of K-steps: the last one is already in rawA
+    if (k < T) {  // odd total: the last step is already in rawA
       produce(rawA, 0);
       __syncthreads();
     }
+    __syncthreads();  // pairs with the consumers' barrier inside the last K-step
     return;
   }
 
   // ==================================================================================================
-  // consumer waves [0, WN): 32 output channels x 64 pairs x 4 points each; MFMA + weight stream only
+  // consumer waves 0..3: wave (wm, wn): 64 pairs x 32 output channels x 4 points; MFMA + weight stream
   // ==================================================================================================
-  const int n0 = nt * 32 * WN + wave * 32;
-  // weights: [step][ntile32][xi][piece][lane][8 bf16]; 16 B per lane and (xi, piece)
+  const int wn = (WN == 4) ? wave : (wave % WN), wm = (WM == 1) ? 0 : (wave / WN);
   const int ntiles32 = p.Cout_pad >> 5;
-  const unsigned short* w_ptr = p.wgt + ((size_t)(nt * WN + wave) * 12 * 64 + lane) * 8;
-  const size_t w_step = (p.dbg & 1) ? 0 : (size_t)ntiles32 * 12 * 64 * 8;  // ushorts per K-step
+  const size_t w_step = (size_t)ntiles32 * 12 * 64 * 8;  // ushorts per K-step
+  // weights: [step][ntile32][xi][piece][lane][8 bf16]; 16 B per lane and (xi, piece)
+  auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * WN + wn) * 12 * 64 + lane) * 8; };
 
   bf8 bw[4][3];
-#pragma unroll
-  for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-    for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w_ptr + (size_t)(xi * 3 + s) * 64 * 8);
-
-  f16v acc[4][2];  // [xi][M-tile]
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
+  f16v acc[4][2];  // [xi][own M-tile]
+  const int a_lane = (wm * 2 * 2 + l5) * KH_STRIDE + ((l31 * 8) ^ (l5 * 32));
+  auto load_a = [&](bf8 (&a)[2][3], const unsigned short* bufp, int xi) __attribute__((always_inline)) {
+    const unsigned short* base = bufp + xi * 3 * PLANE + a_lane;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[x][m][r] = 0.f;
-
-  const int a_lane = l5 * KH_STRIDE + ((l31 * 8) ^ (l5 * 32));
-  auto load_a = [&](bf8 (&a)[2][3], int buf, int xi) __attribute__((always_inline)) {
-    const unsigned short* base = &As[buf][xi][0][0][0][0] + a_lane;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int s = 0; s < 3; ++s) a[m][s] = *reinterpret_cast<const bf8*>(base + (s * 4 + m * 2) * KH_STRIDE);
+      for (int s = 0; s < 3; ++s) a[m][s] = *reinterpret_cast<const bf8*>(base + s * PLANE + m * 2 * KH_STRIDE);
   };
   auto mfma6 = [&](const bf8 (&a)[2][3], int xi) __attribute__((always_inline)) {
     const bf8 b0 = bw[xi][0], b1 = bw[xi][1], b2 = bw[xi][2];
@@ -252,101 +277,129 @@ __global__ __launch_bounds__(128 * WN) void conv_ws_kernel(WsParams p) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b0, acc[xi][m], 0, 0, 0);
   };
-  // one K-step: A operands of point xi+1 are fetched from LDS while the 12 MFMAs of point xi run;
-  // a point's weights are re-fetched (next K-step) as soon as its MFMAs are issued
-  auto compute_step = [&](int buf, const unsigned short* w_next) __attribute__((always_inline)) {
-    bf8 a0[2][3], a1[2][3];
+  // One K-step.  A operands of point xi+1 are fetched from LDS while the 12 MFMAs of point xi run; a
+  // point's weights are re-fetched (next K-step) as soon as its MFMAs are issued.  The block barrier
+  // that publishes the NEXT K-step sits before the last point's MFMAs (all LDS reads of this step have
+  // landed by then), so the next step's first operands are fetched behind those 12 MFMAs instead of
+  // exposing the LDS latency after the barrier.  a0 carries point 0 of the current step on entry.
+  bf8 a0[2][3], a1[2][3];
+  auto compute_step = [&](const unsigned short* bufp, const unsigned short* bufn,
+                          const unsigned short* w_next) __attribute__((always_inline)) {
     auto load_b = [&](int xi) __attribute__((always_inline)) {
 #pragma unroll
       for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w_next + (size_t)(xi * 3 + s) * 64 * 8);
     };
     // the fences pin the issue order: LDS fetch of the next point, 12 MFMAs, weight fetch
-    load_a(a0, buf, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    load_a(a1, buf, 1);
+    load_a(a1, bufp, 1);
     __builtin_amdgcn_sched_barrier(0);
     mfma6(a0, 0);
     __builtin_amdgcn_sched_barrier(0);
     load_b(0);
-    load_a(a0, buf, 2);
+    load_a(a0, bufp, 2);
     __builtin_amdgcn_sched_barrier(0);
     mfma6(a1, 1);
     __builtin_amdgcn_sched_barrier(0);
     load_b(1);
-    load_a(a1, buf, 3);
+    load_a(a1, bufp, 3);
     __builtin_amdgcn_sched_barrier(0);
     mfma6(a0, 2);
     __builtin_amdgcn_sched_barrier(0);
     load_b(2);
+    // unconditional (a branch here makes the compiler drain vmcnt at the loop head); the producers run
+    // one extra barrier for the last K-step, whose prefetch reads stale but valid LDS
+    __syncthreads();  // waits for this wave's LDS reads too: the current buffer is free, the next one is full
+    load_a(a0, bufn, 0);
     __builtin_amdgcn_sched_barrier(0);
     mfma6(a1, 3);
     __builtin_amdgcn_sched_barrier(0);
     load_b(3);
   };
 
-  __syncthreads();  // K-step 0 is in LDS
-  for (int s = 0; s + 1 < ns; ++s) {
-    if (!(p.dbg & 8)) compute_step(s & 1, w_ptr + (size_t)(s + 1) * w_step);
-    __syncthreads();
+  int gs = 0;  // global K-step counter of this block (LDS buffer = gs & 1)
+  {
+    const WsTile t0 = ws_tile<POOL, WM, WN>(p, blockIdx.x, total, nblk_n);
+    const unsigned short* w0 = w_tile(t0.nt);
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w0 + (size_t)(xi * 3 + s) * 64 * 8);
   }
-  // last step: the rolling prefetch re-reads the last step's weights (in bounds, unused)
-  compute_step((ns - 1) & 1, w_ptr + (size_t)(ns - 1) * w_step);
+  __syncthreads();  // global step 0 is in LDS
+  load_a(a0, As, 0);
+  for (int L = blockIdx.x; L < total; L += G) {
+    const WsTile t = ws_tile<POOL, WM, WN>(p, L, total, nblk_n);
+    const unsigned short* w_ptr = w_tile(t.nt);
+    // the last K-step prefetches the first weights of this block's next tile (or re-reads its own)
+    const unsigned short* w_after = (L + G < total) ? w_tile(ws_tile<POOL, WM, WN>(p, L + G, total, nblk_n).nt)
+                                                    : w_ptr;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][m][r] = 0.f;
+    // drain the epilogue's stores here, once per tile: otherwise the compiler merges their unknown count
+    // into the K-loop head and waits for vmcnt(0) -- i.e. for the weights just prefetched -- every K-step
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int s = 0; s < ns; ++s, ++gs)
+      compute_step(As + (gs & 1) * BUF, As + ((gs + 1) & 1) * BUF, s + 1 < ns ? w_ptr + (size_t)(s + 1) * w_step : w_after);
 
-  // ---- epilogue: 32x32 C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ---------------
-  const int n = n0 + l31;
-  if (n < p.Cout) {
-    const float pa = p.pre_a[n], pb = p.pre_b[n];
-    const bool has_post = p.post_a != nullptr;
-    const float qa = has_post ? p.post_a[n] : 1.f, qb = has_post ? p.post_b[n] : 0.f;
-    auto finish = [&](float m0, float m1, float m2, float m3, float& o0, float& o1) {
-      o0 = (m0 + m1) + m2;
-      o1 = (m1 - m2) - m3;
-      o0 = o0 * pa + pb;
-      o1 = o1 * pa + pb;
-      if (p.relu) {
-        o0 = fmaxf(o0, 0.f);
-        o1 = fmaxf(o1, 0.f);
-      }
-      if (has_post) {
-        o0 = o0 * qa + qb;
-        o1 = o1 * qa + qb;
-      }
-    };
-    if constexpr (POOL) {
-      const long nimg = pm0 / ((long)p.H * p.W);
-      const long pp0 = (nimg * (p.H >> 1) + (y0t >> 1)) * (p.W >> 1) + (x0t >> 1);
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int i = (r & 3) + 8 * (r >> 2) + 4 * l5;  // 0..15: pair inside the M-tile
-          const int pp = m * 16 + i;                      // pair inside the row == pooled column
-          float a0, a1, b0, b1;
-          finish(acc[0][m][r], acc[1][m][r], acc[2][m][r], acc[3][m][r], a0, a1);                  // row y
-          finish(acc[0][m][r + 8], acc[1][m][r + 8], acc[2][m][r + 8], acc[3][m][r + 8], b0, b1);  // row y+1
-          if (p.write_full) {
-            float* o = p.out + ((pm0 + 2 * pp) * p.out_cs + p.out_co + n);
-            o[0] = a0;
-            o[p.out_cs] = a1;
-            o[(long)p.W * p.out_cs] = b0;
-            o[(long)p.W * p.out_cs + p.out_cs] = b1;
-          }
-          p.pool_out[(pp0 + pp) * p.pool_cs + p.pool_co + n] = fmaxf(fmaxf(a0, a1), fmaxf(b0, b1));
+    // ---- epilogue: 32x32 C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------------
+    const int n = (t.nt * WN + wn) * 32 + l31;
+    if (n < p.Cout) {
+      const float pa = p.pre_a[n], pb = p.pre_b[n];
+      const bool has_post = p.post_a != nullptr;
+      const float qa = has_post ? p.post_a[n] : 1.f, qb = has_post ? p.post_b[n] : 0.f;
+      auto finish = [&](float m0, float m1, float m2, float m3, float& o0, float& o1) {
+        o0 = (m0 + m1) + m2;
+        o1 = (m1 - m2) - m3;
+        o0 = o0 * pa + pb;
+        o1 = o1 * pa + pb;
+        if (p.relu) {
+          o0 = fmaxf(o0, 0.f);
+          o1 = fmaxf(o1, 0.f);
         }
-    } else {
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int pair = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * l5;
-          float o0, o1;
-          finish(acc[0][m][r], acc[1][m][r], acc[2][m][r], acc[3][m][r], o0, o1);
-          if (pm0 + 2 * pair < p.Mtotal) {  // W even -> Mtotal even -> both pixels of the pair exist
-            float* o = p.out + ((pm0 + 2 * pair) * p.out_cs + p.out_co + n);
-            o[0] = o0;
-            o[p.out_cs] = o1;
-          }
+        if (has_post) {
+          o0 = o0 * qa + qb;
+          o1 = o1 * qa + qb;
         }
+      };
+      if constexpr (POOL) {
+        const long nimg = t.pm0 / ((long)p.H * p.W);
+        const long pp0 = (nimg * (p.H >> 1) + (t.y0t >> 1)) * (p.W >> 1) + (t.x0t >> 1);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * l5;  // 0..15: pair inside the M-tile
+            const int pp = (wm * 2 + m) * 16 + i;           // pair inside the row == pooled column
+            float a0, a1, b0, b1;
+            finish(acc[0][m][r], acc[1][m][r], acc[2][m][r], acc[3][m][r], a0, a1);                  // row y
+            finish(acc[0][m][r + 8], acc[1][m][r + 8], acc[2][m][r + 8], acc[3][m][r + 8], b0, b1);  // row y+1
+            if (p.write_full) {
+              float* o = p.out + ((t.pm0 + 2 * pp) * p.out_cs + p.out_co + n);
+              o[0] = a0;
+              o[p.out_cs] = a1;
+              o[(long)p.W * p.out_cs] = b0;
+              o[(long)p.W * p.out_cs + p.out_cs] = b1;
+            }
+            p.pool_out[(pp0 + pp) * p.pool_cs + p.pool_co + n] = fmaxf(fmaxf(a0, a1), fmaxf(b0, b1));
+          }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int pair = (wm * 2 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * l5;
+            float o0, o1;
+            finish(acc[0][m][r], acc[1][m][r], acc[2][m][r], acc[3][m][r], o0, o1);
+            if (t.pm0 + 2 * pair < p.Mtotal) {  // W even -> Mtotal even -> both pixels of the pair exist
+              float* o = p.out + ((t.pm0 + 2 * pair) * p.out_cs + p.out_co + n);
+              o[0] = o0;
+              o[p.out_cs] = o1;
+            }
+          }
+      }
     }
   }
 }
@@ -405,9 +458,34 @@ bool wsplit_applicable(const ConvLayer& L, const Tensor& in) {
          L.Cin % 16 == 0;
 }
 
+template <int POOL, int WM, int WN>
+static int ws_launch(kocr_ctx* ctx, WsParams& p, size_t M) {
+  constexpr int LDS_BYTES = 2 * 12 * (2 * WM) * 2 * 256 * 2;  // 48 KB (WM = 1) / 96 KB (WM = 2)
+  static bool attr_done = false;
+  if (!attr_done) {
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_ws_kernel<POOL, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      LDS_BYTES));
+    attr_done = true;
+  }
+  static int n_cu = 0;
+  if (!n_cu) {
+    hipDeviceProp_t prop;
+    KOCR_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    n_cu = prop.multiProcessorCount;
+  }
+  const size_t mtiles = POOL ? M / (size_t)(128 * WM) : (M + 128 * WM - 1) / (128 * WM);
+  p.total_tiles = (int)(mtiles * (p.Cout_pad / (32 * WN)));
+  const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;  // persistent: one block per CU
+  hipLaunchKernelGGL((conv_ws_kernel<POOL, WM, WN>), dim3(grid), dim3(512), LDS_BYTES, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
 int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
                        bool need_full) {
-  const bool fuse = pool && in.H % 2 == 0 && in.W % 64 == 0;
+  const int wcls = L.Cout > 64 ? 128 : 64;     // <1,4>: 128 px x 128 couts, <2,2>: 256 px x 64 couts
+  const int tile_w = wcls == 128 ? 64 : 128;   // fused pooling: tile = 2 rows x tile_w columns
+  const bool fuse = pool && in.H % 2 == 0 && in.W % tile_w == 0;
   const size_t M = in.pixels();
   WsParams p;
   p.in = in.p;
@@ -431,40 +509,35 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   p.Mtotal = (int)M;
   p.pool_out = nullptr;
   p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
-  static const int dbg = getenv("KOCR_WS_DBG") ? atoi(getenv("KOCR_WS_DBG")) : 0;
-  p.dbg = dbg;
+  p.total_tiles = 0;
   if (fuse) {
     p.pool_out = pool->p;
     p.pool_cs = pool->cs;
     p.pool_co = pool->co;
     p.write_full = need_full ? 1 : 0;
-    p.tiles_per_row = in.W / 64;
+    p.tiles_per_row = in.W / tile_w;
   }
-  const int wcls = L.Cout > 64 ? 128 : 64;
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_ws_128x%d%s:%s", wcls, fuse ? "p" : "", L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_ws_%dx%d%s:%s", wcls == 128 ? 128 : 256, wcls, fuse ? "p" : "", L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_ws_128x%d%s", wcls, fuse ? "_pool" : "");
+    snprintf(nm, sizeof nm, "conv_ws_%dx%d%s", wcls == 128 ? 128 : 256, wcls, fuse ? "_pool" : "");
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   {
     ProfScope ps(ctx, nm, flops, bytes);
-    const size_t mtiles = (M + 127) / 128;
-    dim3 grid((unsigned)(mtiles * (p.Cout_pad / wcls)));
     if (wcls == 128) {
       if (fuse)
-        hipLaunchKernelGGL((conv_ws_kernel<1, 4>), grid, dim3(512), 0, ctx->stream, p);
+        KOCR_TRY((ws_launch<1, 1, 4>(ctx, p, M)));
       else
-        hipLaunchKernelGGL((conv_ws_kernel<0, 4>), grid, dim3(512), 0, ctx->stream, p);
+        KOCR_TRY((ws_launch<0, 1, 4>(ctx, p, M)));
     } else {
       if (fuse)
-        hipLaunchKernelGGL((conv_ws_kernel<1, 2>), grid, dim3(256), 0, ctx->stream, p);
+        KOCR_TRY((ws_launch<1, 2, 2>(ctx, p, M)));
       else
-        hipLaunchKernelGGL((conv_ws_kernel<0, 2>), grid, dim3(256), 0, ctx->stream, p);
+        KOCR_TRY((ws_launch<0, 2, 2>(ctx, p, M)));
     }
-    KOCR_HIP(ctx, hipGetLastError());
   }
   if (pool && !fuse) return launch_maxpool2x2(ctx, out, *pool);
   return KOCR_OK;

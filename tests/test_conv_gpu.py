@@ -83,3 +83,38 @@ def test_conv_transpose_detecting(ctx):
     got = ctx.conv2d_nhwc(x, w)
     want = np.einsum("nhwc,co->nhwo", x, w[0, 0])
     assert np.array_equal(got, want)
+
+
+# ---------------------------------------------------------------------------------------------------
+# conv_wsplit.hip: 3x3 convolutions run on the bf16 matrix cores with every fp32 operand split exactly
+# into three bf16 pieces and six of the nine piece products kept.  The claim to defend is "fp32-class":
+# the error against an fp64 convolution of the same fp32 inputs must stay at fp32 round-off level,
+#     |err| <= 1e-6 * (|x| conv |w|)     elementwise
+# (a plain fp32 fma chain of K = 9*Cin terms has a worst case of K * 6e-8 and typically 2e-7 of that
+# bound; a kernel that dropped the third piece would sit at 4e-6..4e-5).  Shapes are chosen so that the
+# persistent blocks walk over several tiles each and both tile shapes (128 px x 128 couts, 256 px x 64
+# couts) and odd/even K-step counts are hit.
+# ---------------------------------------------------------------------------------------------------
+SPLIT_CASES = [
+    # N, H, W, Cin, Cout
+    (1, 96, 192, 256, 256),   # 288 tiles of 128x128 > 256 CUs: blocks take a second tile
+    (2, 64, 128, 64, 64),     # 256x64 tiles
+    (1, 40, 64, 48, 96),      # 9 K-steps (odd)
+    (1, 30, 50, 512, 130),    # ragged couts, tiles crossing image rows
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES, ids=[str(c) for c in SPLIT_CASES])
+def test_split_kernel_is_fp32_class_against_fp64(ctx, case):
+    n, h, w, cin, cout = case
+    rng = np.random.default_rng(hash(case) % (2 ** 32))
+    x = np.maximum(rng.standard_normal((n, h, w, cin)), 0).astype(np.float32)  # post-ReLU-like, half zeros
+    wt = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32)
+    got = ctx.conv2d_nhwc(x, wt).astype(np.float64)
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
+    wtt = torch.from_numpy(wt).double().permute(3, 2, 0, 1)
+    want = F.conv2d(xt, wtt, None, padding=1).permute(0, 2, 3, 1).numpy()
+    bound = F.conv2d(xt.abs(), wtt.abs(), None, padding=1).permute(0, 2, 3, 1).numpy()
+    ratio = np.abs(got - want) / np.maximum(bound, 1e-30)
+    assert float(ratio.max()) <= 1e-6, f"max err / (|x| conv |w|) = {ratio.max():.3e}"
+    assert float(np.sqrt((ratio ** 2).mean())) <= 1.5e-7, f"rms = {np.sqrt((ratio ** 2).mean()):.3e}"

@@ -69,6 +69,8 @@ struct ConvLayer {
   int wino_cout_pad = 0;
   unsigned short* d_ws = nullptr;  // Winograd F(2,3) weights, 3-way bf16 split, conv_wsplit.hip order (Cout > 32)
   int ws_cout_pad = 0;
+  unsigned short* d_ds = nullptr;  // direct-conv weights, 3-way bf16 split, conv_dsplit.hip order
+  int ds_cout_pad = 0;
   bool tap_inner = false;  // K order [16-channel group][tap][16] (Cin % 16 == 0) instead of [tap][Cin]
   bool ready() const { return d_w != nullptr; }
 };
@@ -169,6 +171,10 @@ int prepare_wsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
 bool wsplit_applicable(const ConvLayer& L, const Tensor& in);
 int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
                        bool need_full);
+// conv_dsplit.hip
+int prepare_dsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
+bool dsplit_applicable(const ConvLayer& L, const Tensor& in);
+int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out);
 // elementwise.hip
 // row_off: input row that starts output row 0 (0 = keras 'valid' pooling; 1 = the same pooling seen
 // through a vertical flip of an odd-height tensor, as in the CRNN's natural-orientation conv stack)

@@ -1,0 +1,392 @@
+// conv_dsplit.hip — direct (implicit-GEMM) stride-1 'same' convolution of any kernel size / dilation
+// on the gfx950 BF16 matrix cores, fp32 operands split exactly into three bf16 pieces (six of the nine
+// piece products kept, fp32 accumulation) — the same arithmetic as conv_wsplit.hip, without the
+// Winograd transform.  It serves the layers the Winograd kernel cannot take: 1x1 convolutions
+// (detection.py:349-353 slice5 1x1, :106-115 the upconv 1x1s) and the dilated 3x3 of slice5
+// (detection.py:351, dilation 6).
+//
+//   out[pixel][o] = sum_{tap, c} in[pixel + offset(tap)][c] * w[tap][c][o]
+//
+// Block = 512 threads, persistent (one per CU): 4 consumer waves (MFMA + weight stream) and 4 producer
+// waves (gather of the shifted input pixels through raw buffer loads whose out-of-range offset returns
+// the zero padding, exact bf16x3 split, LDS fill).  Tile = 256*WM consecutive pixels of the flattened
+// (n, y, x) order x 32*WN output channels; consumer wave (wm, wn) owns 8 M-tiles of 32 pixels x 32
+// couts (128 accumulator registers).  K-step = one (16-channel group, tap): 48 MFMA 32x32x16 per wave.
+// LDS: As[buf][piece][M-tile][k half][32 rows x 8 ch] bf16, 24 KB * WM per buffer, the same
+// conflict-free layout as conv_wsplit.hip.  Weights: [16-ch group][tap][32-cout tile][piece][lane][8].
+#include "common.h"
+
+typedef short bf8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+
+struct DsParams {
+  const float* in;
+  const unsigned short* wgt;
+  float* out;
+  const float* pre_a;
+  const float* pre_b;
+  const float* post_a;
+  const float* post_b;
+  int H, W, Cin, in_cs, in_co;
+  int Cout, Cout_pad, out_cs, out_co;
+  int relu;
+  int KH, KW, dil;
+  int nsteps;  // KH * KW * Cin / 16
+  int Mtotal;
+  int total_tiles;
+};
+
+__device__ __forceinline__ int ds_xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7;
+  const int q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// exact 3-way truncation split of four fp32 values, packed as 4 bf16 (8 bytes) per piece
+__device__ __forceinline__ void ds_split4(const v4f v, u2v& h, u2v& m, u2v& l) {
+  unsigned uh[4], um[4], ul[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    uh[c] = __float_as_uint(v[c]) & 0xFFFF0000u;
+    const float r = v[c] - __uint_as_float(uh[c]);
+    um[c] = __float_as_uint(r) & 0xFFFF0000u;
+    ul[c] = __float_as_uint(r - __uint_as_float(um[c]));
+  }
+  h = u2v{__builtin_amdgcn_perm(uh[1], uh[0], 0x07060302u), __builtin_amdgcn_perm(uh[3], uh[2], 0x07060302u)};
+  m = u2v{__builtin_amdgcn_perm(um[1], um[0], 0x07060302u), __builtin_amdgcn_perm(um[3], um[2], 0x07060302u)};
+  l = u2v{__builtin_amdgcn_perm(ul[1], ul[0], 0x07060302u), __builtin_amdgcn_perm(ul[3], ul[2], 0x07060302u)};
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
+  constexpr int NMT = 8 * WM;                 // 32-pixel M-tiles per block tile
+  constexpr int TILE_PX = 256 * WM;
+  constexpr int IPT = 4 * WM;                 // gather items (pixel, channel quad) per producer thread
+  constexpr int KH_STRIDE = 256;              // ushorts: 32 rows x 8 channels
+  constexpr int PLANE = NMT * 2 * KH_STRIDE;  // one piece plane
+  constexpr int BUF = 3 * PLANE;              // one K-step: 24 KB * WM
+  extern __shared__ __attribute__((aligned(16))) unsigned short As[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, l5 = lane >> 5;
+  const int nblk_n = p.Cout_pad / (32 * WN);
+  const int total = p.total_tiles;
+  const int ns = p.nsteps;
+  const int G = gridDim.x;
+  const int ntaps = p.KH * p.KW;
+  const int pad_y = p.dil * (p.KH / 2), pad_x = p.dil * (p.KW / 2);
+
+  // ==================================================================================================
+  // producer waves 4..7
+  // ==================================================================================================
+  if (wave >= 4) {
+    const int ptid = tid - 256;
+    const int quad = ptid & 3;
+    constexpr unsigned OOB = 0x80000000u;
+    int ldst[IPT];
+#pragma unroll
+    for (int it = 0; it < IPT; ++it) {
+      const int idx = (ptid >> 2) + it * 64;
+      ldst[it] = ((idx >> 5) * 2 + (quad >> 1)) * KH_STRIDE + ((((idx & 31) * 8) ^ ((quad >> 1) * 32)) + (quad & 1) * 4);
+    }
+    // position of the NEXT K-step to load: tile L_ld, step (ld_cg, ld_tap = (ld_ky, ld_kx))
+    int L_ld = blockIdx.x, ld_ky = 0, ld_kx = 0, ld_cg = 0;
+    unsigned goff[IPT];
+    int gy[IPT], gx[IPT];
+    bool gok[IPT];
+    __amdgpu_buffer_rsrc_t rsrc;
+    // buffer resource based (pad_y rows + pad_x pixels) BEFORE the tile: every tap offset is >= 0
+    auto tile_geometry = [&]() __attribute__((always_inline)) {
+      const int tile = ds_xcd_remap(L_ld < total ? L_ld : 0, total);
+      const long pm0 = (long)(tile / nblk_n) * TILE_PX;
+      const float* bbase_v = p.in + (pm0 * p.in_cs + p.in_co) - (long)(pad_y * p.W + pad_x) * p.in_cs;
+      const unsigned long long bb = (unsigned long long)bbase_v;
+      const unsigned long long bbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)bb);
+      rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)bbu, 0, 0x80000000, 0x00020000);
+#pragma unroll
+      for (int it = 0; it < IPT; ++it) {
+        const int idx = (ptid >> 2) + it * 64;
+        const long g = pm0 + idx;
+        gok[it] = g < p.Mtotal && L_ld < total;
+        gx[it] = (int)(g % p.W);
+        gy[it] = (int)((g / p.W) % p.H);
+        goff[it] = (unsigned)((idx * p.in_cs + quad * 4) * 4);
+      }
+    };
+    auto load_raw = [&](v4f (&raw)[IPT]) __attribute__((always_inline)) {
+      const int dy = ld_ky * p.dil - pad_y, dx = ld_kx * p.dil - pad_x;
+      const int soff = (((dy + pad_y) * p.W + (dx + pad_x)) * p.in_cs + ld_cg * 16) * 4;
+#pragma unroll
+      for (int it = 0; it < IPT; ++it) {
+        const bool ok = gok[it] && (unsigned)(gy[it] + dy) < (unsigned)p.H && (unsigned)(gx[it] + dx) < (unsigned)p.W;
+        raw[it] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? goff[it] : OOB, soff, 0));
+      }
+      if (++ld_kx == p.KW) {
+        ld_kx = 0;
+        if (++ld_ky == p.KH) {
+          ld_ky = 0;
+          if (++ld_cg == p.Cin / 16) {  // next tile
+            ld_cg = 0;
+            L_ld += G;
+            tile_geometry();
+          }
+        }
+      }
+    };
+    auto produce = [&](const v4f (&raw)[IPT], int buf) __attribute__((always_inline)) {
+      unsigned short* base = As + buf * BUF;
+#pragma unroll
+      for (int it = 0; it < IPT; ++it) {
+        u2v h, m, l;
+        ds_split4(raw[it], h, m, l);
+        unsigned short* dst = base + ldst[it];
+        *reinterpret_cast<u2v*>(dst) = h;
+        *reinterpret_cast<u2v*>(dst + PLANE) = m;
+        *reinterpret_cast<u2v*>(dst + 2 * PLANE) = l;
+      }
+    };
+    const int my_tiles = (total - (int)blockIdx.x + G - 1) / G;
+    const int T = my_tiles * ns;
+    tile_geometry();
+    v4f rawA[IPT], rawB[IPT];
+    load_raw(rawA);
+    int k = 0;
+    for (; k + 2 <= T; k += 2) {
+      load_raw(rawB);
+      produce(rawA, 0);
+      __syncthreads();
+      load_raw(rawA);
+      produce(rawB, 1);
+      __syncthreads();
+    }
+    if (k < T) {
+      produce(rawA, 0);
+      __syncthreads();
+    }
+    __syncthreads();  // pairs with the consumers' barrier inside the last K-step
+    return;
+  }
+
+  // ==================================================================================================
+  // consumer waves 0..3: wave (wm, wn): 8 M-tiles (256 pixels) x 32 output channels
+  // ==================================================================================================
+  const int wn = (WN == 4) ? wave : (wave % WN), wm = (WM == 1) ? 0 : (wave / WN);
+  const int ntiles32 = p.Cout_pad >> 5;
+  const size_t w_step = (size_t)ntiles32 * 3 * 64 * 8;  // ushorts per K-step
+  auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * WN + wn) * 3 * 64 + lane) * 8; };
+
+  bf8 bw[3], bwn[3];
+  f16v acc[4][2];  // [M-tile pair][M-tile in pair]
+  const int a_lane = (wm * 8 * 2 + l5) * KH_STRIDE + ((l31 * 8) ^ (l5 * 32));
+  auto load_a = [&](bf8 (&a)[2][3], const unsigned short* bufp, int g) __attribute__((always_inline)) {
+    const unsigned short* base = bufp + a_lane + g * 4 * KH_STRIDE;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) a[m][s] = *reinterpret_cast<const bf8*>(base + s * PLANE + m * 2 * KH_STRIDE);
+  };
+  auto mfma6 = [&](const bf8 (&a)[2][3], int g) __attribute__((always_inline)) {
+    const bf8 b0 = bw[0], b1 = bw[1], b2 = bw[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b0, acc[g][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b2, acc[g][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b1, acc[g][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b0, acc[g][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b1, acc[g][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b0, acc[g][m], 0, 0, 0);
+  };
+  // One K-step (see conv_wsplit.hip): LDS fetch of the next M-tile pair behind the 12 MFMAs of the
+  // current one; the barrier publishing the next K-step sits before the last pair's MFMAs; the next
+  // step's weights (3 x 16 B per lane) are fetched at the start of the step.
+  bf8 a0[2][3], a1[2][3];
+  auto compute_step = [&](const unsigned short* bufp, const unsigned short* bufn,
+                          const unsigned short* w_next) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) bwn[s] = *reinterpret_cast<const bf8*>(w_next + (size_t)s * 64 * 8);
+    load_a(a1, bufp, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(a0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(a0, bufp, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(a1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(a1, bufp, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(a0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    load_a(a0, bufn, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(a1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) bw[s] = bwn[s];
+  };
+
+  int gs = 0;
+  {
+    const int tile0 = ds_xcd_remap(blockIdx.x, total);
+    const unsigned short* w0 = w_tile(tile0 % nblk_n);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) bw[s] = *reinterpret_cast<const bf8*>(w0 + (size_t)s * 64 * 8);
+  }
+  __syncthreads();  // global step 0 is in LDS
+  load_a(a0, As, 0);
+  for (int L = blockIdx.x; L < total; L += G) {
+    const int tile = ds_xcd_remap(L, total);
+    const int mt = tile / nblk_n, nt = tile - mt * nblk_n;
+    const long pm0 = (long)mt * TILE_PX;
+    const unsigned short* w_ptr = w_tile(nt);
+    const unsigned short* w_after = (L + G < total) ? w_tile(ds_xcd_remap(L + G, total) % nblk_n) : w_ptr;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][m][r] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the epilogue's stores once per tile (see conv_wsplit.hip)
+    for (int s = 0; s < ns; ++s, ++gs)
+      compute_step(As + (gs & 1) * BUF, As + ((gs + 1) & 1) * BUF, s + 1 < ns ? w_ptr + (size_t)(s + 1) * w_step : w_after);
+
+    // ---- epilogue: 32x32 C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------------
+    const int n = (nt * WN + wn) * 32 + l31;
+    if (n < p.Cout) {
+      const float pa = p.pre_a[n], pb = p.pre_b[n];
+      const bool has_post = p.post_a != nullptr;
+      const float qa = has_post ? p.post_a[n] : 1.f, qb = has_post ? p.post_b[n] : 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int px = ((wm * 4 + g) * 2 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * l5;
+            float o = acc[g][m][r] * pa + pb;
+            if (p.relu) o = fmaxf(o, 0.f);
+            if (has_post) o = o * qa + qb;
+            if (pm0 + px < p.Mtotal) p.out[(pm0 + px) * p.out_cs + p.out_co + n] = o;
+          }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+static inline void ds_split3_host(float v, unsigned short out[3]) {
+  float r = v;
+  for (int s = 0; s < 3; ++s) {
+    uint32_t u;
+    memcpy(&u, &r, 4);
+    u &= 0xFFFF0000u;
+    float h;
+    memcpy(&h, &u, 4);
+    out[s] = (unsigned short)(u >> 16);
+    r = r - h;
+  }
+}
+
+// Built for every layer the Winograd split kernel does not take (1x1, dilated, 5x5 ...) whose GEMM is
+// wide enough to fill the 32-cout wave tiles.
+int prepare_dsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
+  if (L.Cin % 16 != 0 || L.Cout <= 32 || (L.KH == 3 && L.KW == 3 && L.dil == 1)) return KOCR_OK;
+  const int Cin = L.Cin, Cout = L.Cout, ntaps = L.KH * L.KW;
+  const int wcls = Cout > 64 ? 128 : 64;
+  const int cp = (Cout + wcls - 1) / wcls * wcls;
+  const int nt32 = cp / 32;
+  std::vector<unsigned short> u((size_t)(Cin / 16) * ntaps * nt32 * 3 * 64 * 8, 0);
+  for (int c = 0; c < Cin; ++c)
+    for (int tap = 0; tap < ntaps; ++tap)
+      for (int o = 0; o < Cout; ++o) {
+        const float g = w_is_oihw ? w[((size_t)o * Cin + c) * ntaps + tap] : w[((size_t)tap * Cin + c) * Cout + o];
+        // MFMA 32x32x16 B operand: lane = (k >> 3) * 32 + (o & 31) holds k = 8*(lane>>5) + j, j = 0..7
+        const int k = c % 16, lane = (k >> 3) * 32 + (o & 31), j = k & 7;
+        const size_t step = (size_t)(c / 16) * ntaps + tap;
+        unsigned short pc[3];
+        ds_split3_host(g, pc);
+        for (int s = 0; s < 3; ++s) u[(((step * nt32 + o / 32) * 3 + s) * 64 + lane) * 8 + j] = pc[s];
+      }
+  L.ds_cout_pad = cp;
+  void* d = nullptr;
+  KOCR_TRY(ctx->dev_alloc(&d, u.size() * sizeof(unsigned short)));
+  KOCR_HIP(ctx, hipMemcpy(d, u.data(), u.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  L.d_ds = (unsigned short*)d;
+  return KOCR_OK;
+}
+
+bool dsplit_applicable(const ConvLayer& L, const Tensor& in) {
+  static const bool off = getenv("KOCR_DSPLIT") && atoi(getenv("KOCR_DSPLIT")) == 0;
+  // small GEMMs (the CRNN's dense layers) stay on the fp32 kernel: nothing to gain below a few tiles
+  return !off && L.d_ds && in.cs % 4 == 0 && in.co % 4 == 0 && ((uintptr_t)in.p & 15) == 0 && in.pixels() >= 4096 &&
+         (size_t)in.pixels() * in.cs < ((size_t)1 << 40);
+}
+
+template <int WM, int WN>
+static int ds_launch(kocr_ctx* ctx, DsParams& p, size_t M) {
+  constexpr int LDS_BYTES = 2 * 3 * (8 * WM) * 2 * 256 * 2;  // 48 KB (WM = 1) / 96 KB (WM = 2)
+  static bool attr_done = false;
+  if (!attr_done) {
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_ds_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_done = true;
+  }
+  static int n_cu = 0;
+  if (!n_cu) {
+    hipDeviceProp_t prop;
+    KOCR_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    n_cu = prop.multiProcessorCount;
+  }
+  const size_t mtiles = (M + 256 * WM - 1) / (256 * WM);
+  p.total_tiles = (int)(mtiles * (p.Cout_pad / (32 * WN)));
+  const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
+  hipLaunchKernelGGL((conv_ds_kernel<WM, WN>), dim3(grid), dim3(512), LDS_BYTES, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
+int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out) {
+  const size_t M = in.pixels();
+  DsParams p;
+  p.in = in.p;
+  p.wgt = L.d_ds;
+  p.out = out.p;
+  p.pre_a = L.d_pre_a;
+  p.pre_b = L.d_pre_b;
+  p.post_a = L.d_post_a;
+  p.post_b = L.d_post_b;
+  p.H = in.H;
+  p.W = in.W;
+  p.Cin = L.Cin;
+  p.in_cs = in.cs;
+  p.in_co = in.co;
+  p.Cout = L.Cout;
+  p.Cout_pad = L.ds_cout_pad;
+  p.out_cs = out.cs;
+  p.out_co = out.co;
+  p.relu = L.relu;
+  p.KH = L.KH;
+  p.KW = L.KW;
+  p.dil = L.dil;
+  p.nsteps = L.KH * L.KW * (L.Cin / 16);
+  p.Mtotal = (int)M;
+  p.total_tiles = 0;
+  const int wcls = L.Cout > 64 ? 128 : 64;
+  static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
+  char nm[64];
+  if (per_layer)
+    snprintf(nm, sizeof nm, "conv_ds_%dx%d:%s", wcls == 128 ? 256 : 512, wcls, L.name.c_str());
+  else
+    snprintf(nm, sizeof nm, "conv_ds_%dx%d", wcls == 128 ? 256 : 512, wcls);
+  const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
+  const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
+  ProfScope ps(ctx, nm, flops, bytes);
+  if (wcls == 128) return ds_launch<1, 4>(ctx, p, M);
+  return ds_launch<2, 2>(ctx, p, M);
+}

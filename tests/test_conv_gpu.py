@@ -118,3 +118,36 @@ def test_split_kernel_is_fp32_class_against_fp64(ctx, case):
     ratio = np.abs(got - want) / np.maximum(bound, 1e-30)
     assert float(ratio.max()) <= 1e-6, f"max err / (|x| conv |w|) = {ratio.max():.3e}"
     assert float(np.sqrt((ratio ** 2).mean())) <= 1.5e-7, f"rms = {np.sqrt((ratio ** 2).mean()):.3e}"
+
+
+# conv_dsplit.hip: the same bf16x3 arithmetic for 1x1 / dilated / larger kernels (>= 4096 pixels)
+DSPLIT_CASES = [
+    # N, H, W, Cin, Cout, k, dil
+    (1, 96, 96, 512, 256, 3, 6),    # slice5.1 class (dilated), 256x128 tiles
+    (2, 64, 72, 1024, 128, 1, 1),   # slice5.2 class
+    (1, 192, 192, 192, 64, 1, 1),   # upconv4.conv.0 class: 512x64 tiles
+    (1, 70, 61, 48, 100, 1, 1),     # ragged pixels / couts, 3 K-steps
+    (1, 65, 67, 32, 40, 5, 1),      # 5x5, tiles crossing rows, odd sizes
+    (2, 50, 90, 64, 70, 3, 2),      # dilation 2, two images
+]
+
+
+@pytest.mark.parametrize("case", DSPLIT_CASES, ids=[str(c) for c in DSPLIT_CASES])
+def test_direct_split_kernel_is_fp32_class_against_fp64(ctx, case):
+    n, h, w, cin, cout, k, dil = case
+    rng = np.random.default_rng(hash(case) % (2 ** 32))
+    x = np.maximum(rng.standard_normal((n, h, w, cin)), 0).astype(np.float32)
+    wt = (rng.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32)
+    pre_a = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    pre_b = rng.uniform(-0.3, 0.3, cout).astype(np.float32)
+    got = ctx.conv2d_nhwc(x, wt, dilation=dil, pre_a=pre_a, pre_b=pre_b, relu=True).astype(np.float64)
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
+    wtt = torch.from_numpy(wt).double().permute(3, 2, 0, 1)
+    pad = dil * (k // 2)
+    a = torch.from_numpy(pre_a).double().view(1, -1, 1, 1)
+    b = torch.from_numpy(pre_b).double().view(1, -1, 1, 1)
+    want = F.relu(F.conv2d(xt, wtt, None, padding=pad, dilation=dil) * a + b).permute(0, 2, 3, 1).numpy()
+    bound = (F.conv2d(xt.abs(), wtt.abs(), None, padding=pad, dilation=dil) * a + b.abs()).permute(0, 2, 3, 1).numpy()
+    ratio = np.abs(got - want) / np.maximum(bound, 1e-30)
+    assert got.shape == want.shape
+    assert float(ratio.max()) <= 1e-6, f"max err / bound = {ratio.max():.3e}"

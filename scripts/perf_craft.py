@@ -8,7 +8,10 @@ import keras_ocr_amd as k
 N, H, W = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 ctx = k.Context(0)
-ctx.load_craft(k.weights.synthetic_craft_weights())
+wts = k.weights.synthetic_craft_weights()
+if os.environ.get("PERF_ZERO_W"):  # power experiment: zero conv kernels -> constant activations, minimal toggling
+    wts = {n: (np.zeros_like(v) if v.ndim == 4 else v) for n, v in wts.items()}
+ctx.load_craft(wts)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 img = torch.randint(0, 256, (N, H, W, 3), dtype=torch.uint8, device="cuda")
 heat = torch.empty((N, H // 2, W // 2, 2), dtype=torch.float32, device="cuda")

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
   constexpr int PLANE = NMT * 2 * KH_STRIDE;  // one piece plane
   constexpr int BUF = 3 * PLANE;              // one K-step: 24 KB * WM
   extern __shared__ __attribute__((aligned(16))) unsigned short As[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keep it in an SGPR
   const int l31 = lane & 31, l5 = lane >> 5;
   const int nblk_n = p.Cout_pad / (32 * WN);
   const int total = p.total_tiles;
@@ -257,22 +258,40 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
       compute_step(As + (gs & 1) * BUF, As + ((gs + 1) & 1) * BUF, s + 1 < ns ? w_ptr + (size_t)(s + 1) * w_step : w_after);
 
     // ---- epilogue: 32x32 C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------------
-    const int n = (nt * WN + wn) * 32 + l31;
-    if (n < p.Cout) {
-      const float pa = p.pre_a[n], pb = p.pre_b[n];
+    // branch-free, in place, raw buffer stores back to back (see conv_wsplit.hip)
+    {
+      const int n = (nt * WN + wn) * 32 + l31;
+      const int nc = n < p.Cout ? n : p.Cout - 1;
+      const float pa = p.pre_a[nc], pb = p.pre_b[nc];
       const bool has_post = p.post_a != nullptr;
-      const float qa = has_post ? p.post_a[n] : 1.f, qb = has_post ? p.post_b[n] : 0.f;
+      const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int px = ((wm * 4 + g) * 2 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * l5;
             float o = acc[g][m][r] * pa + pb;
             if (p.relu) o = fmaxf(o, 0.f);
             if (has_post) o = o * qa + qb;
-            if (pm0 + px < p.Mtotal) p.out[(pm0 + px) * p.out_cs + p.out_co + n] = o;
+            acc[g][m][r] = o;
+          }
+      const int ocs4 = p.out_cs * 4;
+      const long rem = ((long)p.Mtotal - pm0) * ocs4;  // stores past the end of the tensor are dropped
+      const unsigned long long bb = (unsigned long long)(p.out + (pm0 * p.out_cs + p.out_co));
+      const unsigned long long bbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)bb);
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)bbu, 0, __builtin_amdgcn_readfirstlane((int)(rem < 0x7FFFFFFFL ? rem : 0x7FFFFFFFL)), 0x00020000);
+      const unsigned vo = n < p.Cout ? (unsigned)((4 * l5 * p.out_cs + n) * 4) : 0x80000000u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int px = ((wm * 4 + g) * 2 + m) * 32 + (r & 3) + 8 * (r >> 2);  // + 4*l5 in vo
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[g][m][r]), ro, vo, px * ocs4, 0);
           }
     }
   }

@@ -49,6 +49,7 @@ struct WsParams {
   float* pool_out;
   int pool_cs, pool_co, write_full, tiles_per_row;
   int total_tiles;
+  int dbg;  // developer timing experiments (wrong results): 1 = skip the epilogue
 };
 
 __device__ __forceinline__ int ws_xcd_remap(int bid, int nwg) {
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
   // contiguous bytes (16 B per lane, conflict-free); the rows of k half 1 are XOR-ed with 64 B so the two
   // k halves a 16-lane ds_write_b64 group touches fall into different halves of the 32 store banks.
   extern __shared__ __attribute__((aligned(16))) unsigned short As[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: keep it in an SGPR
   const int l31 = lane & 31, l5 = lane >> 5;
   const int nblk_n = p.Cout_pad / (32 * WN);
   const int total = p.total_tiles;
@@ -345,11 +347,17 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
       compute_step(As + (gs & 1) * BUF, As + ((gs + 1) & 1) * BUF, s + 1 < ns ? w_ptr + (size_t)(s + 1) * w_step : w_after);
 
     // ---- epilogue: 32x32 C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------------
-    const int n = (t.nt * WN + wn) * 32 + l31;
-    if (n < p.Cout) {
-      const float pa = p.pre_a[n], pb = p.pre_b[n];
+    // Two phases, no branches: (1) inverse transform + BN + ReLU IN PLACE in the accumulators, (2) all
+    // stores back to back as raw buffer stores: one per-lane byte offset (never rewritten), the per-
+    // register pixel offset in an SGPR, out-of-range pixels / padded couts dropped by the hardware range
+    // check.  (With `if (pixel < M) o[..] = ..` per pair hipcc put `s_waitcnt vmcnt(0)` before every
+    // store pair -- one full memory round trip each, 20-35 % of the kernel.)
+    {
+      const int n = (t.nt * WN + wn) * 32 + l31;
+      const int nc = n < p.Cout ? n : p.Cout - 1;
+      const float pa = p.pre_a[nc], pb = p.pre_b[nc];
       const bool has_post = p.post_a != nullptr;
-      const float qa = has_post ? p.post_a[n] : 1.f, qb = has_post ? p.post_b[n] : 0.f;
+      const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
       auto finish = [&](float m0, float m1, float m2, float m3, float& o0, float& o1) {
         o0 = (m0 + m1) + m2;
         o1 = (m1 - m2) - m3;
@@ -364,40 +372,76 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
           o1 = o1 * qa + qb;
         }
       };
+      constexpr unsigned OOB = 0x80000000u;
+      const bool live = n < p.Cout && !(p.dbg & 1);
+      auto uniform_rsrc = [&](const float* base, unsigned bytes) {
+        const unsigned long long bb = (unsigned long long)base;
+        const unsigned long long bbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)bb);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)bbu, 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+      };
+      const int ocs4 = p.out_cs * 4;
       if constexpr (POOL) {
-        const long nimg = t.pm0 / ((long)p.H * p.W);
-        const long pp0 = (nimg * (p.H >> 1) + (t.y0t >> 1)) * (p.W >> 1) + (t.x0t >> 1);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * l5;  // 0..15: pair inside the M-tile
-            const int pp = (wm * 2 + m) * 16 + i;           // pair inside the row == pooled column
             float a0, a1, b0, b1;
             finish(acc[0][m][r], acc[1][m][r], acc[2][m][r], acc[3][m][r], a0, a1);                  // row y
             finish(acc[0][m][r + 8], acc[1][m][r + 8], acc[2][m][r + 8], acc[3][m][r + 8], b0, b1);  // row y+1
-            if (p.write_full) {
-              float* o = p.out + ((t.pm0 + 2 * pp) * p.out_cs + p.out_co + n);
-              o[0] = a0;
-              o[p.out_cs] = a1;
-              o[(long)p.W * p.out_cs] = b0;
-              o[(long)p.W * p.out_cs + p.out_cs] = b1;
+            acc[0][m][r] = a0;
+            acc[1][m][r] = a1;
+            acc[0][m][r + 8] = b0;
+            acc[1][m][r + 8] = b1;
+            acc[2][m][r] = fmaxf(fmaxf(a0, a1), fmaxf(b0, b1));
+          }
+        const long nimg = t.pm0 / ((long)p.H * p.W);
+        const long pp0 = (nimg * (p.H >> 1) + (t.y0t >> 1)) * (p.W >> 1) + (t.x0t >> 1);
+        if (p.write_full) {
+          const __amdgpu_buffer_rsrc_t ro = uniform_rsrc(p.out + (t.pm0 * p.out_cs + p.out_co), 0x7FFFFFFFu);
+          const unsigned vo = live ? (unsigned)((8 * l5 * p.out_cs + n) * 4) : OOB;
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const int px = 2 * ((wm * 2 + m) * 16 + (r & 3) + 8 * (r >> 2));  // + 8*l5 in vo
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[0][m][r]), ro, vo, px * ocs4, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[1][m][r]), ro, vo, (px + 1) * ocs4, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[0][m][r + 8]), ro, vo, (px + p.W) * ocs4, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[1][m][r + 8]), ro, vo, (px + p.W + 1) * ocs4, 0);
             }
-            p.pool_out[(pp0 + pp) * p.pool_cs + p.pool_co + n] = fmaxf(fmaxf(a0, a1), fmaxf(b0, b1));
+        }
+        const __amdgpu_buffer_rsrc_t rp = uniform_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
+        const unsigned vp = live ? (unsigned)((4 * l5 * p.pool_cs + n) * 4) : OOB;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int pp = (wm * 2 + m) * 16 + (r & 3) + 8 * (r >> 2);  // + 4*l5 in vp
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[2][m][r]), rp, vp, pp * p.pool_cs * 4, 0);
           }
       } else {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int pair = (wm * 2 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * l5;
             float o0, o1;
             finish(acc[0][m][r], acc[1][m][r], acc[2][m][r], acc[3][m][r], o0, o1);
-            if (t.pm0 + 2 * pair < p.Mtotal) {  // W even -> Mtotal even -> both pixels of the pair exist
-              float* o = p.out + ((t.pm0 + 2 * pair) * p.out_cs + p.out_co + n);
-              o[0] = o0;
-              o[p.out_cs] = o1;
-            }
+            acc[0][m][r] = o0;
+            acc[1][m][r] = o1;
+          }
+        // bytes from the tile's first pixel to the end of the tensor: stores past it are dropped
+        const long rem = ((long)p.Mtotal - t.pm0) * ocs4;
+        const __amdgpu_buffer_rsrc_t ro =
+            uniform_rsrc(p.out + (t.pm0 * p.out_cs + p.out_co), rem < 0x7FFFFFFFL ? (unsigned)rem : 0x7FFFFFFFu);
+        const unsigned vo = live ? (unsigned)((8 * l5 * p.out_cs + n) * 4) : OOB;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int px = 2 * ((wm * 2 + m) * 32 + (r & 3) + 8 * (r >> 2));  // + 8*l5 in vo
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[0][m][r]), ro, vo, px * ocs4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[1][m][r]), ro, vo, (px + 1) * ocs4, 0);
           }
       }
     }
@@ -510,6 +554,8 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   p.pool_out = nullptr;
   p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
   p.total_tiles = 0;
+  static const int dbg = getenv("KOCR_WS_DBG") ? atoi(getenv("KOCR_WS_DBG")) : 0;
+  p.dbg = dbg;
   if (fuse) {
     p.pool_out = pool->p;
     p.pool_cs = pool->cs;

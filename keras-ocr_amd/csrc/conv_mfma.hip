@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
   __shared__ float lut_s[MODE == 2 ? 768 : 1];  // compute_input table (first layer, uint8 input)
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: SGPR
   const int wm = wave / WN, wn = wave % WN;
   const int lr = lane & 31, lk = lane >> 5;
 
@@ -372,11 +372,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WTN + j * 32 + lr;
-    if (n >= p.Cout) continue;
-    const float pa = p.pre_a[n], pb = p.pre_b[n];
+    const bool live = n < p.Cout;
+    if (POOL && !live) continue;
+    const int nc = live ? n : p.Cout - 1;
+    const float pa = p.pre_a[nc], pb = p.pre_b[nc];
     const bool has_post = p.post_a != nullptr;
-    const float qa = has_post ? p.post_a[n] : 1.f;
-    const float qb = has_post ? p.post_b[n] : 0.f;
+    const float qa = has_post ? p.post_a[nc] : 1.f;
+    const float qb = has_post ? p.post_b[nc] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       if constexpr (POOL) {
@@ -401,18 +403,35 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
           p.pool_out[pp * p.pool_cs + p.pool_co + n] = best;
         }
       } else {
+        // in place; the stores follow below, back to back
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-          const int m = m0 + wm * WTM + i * 32 + row;
-          if (m < p.Mtotal) {
-            float v = acc[i][j][r] * pa + pb;
-            if (p.relu) v = fmaxf(v, 0.f);
-            if (has_post) v = v * qa + qb;
-            p.out[(size_t)m * p.out_cs + p.out_co + n] = v;
-          }
+          float v = acc[i][j][r] * pa + pb;
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (has_post) v = v * qa + qb;
+          acc[i][j][r] = v;
         }
       }
+    }
+    if constexpr (!POOL) {
+      // Raw buffer stores: one per-lane byte offset, the per-register pixel offset in an SGPR, pixels past
+      // the end of the tensor and padded couts dropped by the range check.  (A per-pixel `if (m < M)`
+      // around each store made hipcc wait for vmcnt(0) before every store.)
+      const int ocs4 = p.out_cs * 4;
+      const long rem = ((long)p.Mtotal - m0) * ocs4;
+      const unsigned long long bb = (unsigned long long)(p.out + ((long)m0 * p.out_cs + p.out_co));
+      const unsigned long long bbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)bb);
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)bbu, 0, __builtin_amdgcn_readfirstlane((int)(rem < 0x7FFFFFFFL ? rem : 0x7FFFFFFFL)), 0x00020000);
+      const unsigned vo = live ? (unsigned)((4 * lk * p.out_cs + n) * 4) : 0x80000000u;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int px = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2);  // + 4*lk in vo
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), ro, vo, px * ocs4, 0);
+        }
     }
   }
 }

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
   constexpr int MT = 4 / WP;    // M-tiles (16 pairs each) per wave
   static_assert(WP * MT == 4 && (!POOL || WP <= 2), "tile split");
   __shared__ float As[2][16][LDA];        // raw input: As[buf][k][1 + pixel], pixel = -1 .. 128
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR
   const int l15 = lane & 15, l4 = lane >> 4;
 
   const int nblk_n = p.Cout_pad / (16 * WC);
@@ -255,18 +255,33 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
           p.pool_out[(pp0 + pp) * p.pool_cs + p.pool_co + n] = fmaxf(fmaxf(a0, a1), fmaxf(b0, b1));
         }
     } else {
+      // in place, then raw buffer stores back to back: one per-lane byte offset, the per-register pixel
+      // offset in an SGPR, pixels past the end of the tensor dropped by the range check (a per-pair
+      // `if (pixel < M)` made hipcc wait for vmcnt(0) before every store pair)
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int pair = (wp + WP * m) * 16 + l4 * 4 + r;
           float o0, o1;
           finish(acc[0][m][r], acc[1][m][r], acc[2][m][r], acc[3][m][r], o0, o1);
-          if (pm0 + 2 * pair < p.Mtotal) {  // W even -> Mtotal even -> both pixels of the pair exist
-            float* o = p.out + ((pm0 + 2 * pair) * p.out_cs + p.out_co + n);
-            o[0] = o0;
-            o[p.out_cs] = o1;
-          }
+          acc[0][m][r] = o0;
+          acc[1][m][r] = o1;
+        }
+      const int ocs4 = p.out_cs * 4;
+      const long rem = ((long)p.Mtotal - pm0) * ocs4;
+      const unsigned long long bb = (unsigned long long)(p.out + (pm0 * p.out_cs + p.out_co));
+      const unsigned long long bbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)bb);
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)bbu, 0, __builtin_amdgcn_readfirstlane((int)(rem < 0x7FFFFFFFL ? rem : 0x7FFFFFFFL)), 0x00020000);
+      const unsigned vo = (unsigned)((8 * l4 * p.out_cs + n) * 4);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int px = 2 * ((wp + WP * m) * 16 + r);  // + 8*l4 in vo
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[0][m][r]), ro, vo, px * ocs4, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[1][m][r]), ro, vo, (px + 1) * ocs4, 0);
         }
     }
   }

@@ -505,18 +505,20 @@ bool wsplit_applicable(const ConvLayer& L, const Tensor& in) {
 template <int POOL, int WM, int WN>
 static int ws_launch(kocr_ctx* ctx, WsParams& p, size_t M) {
   constexpr int LDS_BYTES = 2 * 12 * (2 * WM) * 2 * 256 * 2;  // 48 KB (WM = 1) / 96 KB (WM = 2)
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64] = {};  // per device: one process may hold contexts on several GPUs
+  const int dev = ctx->device & 63;
+  if (!attr_done[dev]) {
     KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_ws_kernel<POOL, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       LDS_BYTES));
-    attr_done = true;
+    attr_done[dev] = true;
   }
-  static int n_cu = 0;
-  if (!n_cu) {
+  static int n_cus[64] = {};
+  if (!n_cus[dev]) {
     hipDeviceProp_t prop;
     KOCR_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
-    n_cu = prop.multiProcessorCount;
+    n_cus[dev] = prop.multiProcessorCount;
   }
+  const int n_cu = n_cus[dev];
   const size_t mtiles = POOL ? M / (size_t)(128 * WM) : (M + 128 * WM - 1) / (128 * WM);
   p.total_tiles = (int)(mtiles * (p.Cout_pad / (32 * WN)));
   const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;  // persistent: one block per CU

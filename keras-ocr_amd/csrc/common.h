@@ -182,6 +182,8 @@ int launch_maxpool2x2(kocr_ctx* ctx, const Tensor& in, const Tensor& out, int ro
 int launch_maxpool3x3s1(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
 int launch_resize_bilinear(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
 int launch_copy_channels(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
+// conv_cls.6 + conv_cls.8 of the CRAFT head in one pass (16 -> 16 ReLU -> 2), heat-map written densely
+int launch_head_tail(kocr_ctx* ctx, const ConvLayer& L6, const ConvLayer& L8, const Tensor& in, float* d_heat);
 
 // craft.cpp
 int craft_load(kocr_ctx* ctx, int n, const char* const* names, const float* const* data,

@@ -75,7 +75,6 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
   const int total = p.total_tiles;
   const int ns = p.nsteps;
   const int G = gridDim.x;
-  const int ntaps = p.KH * p.KW;
   const int pad_y = p.dil * (p.KH / 2), pad_x = p.dil * (p.KW / 2);
 
   // ==================================================================================================

@@ -257,7 +257,7 @@ int craft_forward(kocr_ctx* ctx, const void* d_img, int dtype, int N, int H, int
   KOCR_TRY(conv("basenet.slice5.1", h0, h1));
   KOCR_TRY(conv("basenet.slice5.2", h1, cat1.slice(0, 1024)));
   // ---- U-Net decoder (detection.py:380-390) ---------------------------------------------
-  Tensor u1a, u1b, u2a, u2b, u3a, u3b, u4a, feat, k0, k1, k2, k3;
+  Tensor u1a, u1b, u2a, u2b, u3a, u3b, u4a, feat, k0, k1, k2;
   KOCR_TRY(mk(d.H16, d.W16, 512, &u1a));
   KOCR_TRY(mk(d.H16, d.W16, 256, &u1b));
   KOCR_TRY(conv("upconv1.conv.0", cat1, u1a));
@@ -281,19 +281,9 @@ int craft_forward(kocr_ctx* ctx, const void* d_img, int dtype, int N, int H, int
   KOCR_TRY(mk(d.H2, d.W2, 32, &k0));
   KOCR_TRY(mk(d.H2, d.W2, 32, &k1));
   KOCR_TRY(mk(d.H2, d.W2, 16, &k2));
-  KOCR_TRY(mk(d.H2, d.W2, 16, &k3));
   KOCR_TRY(conv("conv_cls.0", feat, k0));
   KOCR_TRY(conv("conv_cls.2", k0, k1));
   KOCR_TRY(conv("conv_cls.4", k1, k2));
-  KOCR_TRY(conv("conv_cls.6", k2, k3));
-  Tensor heat;
-  heat.N = N;
-  heat.H = d.H2;
-  heat.W = d.W2;
-  heat.C = 2;
-  heat.cs = 2;
-  heat.co = 0;
-  heat.p = d_heat;
-  KOCR_TRY(conv("conv_cls.8", k3, heat));
-  return KOCR_OK;
+  // conv_cls.6 + conv_cls.8 (1x1 16 -> 16 ReLU, 1x1 16 -> 2): one fused pass, no 16-channel round trip
+  return launch_head_tail(ctx, net->L.at("conv_cls.6"), net->L.at("conv_cls.8"), k2, d_heat);
 }

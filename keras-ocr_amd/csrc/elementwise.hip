@@ -212,3 +212,93 @@ int launch_copy_channels(kocr_ctx* ctx, const Tensor& in, const Tensor& out) {
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// CRAFT head tail, fused: conv_cls.6 (1x1, 16 -> 16, ReLU) + conv_cls.8 (1x1, 16 -> 2, linear),
+// detection.py:407-410.  Both are far below the MFMA ridge (4 and 0.9 FLOP/B as separate layers):
+// one thread per pixel reads its 16 channels once (64 B), keeps the 16 hidden values in registers
+// and writes the two heat-map channels (8 B); weights and biases sit in LDS.  fp32 fma chains over
+// the input channels in index order.
+// ---------------------------------------------------------------------------------------
+struct HeadTailParams {
+  const float* in;   // [P][in_cs], 16 channels at in_co
+  float* out;        // [P][2]
+  const float* w6;   // [16][ld6] (k = cin, col = cout), pre_a6/pre_b6 per cout
+  const float* a6;
+  const float* b6;
+  const float* w8;   // [16][ld8]
+  const float* a8;
+  const float* b8;
+  int ld6, ld8, in_cs, in_co, relu6;
+  size_t P;
+};
+
+__global__ __launch_bounds__(256) void head_tail_kernel(HeadTailParams p) {
+  __shared__ float s_w6[16][16], s_a6[16], s_b6[16], s_w8[16][2], s_a8[2], s_b8[2];
+  const int tid = threadIdx.x;
+  s_w6[tid >> 4][tid & 15] = p.w6[(tid >> 4) * p.ld6 + (tid & 15)];
+  if (tid < 16) {
+    s_a6[tid] = p.a6[tid];
+    s_b6[tid] = p.b6[tid];
+    s_w8[tid][0] = p.w8[tid * p.ld8 + 0];
+    s_w8[tid][1] = p.w8[tid * p.ld8 + 1];
+  }
+  if (tid < 2) {
+    s_a8[tid] = p.a8[tid];
+    s_b8[tid] = p.b8[tid];
+  }
+  __syncthreads();
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + tid; i < p.P; i += (size_t)gridDim.x * blockDim.x) {
+    const float* src = p.in + i * p.in_cs + p.in_co;
+    float x[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const v4f v = *reinterpret_cast<const v4f*>(src + 4 * q);
+      x[4 * q + 0] = v.x;
+      x[4 * q + 1] = v.y;
+      x[4 * q + 2] = v.z;
+      x[4 * q + 3] = v.w;
+    }
+    float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      float h = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) h = fmaf(x[c], s_w6[c][o], h);
+      h = h * s_a6[o] + s_b6[o];
+      if (p.relu6) h = fmaxf(h, 0.f);
+      y0 = fmaf(h, s_w8[o][0], y0);
+      y1 = fmaf(h, s_w8[o][1], y1);
+    }
+    *reinterpret_cast<v2f*>(p.out + 2 * i) = v2f{y0 * s_a8[0] + s_b8[0], y1 * s_a8[1] + s_b8[1]};
+  }
+}
+
+int launch_head_tail(kocr_ctx* ctx, const ConvLayer& L6, const ConvLayer& L8, const Tensor& in, float* d_heat) {
+  if (L6.Cin != 16 || L6.Cout != 16 || L6.KH != 1 || L8.Cin != 16 || L8.Cout != 2 || L8.KH != 1 || L8.relu ||
+      L6.d_post_a || L8.d_post_a || !L6.tap_inner || !L8.tap_inner || in.C != 16 || in.cs % 4 || in.co % 4)
+    KOCR_FAIL(ctx, KOCR_EINVAL, "head_tail: unexpected layer shapes");
+  HeadTailParams p;
+  p.in = in.p;
+  p.out = d_heat;
+  p.w6 = L6.d_w;
+  p.a6 = L6.d_pre_a;
+  p.b6 = L6.d_pre_b;
+  p.w8 = L8.d_w;
+  p.a8 = L8.d_pre_a;
+  p.b8 = L8.d_pre_b;
+  p.ld6 = L6.Cout_pad;
+  p.ld8 = L8.Cout_pad;
+  p.in_cs = in.cs;
+  p.in_co = in.co;
+  p.relu6 = L6.relu;
+  p.P = in.pixels();
+  if (!p.P) return KOCR_OK;
+  const double flops = 2.0 * (double)p.P * (16 * 16 + 16 * 2);
+  ProfScope ps(ctx, "conv_head_tail", flops, (double)p.P * (64 + 8));
+  hipLaunchKernelGGL(head_tail_kernel, ew_grid(p.P), dim3(256), 0, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}

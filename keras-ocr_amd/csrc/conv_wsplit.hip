@@ -17,15 +17,17 @@
 //     d_i = in[y+ky-1][x0-1+i][c],   V = (d0-d2, d1+d2, d2-d1, d1-d3),   U = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)
 //     M_xi[pair][o] = sum_{ky,c} V_xi U_xi,   out[x0] = M0+M1+M2,   out[x0+1] = M1-M2-M3.
 //
-// Block = WN waves; tile = 64 pairs (128 pixels) x 32*WN output channels; K-step = one (16-channel
-// group, ky).  The block transforms its input piece ONCE: thread (pair, channel quad) loads the four
-// raw pixels, forms V (fp32, as conv_wino.hip does), splits and writes bf16 operands to LDS in MFMA
-// A-operand order As[buf][xi][piece][M-tile][k half][32 pairs][8 ch] (a 32x32x16 A fetch is two
-// contiguous 512-B runs, bank-conflict free).  Every wave owns 32 output channels for ALL pairs and all four points, so the
-// inverse transform is register-only.  U is pre-transformed and pre-split on the host and packed in
-// B-operand order [16-ch group][ky][32-cout tile][xi][piece][lane][8], fetched straight into
-// registers with a rolling per-point prefetch; weights never touch LDS.
-// Requires W even.  POOL variant: tile = 2 image rows x 64 columns with the 2x2 max taken in-lane.
+// Block = 512 threads, persistent (one per CU, walking over tiles): waves 4-7 PRODUCE -- thread (pair,
+// channel quad) loads the four raw pixels through raw buffer loads (out-of-range offset = zero padding),
+// forms V in fp32 exactly as conv_wino.hip does, splits and writes bf16 operands to LDS in MFMA A-operand
+// order As[buf][xi][piece][M-tile][k half][32 pairs][8 ch] (a 32x32x16 A fetch is two contiguous 512-B
+// runs, bank-conflict free) -- and waves 0-3 CONSUME: wave (wm, wn) owns 64 pairs x 32 output channels
+// for all four points (128 accumulator VGPRs), so the inverse transform is register-only.  Tile = 128 px x
+// 128 couts (<1,4>) or 256 px x 64 couts (<2,2>); K-step = one (16-channel group, ky) = 48 MFMAs per
+// consumer wave.  U is pre-transformed and pre-split on the host and packed in B-operand order
+// [16-ch group][ky][32-cout tile][xi][piece][lane][8], fetched straight into registers with a rolling
+// per-point prefetch; weights never touch LDS.  Requires W even.  POOL variant: tile = 2 image rows x
+// 64*WM columns with the 2x2 max taken in-lane.  Details at the kernel below; measurements in DESIGN.md.
 #include "common.h"
 
 typedef short bf8 __attribute__((ext_vector_type(8)));

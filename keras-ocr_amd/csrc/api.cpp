@@ -29,6 +29,19 @@ int arena_reserve(kocr_ctx* ctx, Arena& a, size_t bytes) {
 
 int kocr_ctx::ws_reserve(size_t bytes) { return arena_reserve(this, ws, bytes); }
 
+int kocr_ctx::amax_begin() {
+  if (!d_amax) {
+    void* d = nullptr;
+    KOCR_TRY(dev_alloc(&d, AMAX_SLOTS * sizeof(unsigned)));
+    d_amax = (unsigned*)d;
+  }
+  amax_used = 0;
+  KOCR_HIP(this, hipMemsetAsync(d_amax, 0, AMAX_SLOTS * sizeof(unsigned), stream));
+  return KOCR_OK;
+}
+
+unsigned* kocr_ctx::amax_slot() { return (d_amax && amax_used < AMAX_SLOTS) ? d_amax + amax_used++ : nullptr; }
+
 int kocr_ctx::dev_alloc(void** out, size_t bytes) {
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, bytes ? bytes : 4);
@@ -352,6 +365,7 @@ int kocr_conv2d_nhwc(kocr_ctx* ctx, const float* in, int N, int H, int W, int Ci
       !(KH & 1) || !(KW & 1))
     KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_conv2d_nhwc: bad shape (odd kernels, positive sizes)");
   KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  KOCR_TRY(ctx->amax_begin());  // allocates the slot pool BEFORE the mark below: it outlives this call
   const size_t first_owned = ctx->owned.size();
   ConvLayer L;
   L.name = "kocr_conv2d_nhwc";

@@ -42,6 +42,11 @@ struct Tensor {
   int N = 0, H = 0, W = 0, C = 0;
   int cs = 0;  // channel stride of the underlying buffer (floats per pixel)
   int co = 0;  // channel offset of this view inside the buffer
+  // Optional device slot holding (as uint bits of a non-negative float) an UPPER BOUND of max |x| over
+  // everything written into the underlying buffer during this forward; every producer kernel atomicMax-es
+  // into it.  The fp16-split convolutions derive their exact power-of-two input scale from it; a tensor
+  // without a slot is reduced on demand (launch_absmax).  Slices / views share the buffer's slot.
+  unsigned* amax = nullptr;
   size_t pixels() const { return (size_t)N * H * W; }
   Tensor slice(int off, int c) const {
     Tensor t = *this;
@@ -69,8 +74,12 @@ struct ConvLayer {
   int wino_cout_pad = 0;
   unsigned short* d_ws = nullptr;  // Winograd F(2,3) weights, 3-way bf16 split, conv_wsplit.hip order (Cout > 32)
   int ws_cout_pad = 0;
+  unsigned short* d_ws16 = nullptr;  // the same, 2-way fp16 split of U * 2^ws_wexp (fp16x2 mode)
+  int ws_wexp = 0;
   unsigned short* d_ds = nullptr;  // direct-conv weights, 3-way bf16 split, conv_dsplit.hip order
   int ds_cout_pad = 0;
+  unsigned short* d_ds16 = nullptr;  // 2-way fp16 split of w * 2^ds_wexp
+  int ds_wexp = 0;
   bool tap_inner = false;  // K order [16-channel group][tap][16] (Cin % 16 == 0) instead of [tap][Cin]
   bool ready() const { return d_w != nullptr; }
 };
@@ -97,6 +106,13 @@ struct kocr_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   void set_err(const std::string& s) { err = s; }
+
+  // max-|x| slots of the tensors of the current forward (see Tensor::amax): zeroed by amax_begin()
+  unsigned* d_amax = nullptr;
+  int amax_used = 0;
+  static constexpr int AMAX_SLOTS = 256;
+  int amax_begin();            // (re)start slot allocation, zero the slots on the ctx stream
+  unsigned* amax_slot();       // next slot (nullptr when exhausted: the consumer then reduces on demand)
 
   // workspace arenas (bump allocated per call, grown on demand): ws = network activations,
   // pp = post-processing per-pixel scratch, pp2 = post-processing canvases, io = staging,
@@ -149,6 +165,18 @@ struct ProfScope {
   }
 };
 
+// wave-level max |x| into a Tensor::amax slot (device code; values are non-negative, so uint order = float order)
+#if defined(__HIPCC__)
+__device__ __forceinline__ void kocr_amax_update(unsigned* slot, float m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  // One address for a whole tensor: issue the atomic only when it can still raise the slot (a stale read
+  // merely costs a redundant atomic).  Unconditional atomics from every tile serialise in L2 -- measured
+  // 4x on the first layer.
+  if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > *(volatile const unsigned*)slot) atomicMax(slot, __float_as_uint(m));
+}
+#endif
+
 // ---------------------------------------------------------------------------------------
 // kernels (launchers)
 // ---------------------------------------------------------------------------------------
@@ -166,6 +194,10 @@ int prepare_wino(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
 bool wino_applicable(const ConvLayer& L, const Tensor& in);
 int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
                      bool need_full);
+// Split arithmetic of conv_wsplit.hip / conv_dsplit.hip: 0 = bf16 x 3 pieces / 6 products (exact split),
+// 1 = fp16 x 2 pieces / 3 products (RNE split at 2^-24, exact power-of-two scaling from Tensor::amax).
+// KOCR_SPLIT=bf16|f16 selects; see DESIGN.md for the default.
+int kocr_split_mode();
 // conv_wsplit.hip
 int prepare_wsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
 bool wsplit_applicable(const ConvLayer& L, const Tensor& in);
@@ -182,6 +214,9 @@ int launch_maxpool2x2(kocr_ctx* ctx, const Tensor& in, const Tensor& out, int ro
 int launch_maxpool3x3s1(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
 int launch_resize_bilinear(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
 int launch_copy_channels(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
+// max |x| of a tensor into a slot (atomicMax; the slot is NOT cleared), and slot-to-slot propagation
+int launch_absmax(kocr_ctx* ctx, const Tensor& t, unsigned* slot);
+int launch_amax_copy(kocr_ctx* ctx, const unsigned* from, unsigned* to);
 // conv_cls.6 + conv_cls.8 of the CRAFT head in one pass (16 -> 16 ReLU -> 2), heat-map written densely
 int launch_head_tail(kocr_ctx* ctx, const ConvLayer& L6, const ConvLayer& L8, const Tensor& in, float* d_heat);
 

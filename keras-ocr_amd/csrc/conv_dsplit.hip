@@ -15,8 +15,12 @@
 // LDS: As[buf][piece][M-tile][k half][32 rows x 8 ch] bf16, 24 KB * WM per buffer, the same
 // conflict-free layout as conv_wsplit.hip.  Weights: [16-ch group][tap][32-cout tile][piece][lane][8].
 #include "common.h"
+#include <cmath>
+#include <algorithm>
 
 typedef short bf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
@@ -36,6 +40,9 @@ struct DsParams {
   int nsteps;  // KH * KW * Cin / 16
   int Mtotal;
   int total_tiles;
+  const unsigned* amax_in;  // HALF kernels: tracked max |input| (Tensor::amax), never null there
+  int w_exp;                // HALF kernels: the weights are stored multiplied by 2^w_exp
+  unsigned* amax_out;  // Tensor::amax of the output or nullptr
 };
 
 __device__ __forceinline__ int ds_xcd_remap(int bid, int nwg) {
@@ -59,14 +66,34 @@ __device__ __forceinline__ void ds_split4(const v4f v, u2v& h, u2v& m, u2v& l) {
   l = u2v{__builtin_amdgcn_perm(ul[1], ul[0], 0x07060302u), __builtin_amdgcn_perm(ul[3], ul[2], 0x07060302u)};
 }
 
-template <int WM, int WN>
+// fp16 mode: see conv_wsplit.hip (ws_split4_h / ws_scale_exp); here |x 2^e| < 2^14 with e = 13 - E
+__device__ __forceinline__ void ds_split4_h(const v4f v, u2v& h, u2v& l) {
+  _Float16 hh[4], ll[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    hh[c] = (_Float16)v[c];
+    ll[c] = (_Float16)(v[c] - (float)hh[c]);
+  }
+  h = u2v{__builtin_bit_cast(unsigned, hf2{hh[0], hh[1]}), __builtin_bit_cast(unsigned, hf2{hh[2], hh[3]})};
+  l = u2v{__builtin_bit_cast(unsigned, hf2{ll[0], ll[1]}), __builtin_bit_cast(unsigned, hf2{ll[2], ll[3]})};
+}
+__device__ __forceinline__ int ds_scale_exp(const unsigned* amax) {
+  const unsigned b = *amax;
+  if (b == 0) return 0;
+  int e = 13 - ((int)(b >> 23) - 127);
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+__device__ __forceinline__ float ds_pow2(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
+
+template <int WM, int WN, int HALF>
 __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
+  constexpr int NP = HALF ? 2 : 3;            // operand pieces
   constexpr int NMT = 8 * WM;                 // 32-pixel M-tiles per block tile
   constexpr int TILE_PX = 256 * WM;
   constexpr int IPT = 4 * WM;                 // gather items (pixel, channel quad) per producer thread
   constexpr int KH_STRIDE = 256;              // ushorts: 32 rows x 8 channels
   constexpr int PLANE = NMT * 2 * KH_STRIDE;  // one piece plane
-  constexpr int BUF = 3 * PLANE;              // one K-step: 24 KB * WM
+  constexpr int BUF = NP * PLANE;             // one K-step: 24 KB * WM (bf16x3) / 16 KB * WM (fp16x2)
   extern __shared__ __attribute__((aligned(16))) unsigned short As[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keep it in an SGPR
@@ -84,6 +111,8 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
     const int ptid = tid - 256;
     const int quad = ptid & 3;
     constexpr unsigned OOB = 0x80000000u;
+    const float in_scale = HALF ? ds_pow2(ds_scale_exp(p.amax_in)) : 1.f;  // exact power of two
+    (void)in_scale;
     int ldst[IPT];
 #pragma unroll
     for (int it = 0; it < IPT; ++it) {
@@ -139,12 +168,19 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
       unsigned short* base = As + buf * BUF;
 #pragma unroll
       for (int it = 0; it < IPT; ++it) {
-        u2v h, m, l;
-        ds_split4(raw[it], h, m, l);
         unsigned short* dst = base + ldst[it];
-        *reinterpret_cast<u2v*>(dst) = h;
-        *reinterpret_cast<u2v*>(dst + PLANE) = m;
-        *reinterpret_cast<u2v*>(dst + 2 * PLANE) = l;
+        if constexpr (HALF) {
+          u2v h, l;
+          ds_split4_h(raw[it] * in_scale, h, l);
+          *reinterpret_cast<u2v*>(dst) = h;
+          *reinterpret_cast<u2v*>(dst + PLANE) = l;
+        } else {
+          u2v h, m, l;
+          ds_split4(raw[it], h, m, l);
+          *reinterpret_cast<u2v*>(dst) = h;
+          *reinterpret_cast<u2v*>(dst + PLANE) = m;
+          *reinterpret_cast<u2v*>(dst + 2 * PLANE) = l;
+        }
       }
     };
     const int my_tiles = (total - (int)blockIdx.x + G - 1) / G;
@@ -174,42 +210,55 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
   // ==================================================================================================
   const int wn = (WN == 4) ? wave : (wave % WN), wm = (WM == 1) ? 0 : (wave / WN);
   const int ntiles32 = p.Cout_pad >> 5;
-  const size_t w_step = (size_t)ntiles32 * 3 * 64 * 8;  // ushorts per K-step
-  auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * WN + wn) * 3 * 64 + lane) * 8; };
+  const size_t w_step = (size_t)ntiles32 * NP * 64 * 8;  // ushorts per K-step
+  auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * WN + wn) * NP * 64 + lane) * 8; };
 
-  bf8 bw[3], bwn[3];
+  bf8 bw[NP], bwn[NP];
   f16v acc[4][2];  // [M-tile pair][M-tile in pair]
   const int a_lane = (wm * 8 * 2 + l5) * KH_STRIDE + ((l31 * 8) ^ (l5 * 32));
-  auto load_a = [&](bf8 (&a)[2][3], const unsigned short* bufp, int g) __attribute__((always_inline)) {
+  auto load_a = [&](bf8 (&a)[2][NP], const unsigned short* bufp, int g) __attribute__((always_inline)) {
     const unsigned short* base = bufp + a_lane + g * 4 * KH_STRIDE;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) a[m][s] = *reinterpret_cast<const bf8*>(base + s * PLANE + m * 2 * KH_STRIDE);
+      for (int s = 0; s < NP; ++s) a[m][s] = *reinterpret_cast<const bf8*>(base + s * PLANE + m * 2 * KH_STRIDE);
   };
-  auto mfma6 = [&](const bf8 (&a)[2][3], int g) __attribute__((always_inline)) {
-    const bf8 b0 = bw[0], b1 = bw[1], b2 = bw[2];
+  auto mfma6 = [&](const bf8 (&a)[2][NP], int g) __attribute__((always_inline)) {
+    if constexpr (HALF) {
+      const hf8 b0 = __builtin_bit_cast(hf8, bw[0]), b1 = __builtin_bit_cast(hf8, bw[1]);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b0, acc[g][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m)
+        acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, a[m][1]), b0, acc[g][m], 0, 0, 0);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b2, acc[g][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m)
+        acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, a[m][0]), b1, acc[g][m], 0, 0, 0);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b1, acc[g][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m)
+        acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, a[m][0]), b0, acc[g][m], 0, 0, 0);
+    } else {
+      const bf8 b0 = bw[0], b1 = bw[1], b2 = bw[NP - 1];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b0, acc[g][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][NP - 1], b0, acc[g][m], 0, 0, 0);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b1, acc[g][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b2, acc[g][m], 0, 0, 0);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b0, acc[g][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b1, acc[g][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b0, acc[g][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b1, acc[g][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b0, acc[g][m], 0, 0, 0);
+    }
   };
   // One K-step (see conv_wsplit.hip): LDS fetch of the next M-tile pair behind the 12 MFMAs of the
   // current one; the barrier publishing the next K-step sits before the last pair's MFMAs; the next
   // step's weights (3 x 16 B per lane) are fetched at the start of the step.
-  bf8 a0[2][3], a1[2][3];
+  bf8 a0[2][NP], a1[2][NP];
   auto compute_step = [&](const unsigned short* bufp, const unsigned short* bufn,
                           const unsigned short* w_next) __attribute__((always_inline)) {
 #pragma unroll
-    for (int s = 0; s < 3; ++s) bwn[s] = *reinterpret_cast<const bf8*>(w_next + (size_t)s * 64 * 8);
+    for (int s = 0; s < NP; ++s) bwn[s] = *reinterpret_cast<const bf8*>(w_next + (size_t)s * 64 * 8);
     load_a(a1, bufp, 1);
     __builtin_amdgcn_sched_barrier(0);
     mfma6(a0, 0);
@@ -228,7 +277,7 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
     mfma6(a1, 3);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 3; ++s) bw[s] = bwn[s];
+    for (int s = 0; s < NP; ++s) bw[s] = bwn[s];
   };
 
   int gs = 0;
@@ -236,7 +285,7 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
     const int tile0 = ds_xcd_remap(blockIdx.x, total);
     const unsigned short* w0 = w_tile(tile0 % nblk_n);
 #pragma unroll
-    for (int s = 0; s < 3; ++s) bw[s] = *reinterpret_cast<const bf8*>(w0 + (size_t)s * 64 * 8);
+    for (int s = 0; s < NP; ++s) bw[s] = *reinterpret_cast<const bf8*>(w0 + (size_t)s * 64 * 8);
   }
   __syncthreads();  // global step 0 is in LDS
   load_a(a0, As, 0);
@@ -261,7 +310,8 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
     {
       const int n = (nt * WN + wn) * 32 + l31;
       const int nc = n < p.Cout ? n : p.Cout - 1;
-      const float pa = p.pre_a[nc], pb = p.pre_b[nc];
+      const float unscale = HALF ? ds_pow2(-(ds_scale_exp(p.amax_in) + p.w_exp)) : 1.f;  // exact
+      const float pa = p.pre_a[nc] * unscale, pb = p.pre_b[nc];
       const bool has_post = p.post_a != nullptr;
       const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
 #pragma unroll
@@ -275,6 +325,16 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
             if (has_post) o = o * qa + qb;
             acc[g][m][r] = o;
           }
+      if (p.amax_out) {
+        float mx = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[g][m][r]));
+        kocr_amax_update(p.amax_out, n < p.Cout ? mx : 0.f);
+      }
       const int ocs4 = p.out_cs * 4;
       const long rem = ((long)p.Mtotal - pm0) * ocs4;  // stores past the end of the tensor are dropped
       const unsigned long long bb = (unsigned long long)(p.out + (pm0 * p.out_cs + p.out_co));
@@ -337,6 +397,36 @@ int prepare_dsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) 
   KOCR_TRY(ctx->dev_alloc(&d, u.size() * sizeof(unsigned short)));
   KOCR_HIP(ctx, hipMemcpy(d, u.data(), u.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   L.d_ds = (unsigned short*)d;
+
+  // fp16x2 copy: w * 2^wexp split by round-to-nearest into two fp16, |w 2^wexp| < 2^13
+  float wmax = 0.f;
+  const size_t nw = (size_t)Cout * Cin * ntaps;
+  for (size_t i = 0; i < nw; ++i) wmax = std::max(wmax, std::fabs(w[i]));
+  int wexp = 0;
+  if (wmax > 0.f && std::isfinite(wmax)) {
+    int E;
+    std::frexp(wmax, &E);
+    wexp = 13 - E;
+  }
+  const float wscale = std::ldexp(1.f, wexp);
+  std::vector<unsigned short> v((size_t)(Cin / 16) * ntaps * nt32 * 2 * 64 * 8, 0);
+  for (int c = 0; c < Cin; ++c)
+    for (int tap = 0; tap < ntaps; ++tap)
+      for (int o = 0; o < Cout; ++o) {
+        const float g = (w_is_oihw ? w[((size_t)o * Cin + c) * ntaps + tap] : w[((size_t)tap * Cin + c) * Cout + o]) * wscale;
+        const int k = c % 16, lane = (k >> 3) * 32 + (o & 31), j = k & 7;
+        const size_t step = (size_t)(c / 16) * ntaps + tap;
+        const _Float16 h = (_Float16)g, l = (_Float16)(g - (float)h);
+        unsigned short hb, lb;
+        memcpy(&hb, &h, 2);
+        memcpy(&lb, &l, 2);
+        v[(((step * nt32 + o / 32) * 2 + 0) * 64 + lane) * 8 + j] = hb;
+        v[(((step * nt32 + o / 32) * 2 + 1) * 64 + lane) * 8 + j] = lb;
+      }
+  L.ds_wexp = wexp;
+  KOCR_TRY(ctx->dev_alloc(&d, v.size() * sizeof(unsigned short)));
+  KOCR_HIP(ctx, hipMemcpy(d, v.data(), v.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  L.d_ds16 = (unsigned short*)d;
   return KOCR_OK;
 }
 
@@ -347,13 +437,13 @@ bool dsplit_applicable(const ConvLayer& L, const Tensor& in) {
          (size_t)in.pixels() * in.cs < ((size_t)1 << 40);
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int HALF>
 static int ds_launch(kocr_ctx* ctx, DsParams& p, size_t M) {
-  constexpr int LDS_BYTES = 2 * 3 * (8 * WM) * 2 * 256 * 2;  // 48 KB (WM = 1) / 96 KB (WM = 2)
+  constexpr int LDS_BYTES = 2 * (HALF ? 2 : 3) * (8 * WM) * 2 * 256 * 2;  // 48 / 96 KB (bf16x3), 32 / 64 KB (fp16x2)
   static bool attr_done[64] = {};  // per device: one process may hold contexts on several GPUs
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
-    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_ds_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_ds_kernel<WM, WN, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done[dev] = true;
   }
   static int n_cus[64] = {};
@@ -366,7 +456,7 @@ static int ds_launch(kocr_ctx* ctx, DsParams& p, size_t M) {
   const size_t mtiles = (M + 256 * WM - 1) / (256 * WM);
   p.total_tiles = (int)(mtiles * (p.Cout_pad / (32 * WN)));
   const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
-  hipLaunchKernelGGL((conv_ds_kernel<WM, WN>), dim3(grid), dim3(512), LDS_BYTES, ctx->stream, p);
+  hipLaunchKernelGGL((conv_ds_kernel<WM, WN, HALF>), dim3(grid), dim3(512), LDS_BYTES, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }
@@ -397,16 +487,32 @@ int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   p.nsteps = L.KH * L.KW * (L.Cin / 16);
   p.Mtotal = (int)M;
   p.total_tiles = 0;
+  p.amax_out = out.amax;
+  const bool half = kocr_split_mode() == 1 && L.d_ds16;
+  p.amax_in = nullptr;
+  p.w_exp = 0;
+  if (half) {
+    const unsigned* slot = in.amax;
+    if (!slot) {
+      unsigned* tmp = ctx->amax_slot();
+      if (!tmp) KOCR_FAIL(ctx, KOCR_ECAPACITY, "conv " + L.name + ": out of max-|x| slots");
+      KOCR_TRY(launch_absmax(ctx, in, tmp));
+      slot = tmp;
+    }
+    p.amax_in = slot;
+    p.w_exp = L.ds_wexp;
+    p.wgt = L.d_ds16;
+  }
   const int wcls = L.Cout > 64 ? 128 : 64;
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_ds_%dx%d:%s", wcls == 128 ? 256 : 512, wcls, L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_d%s_%dx%d:%s", half ? "h" : "s", wcls == 128 ? 256 : 512, wcls, L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_ds_%dx%d", wcls == 128 ? 256 : 512, wcls);
+    snprintf(nm, sizeof nm, "conv_d%s_%dx%d", half ? "h" : "s", wcls == 128 ? 256 : 512, wcls);
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   ProfScope ps(ctx, nm, flops, bytes);
-  if (wcls == 128) return ds_launch<1, 4>(ctx, p, M);
-  return ds_launch<2, 2>(ctx, p, M);
+  if (half) return wcls == 128 ? ds_launch<1, 4, 1>(ctx, p, M) : ds_launch<2, 2, 1>(ctx, p, M);
+  return wcls == 128 ? ds_launch<1, 4, 0>(ctx, p, M) : ds_launch<2, 2, 0>(ctx, p, M);
 }

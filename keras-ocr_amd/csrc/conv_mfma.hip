@@ -54,6 +54,8 @@ struct ConvParams {
   float* pool_out;
   int pool_cs, pool_co, write_full, tiles_per_row;
   int stagger;  // s_sleep units per stagger step (0 = off)
+  unsigned* amax_out;   // Tensor::amax slots of the output / pooled output, or nullptr
+  unsigned* amax_pool;
   int tap_inner, ntaps;  // K order: k = ((c/16)*ntaps + tap)*16 + c%16 (vector-gather layers)
 };
 
@@ -373,7 +375,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WTN + j * 32 + lr;
     const bool live = n < p.Cout;
-    if (POOL && !live) continue;
     const int nc = live ? n : p.Cout - 1;
     const float pa = p.pre_a[nc], pb = p.pre_b[nc];
     const bool has_post = p.post_a != nullptr;
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
             if (p.relu) v = fmaxf(v, 0.f);
             if (has_post) v = v * qa + qb;
             best = fmaxf(best, v);
-            if (p.write_full) {
+            if (p.write_full && live) {
               const long pix = pm0 + (long)(e >> 1) * p.W + 2 * (ml >> 2) + (e & 1);
               p.out[pix * p.out_cs + p.out_co + n] = v;
             }
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
           // pooled pixel: (n_img, y0t/2, x0t/2 + q)
           const long nimg = pm0 / ((long)p.H * p.W);
           const long pp = (nimg * (p.H >> 1) + (y0t >> 1)) * (p.W >> 1) + (x0t >> 1) + (ml >> 2);
-          p.pool_out[pp * p.pool_cs + p.pool_co + n] = best;
+          if (live) p.pool_out[pp * p.pool_cs + p.pool_co + n] = best;
         }
       } else {
         // in place; the stores follow below, back to back
@@ -412,6 +413,28 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 2) void conv_mfm
           acc[i][j][r] = v;
         }
       }
+    }
+    if (p.amax_out || p.amax_pool) {  // accumulators hold the finished outputs (non-POOL) / pre-pool values are bounded by them
+      float mx = 0.f;
+      if constexpr (!POOL) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[i][j][r]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[i][j][r] * pa + pb;
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (has_post) v = v * qa + qb;
+            mx = fmaxf(mx, fabsf(v));
+          }
+      }
+      mx = live ? mx : 0.f;
+      if (p.amax_out) kocr_amax_update(p.amax_out, mx);
+      if (p.amax_pool) kocr_amax_update(p.amax_pool, mx);
     }
     if constexpr (!POOL) {
       // Raw buffer stores: one per-lane byte offset, the per-register pixel offset in an SGPR, pixels past
@@ -588,6 +611,8 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
   p.nchunks = (L.Kreal + bk - 1) / bk;  // weight rows are zero padded up to Kpad (multiple of 32)
   p.pool_out = nullptr;
   p.tap_inner = L.tap_inner ? 1 : 0;
+  p.amax_out = out.amax;
+  p.amax_pool = pool ? pool->amax : nullptr;
   p.ntaps = L.KH * L.KW;
   {
     static const int stg = getenv("KOCR_CONV_STAGGER") ? atoi(getenv("KOCR_CONV_STAGGER")) : 0;

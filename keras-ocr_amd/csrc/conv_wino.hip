@@ -45,6 +45,8 @@ struct WinoParams {
   // fused 2x2 max-pool (POOL kernel): tile = 2 image rows x 64 columns
   float* pool_out;
   int pool_cs, pool_co, write_full, tiles_per_row;
+  unsigned* amax_out;   // Tensor::amax slots of the output / pooled output, or nullptr
+  unsigned* amax_pool;
 };
 
 namespace {
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
 
   // ---- epilogue: 16x16x4 C/D map: col = lane&15, row = (lane>>4)*4 + reg --------------------------
   const int n = n0 + wc * 16 + l15;
+  float amx = 0.f;  // max |output| of this lane (Tensor::amax)
   if (n < p.Cout) {
     const float pa = p.pre_a[n], pb = p.pre_b[n];
     const bool has_post = p.post_a != nullptr;
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
           float a0, a1, b0, b1;
           finish(acc[0][mh][r], acc[1][mh][r], acc[2][mh][r], acc[3][mh][r], a0, a1);                          // row y
           finish(acc[0][mh + MR][r], acc[1][mh + MR][r], acc[2][mh + MR][r], acc[3][mh + MR][r], b0, b1);      // row y+1
+          amx = fmaxf(amx, fmaxf(fmaxf(fabsf(a0), fabsf(a1)), fmaxf(fabsf(b0), fabsf(b1))));
           if (p.write_full) {
             float* o = p.out + ((pm0 + 2 * pp) * p.out_cs + p.out_co + n);
             o[0] = a0;
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
           finish(acc[0][m][r], acc[1][m][r], acc[2][m][r], acc[3][m][r], o0, o1);
           acc[0][m][r] = o0;
           acc[1][m][r] = o1;
+          amx = fmaxf(amx, fmaxf(fabsf(o0), fabsf(o1)));
         }
       const int ocs4 = p.out_cs * 4;
       const long rem = ((long)p.Mtotal - pm0) * ocs4;
@@ -285,6 +290,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 4 : 2) void conv_wino_kernel(W
         }
     }
   }
+  // all lanes take part in the wave reduction (padded couts contribute 0)
+  if (p.amax_out) kocr_amax_update(p.amax_out, amx);
+  if (p.amax_pool) kocr_amax_update(p.amax_pool, amx);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -347,6 +355,8 @@ int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
   p.Mtotal = (int)M;
   p.pool_out = nullptr;
   p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
+  p.amax_out = out.amax;
+  p.amax_pool = (fuse && pool) ? pool->amax : nullptr;
   if (fuse) {
     p.pool_out = pool->p;
     p.pool_cs = pool->cs;

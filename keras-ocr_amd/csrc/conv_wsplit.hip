@@ -29,8 +29,12 @@
 // per-point prefetch; weights never touch LDS.  Requires W even.  POOL variant: tile = 2 image rows x
 // 64*WM columns with the 2x2 max taken in-lane.  Details at the kernel below; measurements in DESIGN.md.
 #include "common.h"
+#include <cmath>
+#include <algorithm>
 
 typedef short bf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
@@ -51,6 +55,10 @@ struct WsParams {
   float* pool_out;
   int pool_cs, pool_co, write_full, tiles_per_row;
   int total_tiles;
+  const unsigned* amax_in;  // HALF kernels: tracked max |input| (Tensor::amax), never null there
+  int w_exp;                // HALF kernels: the weights are stored multiplied by 2^w_exp
+  unsigned* amax_out;   // Tensor::amax of the output (and of the pooled output), or nullptr
+  unsigned* amax_pool;
   int dbg;  // developer timing experiments (wrong results): 1 = skip the epilogue
 };
 
@@ -84,6 +92,28 @@ struct WsTile {
   int nt;        // output-channel tile
 };
 
+// fp16 mode (HALF = 1): 2-way RNE fp16 split of four values, v ~ h + l with |v - h - l| <= 2^-24 |v| while l
+// is a normal fp16 (the caller scales the tensor by an exact power of two so that max |v| ~ 2^14)
+__device__ __forceinline__ void ws_split4_h(const v4f v, u2v& h, u2v& l) {
+  _Float16 hh[4], ll[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    hh[c] = (_Float16)v[c];
+    ll[c] = (_Float16)(v[c] - (float)hh[c]);
+  }
+  h = u2v{__builtin_bit_cast(unsigned, hf2{hh[0], hh[1]}), __builtin_bit_cast(unsigned, hf2{hh[2], hh[3]})};
+  l = u2v{__builtin_bit_cast(unsigned, hf2{ll[0], ll[1]}), __builtin_bit_cast(unsigned, hf2{ll[2], ll[3]})};
+}
+// exponent e of the exact input scale 2^e: the Winograd-transformed inputs satisfy |V| <= 2 max|x| < 2^(E+2)
+// (E = exponent of the tracked max), so |V 2^e| < 2^14 with e = 12 - E.  amax == 0 -> e = 0.
+__device__ __forceinline__ int ws_scale_exp(const unsigned* amax) {
+  const unsigned b = *amax;
+  if (b == 0) return 0;
+  int e = 12 - ((int)(b >> 23) - 127);
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+__device__ __forceinline__ float ws_pow2(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
+
 template <int POOL, int WM, int WN>
 __device__ __forceinline__ WsTile ws_tile(const WsParams& p, int L, int total, int nblk_n) {
   WsTile t;
@@ -111,13 +141,14 @@ __device__ __forceinline__ WsTile ws_tile(const WsParams& p, int L, int total, i
 // already in LDS when the consumers finish the previous tile's epilogue.
 //   WM x WN = 4 consumer waves: wave (wm, wn) owns M-tiles {2wm, 2wm+1} (64 pairs) x 32 couts.
 //   <1,4>: tile 128 px x 128 couts      <2,2>: tile 256 px x 64 couts (weights shared by two waves)
-template <int POOL, int WM, int WN>
+template <int POOL, int WM, int WN, int HALF>
 __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
+  constexpr int NP = HALF ? 2 : 3;                   // operand pieces: 2 x fp16 (3 products) or 3 x bf16 (6 products)
   constexpr int NMT = 2 * WM;                        // 32-pair M-tiles per block tile
   constexpr int IPT = WM;                            // gather items (pair, channel quad) per producer thread
   constexpr int KH_STRIDE = 256;                     // ushorts: 32 rows x 8 channels
   constexpr int PLANE = NMT * 2 * KH_STRIDE;         // one (xi, piece) plane
-  constexpr int BUF = 12 * PLANE;                    // one K-step: 24 KB * WM
+  constexpr int BUF = 4 * NP * PLANE;                // one K-step: 24 KB * WM (bf16x3) / 16 KB * WM (fp16x2)
   // As[buf][xi][piece][M-tile][k half][32 rows x 8 ch bf16 = 512 B]: a 32x32x16 A fetch reads 2 x 512
   // contiguous bytes (16 B per lane, conflict-free); the rows of k half 1 are XOR-ed with 64 B so the two
   // k halves a 16-lane ds_write_b64 group touches fall into different halves of the 32 store banks.
@@ -137,6 +168,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
     const int ptid = tid - 256;
     const int quad = ptid & 3;
     constexpr unsigned OOB = 0x80000000u;
+    const float in_scale = HALF ? ws_pow2(ws_scale_exp(p.amax_in)) : 1.f;  // exact power of two
+    (void)in_scale;
     int ldst[IPT];
 #pragma unroll
     for (int it = 0; it < IPT; ++it) {
@@ -212,12 +245,19 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
         const v4f V[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi) {
-          u2v h, m, l;
-          ws_split4(V[xi], h, m, l);
-          unsigned short* dst = base + xi * 3 * PLANE + ldst[it];
-          *reinterpret_cast<u2v*>(dst) = h;
-          *reinterpret_cast<u2v*>(dst + PLANE) = m;
-          *reinterpret_cast<u2v*>(dst + 2 * PLANE) = l;
+          unsigned short* dst = base + xi * NP * PLANE + ldst[it];
+          if constexpr (HALF) {
+            u2v h, l;
+            ws_split4_h(V[xi] * in_scale, h, l);
+            *reinterpret_cast<u2v*>(dst) = h;
+            *reinterpret_cast<u2v*>(dst + PLANE) = l;
+          } else {
+            u2v h, m, l;
+            ws_split4(V[xi], h, m, l);
+            *reinterpret_cast<u2v*>(dst) = h;
+            *reinterpret_cast<u2v*>(dst + PLANE) = m;
+            *reinterpret_cast<u2v*>(dst + 2 * PLANE) = l;
+          }
         }
       }
     };
@@ -251,47 +291,60 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
   // ==================================================================================================
   const int wn = (WN == 4) ? wave : (wave % WN), wm = (WM == 1) ? 0 : (wave / WN);
   const int ntiles32 = p.Cout_pad >> 5;
-  const size_t w_step = (size_t)ntiles32 * 12 * 64 * 8;  // ushorts per K-step
+  const size_t w_step = (size_t)ntiles32 * 4 * NP * 64 * 8;  // ushorts per K-step
   // weights: [step][ntile32][xi][piece][lane][8 bf16]; 16 B per lane and (xi, piece)
-  auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * WN + wn) * 12 * 64 + lane) * 8; };
+  auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * WN + wn) * 4 * NP * 64 + lane) * 8; };
 
-  bf8 bw[4][3];
+  bf8 bw[4][NP];
   f16v acc[4][2];  // [xi][own M-tile]
   const int a_lane = (wm * 2 * 2 + l5) * KH_STRIDE + ((l31 * 8) ^ (l5 * 32));
-  auto load_a = [&](bf8 (&a)[2][3], const unsigned short* bufp, int xi) __attribute__((always_inline)) {
-    const unsigned short* base = bufp + xi * 3 * PLANE + a_lane;
+  auto load_a = [&](bf8 (&a)[2][NP], const unsigned short* bufp, int xi) __attribute__((always_inline)) {
+    const unsigned short* base = bufp + xi * NP * PLANE + a_lane;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) a[m][s] = *reinterpret_cast<const bf8*>(base + s * PLANE + m * 2 * KH_STRIDE);
+      for (int s = 0; s < NP; ++s) a[m][s] = *reinterpret_cast<const bf8*>(base + s * PLANE + m * 2 * KH_STRIDE);
   };
-  auto mfma6 = [&](const bf8 (&a)[2][3], int xi) __attribute__((always_inline)) {
-    const bf8 b0 = bw[xi][0], b1 = bw[xi][1], b2 = bw[xi][2];
+  auto mfma6 = [&](const bf8 (&a)[2][NP], int xi) __attribute__((always_inline)) {
     // smallest terms first; the two M-tiles alternate so consecutive MFMAs are independent
+    if constexpr (HALF) {
+      const hf8 b0 = __builtin_bit_cast(hf8, bw[xi][0]), b1 = __builtin_bit_cast(hf8, bw[xi][1]);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b0, acc[xi][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m)
+        acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, a[m][1]), b0, acc[xi][m], 0, 0, 0);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b2, acc[xi][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m)
+        acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, a[m][0]), b1, acc[xi][m], 0, 0, 0);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b1, acc[xi][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m)
+        acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, a[m][0]), b0, acc[xi][m], 0, 0, 0);
+    } else {
+      const bf8 b0 = bw[xi][0], b1 = bw[xi][1], b2 = bw[xi][NP - 1];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b0, acc[xi][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][NP - 1], b0, acc[xi][m], 0, 0, 0);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b1, acc[xi][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b2, acc[xi][m], 0, 0, 0);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b0, acc[xi][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b1, acc[xi][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b0, acc[xi][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b1, acc[xi][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b0, acc[xi][m], 0, 0, 0);
+    }
   };
   // One K-step.  A operands of point xi+1 are fetched from LDS while the 12 MFMAs of point xi run; a
   // point's weights are re-fetched (next K-step) as soon as its MFMAs are issued.  The block barrier
   // that publishes the NEXT K-step sits before the last point's MFMAs (all LDS reads of this step have
   // landed by then), so the next step's first operands are fetched behind those 12 MFMAs instead of
   // exposing the LDS latency after the barrier.  a0 carries point 0 of the current step on entry.
-  bf8 a0[2][3], a1[2][3];
+  bf8 a0[2][NP], a1[2][NP];
   auto compute_step = [&](const unsigned short* bufp, const unsigned short* bufn,
                           const unsigned short* w_next) __attribute__((always_inline)) {
     auto load_b = [&](int xi) __attribute__((always_inline)) {
 #pragma unroll
-      for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w_next + (size_t)(xi * 3 + s) * 64 * 8);
+      for (int s = 0; s < NP; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w_next + (size_t)(xi * NP + s) * 64 * 8);
     };
     // the fences pin the issue order: LDS fetch of the next point, 12 MFMAs, weight fetch
     load_a(a1, bufp, 1);
@@ -326,7 +379,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
 #pragma unroll
     for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w0 + (size_t)(xi * 3 + s) * 64 * 8);
+      for (int s = 0; s < NP; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w0 + (size_t)(xi * NP + s) * 64 * 8);
   }
   __syncthreads();  // global step 0 is in LDS
   load_a(a0, As, 0);
@@ -357,7 +410,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
     {
       const int n = (t.nt * WN + wn) * 32 + l31;
       const int nc = n < p.Cout ? n : p.Cout - 1;
-      const float pa = p.pre_a[nc], pb = p.pre_b[nc];
+      // HALF: the accumulators carry the exact factor 2^(input scale + weight scale); undo it in pre_a
+      const float unscale = HALF ? ws_pow2(-(ws_scale_exp(p.amax_in) + p.w_exp)) : 1.f;
+      const float pa = p.pre_a[nc] * unscale, pb = p.pre_b[nc];
       const bool has_post = p.post_a != nullptr;
       const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
       auto finish = [&](float m0, float m1, float m2, float m3, float& o0, float& o1) {
@@ -397,6 +452,16 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
             acc[1][m][r + 8] = b1;
             acc[2][m][r] = fmaxf(fmaxf(a0, a1), fmaxf(b0, b1));
           }
+        if (p.amax_out || p.amax_pool) {
+          float mx = 0.f;
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(fabsf(acc[0][m][r]), fabsf(acc[1][m][r])));
+          mx = live ? mx : 0.f;
+          if (p.amax_out) kocr_amax_update(p.amax_out, mx);
+          if (p.amax_pool) kocr_amax_update(p.amax_pool, mx);
+        }
         const long nimg = t.pm0 / ((long)p.H * p.W);
         const long pp0 = (nimg * (p.H >> 1) + (t.y0t >> 1)) * (p.W >> 1) + (t.x0t >> 1);
         if (p.write_full) {
@@ -432,6 +497,14 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
             acc[0][m][r] = o0;
             acc[1][m][r] = o1;
           }
+        if (p.amax_out) {
+          float mx = 0.f;
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(fabsf(acc[0][m][r]), fabsf(acc[1][m][r])));
+          kocr_amax_update(p.amax_out, live ? mx : 0.f);
+        }
         // bytes from the tile's first pixel to the end of the tensor: stores past it are dropped
         const long rem = ((long)p.Mtotal - t.pm0) * ocs4;
         const __amdgpu_buffer_rsrc_t ro =
@@ -495,7 +568,60 @@ int prepare_wsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) 
   KOCR_TRY(ctx->dev_alloc(&d, u.size() * sizeof(unsigned short)));
   KOCR_HIP(ctx, hipMemcpy(d, u.data(), u.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   L.d_ws = (unsigned short*)d;
+
+  // fp16x2 copy: U * 2^wexp split by round-to-nearest into two fp16, |U 2^wexp| < 2^13
+  float umax = 0.f;
+  for (int c = 0; c < Cin; ++c)
+    for (int ky = 0; ky < 3; ++ky)
+      for (int o = 0; o < Cout; ++o) {
+        float g[3];
+        for (int kx = 0; kx < 3; ++kx)
+          g[kx] = w_is_oihw ? w[(((size_t)o * Cin + c) * 3 + ky) * 3 + kx] : w[(((size_t)ky * 3 + kx) * Cin + c) * Cout + o];
+        const float U[4] = {g[0], 0.5f * ((g[0] + g[1]) + g[2]), 0.5f * ((g[0] - g[1]) + g[2]), g[2]};
+        for (int xi = 0; xi < 4; ++xi) umax = std::max(umax, std::fabs(U[xi]));
+      }
+  int wexp = 0;
+  if (umax > 0.f && std::isfinite(umax)) {
+    int E;
+    std::frexp(umax, &E);  // umax = f * 2^E, f in [0.5, 1)
+    wexp = 13 - E;
+  }
+  const float wscale = std::ldexp(1.f, wexp);
+  std::vector<unsigned short> v((size_t)(Cin / 16) * 3 * nt32 * 8 * 64 * 8, 0);
+  for (int c = 0; c < Cin; ++c)
+    for (int ky = 0; ky < 3; ++ky)
+      for (int o = 0; o < Cout; ++o) {
+        float g[3];
+        for (int kx = 0; kx < 3; ++kx)
+          g[kx] = w_is_oihw ? w[(((size_t)o * Cin + c) * 3 + ky) * 3 + kx] : w[(((size_t)ky * 3 + kx) * Cin + c) * Cout + o];
+        const float U[4] = {g[0], 0.5f * ((g[0] + g[1]) + g[2]), 0.5f * ((g[0] - g[1]) + g[2]), g[2]};
+        const int k = c % 16, lane = (k >> 3) * 32 + (o & 31), j = k & 7;
+        const size_t step = (size_t)(c / 16) * 3 + ky;
+        for (int xi = 0; xi < 4; ++xi) {
+          const float x = U[xi] * wscale;
+          const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
+          unsigned short hb, lb;
+          memcpy(&hb, &h, 2);
+          memcpy(&lb, &l, 2);
+          v[((((step * nt32 + o / 32) * 4 + xi) * 2 + 0) * 64 + lane) * 8 + j] = hb;
+          v[((((step * nt32 + o / 32) * 4 + xi) * 2 + 1) * 64 + lane) * 8 + j] = lb;
+        }
+      }
+  L.ws_wexp = wexp;
+  KOCR_TRY(ctx->dev_alloc(&d, v.size() * sizeof(unsigned short)));
+  KOCR_HIP(ctx, hipMemcpy(d, v.data(), v.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  L.d_ws16 = (unsigned short*)d;
   return KOCR_OK;
+}
+
+int kocr_split_mode() {
+  static const int mode = [] {
+    const char* e = getenv("KOCR_SPLIT");
+    if (e && (!strcmp(e, "f16") || !strcmp(e, "fp16"))) return 1;
+    if (e && (!strcmp(e, "bf16"))) return 0;
+    return 0;
+  }();
+  return mode;
 }
 
 bool wsplit_applicable(const ConvLayer& L, const Tensor& in) {
@@ -504,13 +630,13 @@ bool wsplit_applicable(const ConvLayer& L, const Tensor& in) {
          L.Cin % 16 == 0;
 }
 
-template <int POOL, int WM, int WN>
+template <int POOL, int WM, int WN, int HALF>
 static int ws_launch(kocr_ctx* ctx, WsParams& p, size_t M) {
-  constexpr int LDS_BYTES = 2 * 12 * (2 * WM) * 2 * 256 * 2;  // 48 KB (WM = 1) / 96 KB (WM = 2)
+  constexpr int LDS_BYTES = 2 * 4 * (HALF ? 2 : 3) * (2 * WM) * 2 * 256 * 2;  // 48 / 96 KB (bf16x3), 32 / 64 KB (fp16x2)
   static bool attr_done[64] = {};  // per device: one process may hold contexts on several GPUs
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
-    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_ws_kernel<POOL, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_ws_kernel<POOL, WM, WN, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       LDS_BYTES));
     attr_done[dev] = true;
   }
@@ -524,7 +650,7 @@ static int ws_launch(kocr_ctx* ctx, WsParams& p, size_t M) {
   const size_t mtiles = POOL ? M / (size_t)(128 * WM) : (M + 128 * WM - 1) / (128 * WM);
   p.total_tiles = (int)(mtiles * (p.Cout_pad / (32 * WN)));
   const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;  // persistent: one block per CU
-  hipLaunchKernelGGL((conv_ws_kernel<POOL, WM, WN>), dim3(grid), dim3(512), LDS_BYTES, ctx->stream, p);
+  hipLaunchKernelGGL((conv_ws_kernel<POOL, WM, WN, HALF>), dim3(grid), dim3(512), LDS_BYTES, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }
@@ -558,8 +684,26 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   p.pool_out = nullptr;
   p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
   p.total_tiles = 0;
+  p.amax_out = out.amax;
+  p.amax_pool = (fuse && pool) ? pool->amax : nullptr;
   static const int dbg = getenv("KOCR_WS_DBG") ? atoi(getenv("KOCR_WS_DBG")) : 0;
   p.dbg = dbg;
+  // fp16x2 mode needs the input's max |x| on the device: tracked by the producer (Tensor::amax) or reduced here
+  const bool half = kocr_split_mode() == 1 && L.d_ws16;
+  p.amax_in = nullptr;
+  p.w_exp = 0;
+  if (half) {
+    const unsigned* slot = in.amax;
+    if (!slot) {
+      unsigned* tmp = ctx->amax_slot();
+      if (!tmp) KOCR_FAIL(ctx, KOCR_ECAPACITY, "conv " + L.name + ": out of max-|x| slots");
+      KOCR_TRY(launch_absmax(ctx, in, tmp));
+      slot = tmp;
+    }
+    p.amax_in = slot;
+    p.w_exp = L.ws_wexp;
+    p.wgt = L.d_ws16;
+  }
   if (fuse) {
     p.pool_out = pool->p;
     p.pool_cs = pool->cs;
@@ -570,23 +714,35 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_ws_%dx%d%s:%s", wcls == 128 ? 128 : 256, wcls, fuse ? "p" : "", L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_w%s_%dx%d%s:%s", half ? "h" : "s", wcls == 128 ? 128 : 256, wcls, fuse ? "p" : "", L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_ws_%dx%d%s", wcls == 128 ? 128 : 256, wcls, fuse ? "_pool" : "");
+    snprintf(nm, sizeof nm, "conv_w%s_%dx%d%s", half ? "h" : "s", wcls == 128 ? 128 : 256, wcls, fuse ? "_pool" : "");
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   {
     ProfScope ps(ctx, nm, flops, bytes);
-    if (wcls == 128) {
+    if (half) {
+      if (wcls == 128) {
+        if (fuse)
+          KOCR_TRY((ws_launch<1, 1, 4, 1>(ctx, p, M)));
+        else
+          KOCR_TRY((ws_launch<0, 1, 4, 1>(ctx, p, M)));
+      } else {
+        if (fuse)
+          KOCR_TRY((ws_launch<1, 2, 2, 1>(ctx, p, M)));
+        else
+          KOCR_TRY((ws_launch<0, 2, 2, 1>(ctx, p, M)));
+      }
+    } else if (wcls == 128) {
       if (fuse)
-        KOCR_TRY((ws_launch<1, 1, 4>(ctx, p, M)));
+        KOCR_TRY((ws_launch<1, 1, 4, 0>(ctx, p, M)));
       else
-        KOCR_TRY((ws_launch<0, 1, 4>(ctx, p, M)));
+        KOCR_TRY((ws_launch<0, 1, 4, 0>(ctx, p, M)));
     } else {
       if (fuse)
-        KOCR_TRY((ws_launch<1, 2, 2>(ctx, p, M)));
+        KOCR_TRY((ws_launch<1, 2, 2, 0>(ctx, p, M)));
       else
-        KOCR_TRY((ws_launch<0, 2, 2>(ctx, p, M)));
+        KOCR_TRY((ws_launch<0, 2, 2, 0>(ctx, p, M)));
     }
   }
   if (pool && !fuse) return launch_maxpool2x2(ctx, out, *pool);

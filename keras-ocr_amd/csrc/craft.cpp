@@ -183,7 +183,11 @@ int craft_forward(kocr_ctx* ctx, const void* d_img, int dtype, int N, int H, int
   if (N <= 0) return KOCR_OK;
   if (H < 16 || W < 16) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_craft_forward: image smaller than 16x16");
   Dims d(H, W);
+  KOCR_TRY(ctx->amax_begin());
+  // every tensor produced by a convolution / pooling / up-sampling kernel carries a max-|x| slot
+  // (Tensor::amax) so that an fp16-split consumer can pick its exact power-of-two input scale
   auto mk = [&](int h, int w, int c, Tensor* t) -> int {
+    t->amax = ctx->amax_slot();
     t->N = N;
     t->H = h;
     t->W = w;

@@ -170,9 +170,15 @@ int launch_maxpool2x2(kocr_ctx* ctx, const Tensor& in, const Tensor& out, int ro
   p.row_off = row_off;
   const size_t total = out.pixels() * p.C4;
   if (!total) return KOCR_OK;
-  ProfScope ps(ctx, "maxpool2x2", 0, 4.0 * (in.pixels() + out.pixels()) * in.C);
-  hipLaunchKernelGGL(maxpool2x2_kernel, ew_grid(total), dim3(256), 0, ctx->stream, p);
-  KOCR_HIP(ctx, hipGetLastError());
+  {
+    ProfScope ps(ctx, "maxpool2x2", 0, 4.0 * (in.pixels() + out.pixels()) * in.C);
+    hipLaunchKernelGGL(maxpool2x2_kernel, ew_grid(total), dim3(256), 0, ctx->stream, p);
+    KOCR_HIP(ctx, hipGetLastError());
+  }
+  if (out.amax) {  // |out| <= max |in|
+    if (in.amax) return launch_amax_copy(ctx, in.amax, out.amax);
+    return launch_absmax(ctx, out, out.amax);
+  }
   return KOCR_OK;
 }
 
@@ -182,9 +188,15 @@ int launch_maxpool3x3s1(kocr_ctx* ctx, const Tensor& in, const Tensor& out) {
   EwParams p = make_params(in, out);
   const size_t total = out.pixels() * p.C4;
   if (!total) return KOCR_OK;
-  ProfScope ps(ctx, "maxpool3x3s1", 0, 4.0 * (in.pixels() + out.pixels()) * in.C);
-  hipLaunchKernelGGL(maxpool3x3s1_kernel, ew_grid(total), dim3(256), 0, ctx->stream, p);
-  KOCR_HIP(ctx, hipGetLastError());
+  {
+    ProfScope ps(ctx, "maxpool3x3s1", 0, 4.0 * (in.pixels() + out.pixels()) * in.C);
+    hipLaunchKernelGGL(maxpool3x3s1_kernel, ew_grid(total), dim3(256), 0, ctx->stream, p);
+    KOCR_HIP(ctx, hipGetLastError());
+  }
+  if (out.amax) {  // |out| <= max |in|
+    if (in.amax) return launch_amax_copy(ctx, in.amax, out.amax);
+    return launch_absmax(ctx, out, out.amax);
+  }
   return KOCR_OK;
 }
 
@@ -195,9 +207,15 @@ int launch_resize_bilinear(kocr_ctx* ctx, const Tensor& in, const Tensor& out) {
   p.sx = (float)in.W / (float)out.W;
   const size_t total = out.pixels() * p.C4;
   if (!total) return KOCR_OK;
-  ProfScope ps(ctx, "resize_bilinear", 0, 4.0 * (in.pixels() + out.pixels()) * in.C);
-  hipLaunchKernelGGL(resize_bilinear_kernel, ew_grid(total), dim3(256), 0, ctx->stream, p);
-  KOCR_HIP(ctx, hipGetLastError());
+  {
+    ProfScope ps(ctx, "resize_bilinear", 0, 4.0 * (in.pixels() + out.pixels()) * in.C);
+    hipLaunchKernelGGL(resize_bilinear_kernel, ew_grid(total), dim3(256), 0, ctx->stream, p);
+    KOCR_HIP(ctx, hipGetLastError());
+  }
+  if (out.amax) {  // |out| <= max |in|
+    if (in.amax) return launch_amax_copy(ctx, in.amax, out.amax);
+    return launch_absmax(ctx, out, out.amax);
+  }
   return KOCR_OK;
 }
 
@@ -299,6 +317,43 @@ int launch_head_tail(kocr_ctx* ctx, const ConvLayer& L6, const ConvLayer& L8, co
   const double flops = 2.0 * (double)p.P * (16 * 16 + 16 * 2);
   ProfScope ps(ctx, "conv_head_tail", flops, (double)p.P * (64 + 8));
   hipLaunchKernelGGL(head_tail_kernel, ew_grid(p.P), dim3(256), 0, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// max |x| bookkeeping for the fp16-split convolutions (Tensor::amax)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_kernel(const float* in, size_t pixels, int C4, int cs, int co, unsigned* slot) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  float m = 0.f;
+  const size_t total = pixels * C4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t px = i / C4;
+    const int c4 = (int)(i - px * C4);
+    const v4f v = *reinterpret_cast<const v4f*>(in + px * cs + co + 4 * c4);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > *(volatile const unsigned*)slot) atomicMax(slot, __float_as_uint(m));
+}
+
+__global__ void amax_copy_kernel(const unsigned* from, unsigned* to) { atomicMax(to, *from); }
+
+int launch_absmax(kocr_ctx* ctx, const Tensor& t, unsigned* slot) {
+  if (t.C % 4 || t.cs % 4 || t.co % 4 || ((uintptr_t)t.p & 15)) KOCR_FAIL(ctx, KOCR_EINVAL, "absmax: unaligned tensor");
+  const size_t total = t.pixels() * (t.C / 4);
+  if (!total) return KOCR_OK;
+  ProfScope ps(ctx, "absmax", 0, 4.0 * t.pixels() * t.C);
+  hipLaunchKernelGGL(absmax_kernel, ew_grid(total), dim3(256), 0, ctx->stream, t.p, t.pixels(), t.C / 4, t.cs, t.co, slot);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
+int launch_amax_copy(kocr_ctx* ctx, const unsigned* from, unsigned* to) {
+  if (!from || !to || from == to) return KOCR_OK;
+  hipLaunchKernelGGL(amax_copy_kernel, dim3(1), dim3(1), 0, ctx->stream, from, to);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }

@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split", choices=["bf16x3", "f16x2"], default="bf16x3",
+                    help="arithmetic of the wide convolutions for the headline number (include/kocr.h KOCR_SPLIT_*)")
+    ap.add_argument("--no-alt-mode", action="store_true", help="skip the extra leg in the other split mode")
     args = ap.parse_args()
 
     import torch
@@ -97,6 +100,7 @@ def main():
     torch.cuda.set_device(local_rank)
     ctx = k.default_context()
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_split_mode(args.split)
     # the HIP-event profiler runs for the WHOLE process (calibration, warm-up, timed region, CRNN-only
     # leg) so that its per-kernel averages can be cross-checked against the rocprofv3 summary of the
     # same command in profiles/; the timed region is isolated by differencing two reports
@@ -152,6 +156,31 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+    # the other arithmetic mode of the wide convolutions (include/kocr.h KOCR_SPLIT_*), same workload, same
+    # barrier / max-over-ranks timing; reported beside the headline, never as `value`
+    alt = None
+    if not args.no_alt_mode:
+        alt_mode = "f16x2" if args.split == "bf16x3" else "bf16x3"
+        ctx.set_split_mode(alt_mode)
+        step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            out_alt = step()
+        barrier()
+        dt_alt = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt_alt], dtype=torch.float64, device="cuda")
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt_alt = float(tt.item())
+        same = sum(1 for ga, gb in zip(out, out_alt) for (ta, _), (tb, _) in zip(ga, gb) if ta == tb)
+        alt = {"mode": alt_mode, "value": world * args.batch * args.steps / dt_alt, "unit": "images/s",
+               "ms_per_step": dt_alt / args.steps * 1e3,
+               "words": sum(len(g) for g in out_alt), "identical_strings_vs_headline_mode": same,
+               "note": "f16x2 = 2 round-to-nearest fp16 pieces per fp32 operand, 3 products, exact power-of-two "
+                       "scaling; bf16x3 = 3 exact bf16 pieces, 6 products; both within fp32 round-off of an fp64 "
+                       "reference (tests/test_split_modes_gpu.py)"}
+        ctx.set_split_mode(args.split)
     prof = {}
     for kk, v in prof1.items():
         b = prof0.get(kk, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
@@ -183,10 +212,10 @@ def main():
         conv_fl = sum(v["flops"] for kk, v in prof.items() if kk.startswith("conv_"))
         # the Winograd F(2,3) kernel executes 2/3 of the algorithmic (direct-convolution) multiply-adds
         executed = achieved * (2.0 / 3.0 if name.startswith("conv_wino") else 1.0)
-        split = name.startswith("conv_ws")
+        split = name.startswith("conv_ws") or name.startswith("conv_wh") or name.startswith("conv_ds") or name.startswith("conv_dh")
         if split:
-            # conv_wsplit.hip: Winograd F(2,3) (2/3 of the multiplies), every fp32 product as 6 bf16 MFMA products
-            executed = achieved * (2.0 / 3.0) * 6.0
+            # conv_wsplit.hip: Winograd F(2,3) (2/3 of the multiplies); every fp32 product as 6 bf16 (or 3 fp16) MFMA products
+            executed = achieved * (2.0 / 3.0 if name[5] == "w" else 1.0) * (3.0 if name[6] == "h" else 6.0)
         peak = BF16_MFMA_PEAK_TF if split else FP32_MFMA_PEAK_TF
         stage_ms = {kk: round(v["ms"] / args.steps, 3) for kk, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         # HBM traffic of the dominant kernel: PMC passes cannot run inside this process; the number
@@ -197,7 +226,7 @@ def main():
         if cands:
             pm = json.load(open(cands[-1]))
             if split:
-                want = "void conv_ws_kernel<%d, %s>" % (1 if name.endswith("_pool") else 0, "1, 4" if "x128" in name[8:] else "2, 2")
+                want = "void conv_%ss_kernel<%s%s, %d>" % (name[5], ("%d, " % (1 if name.endswith("_pool") else 0)) if name[5] == "w" else "", "1, 4" if "x128" in name[8:] else "2, 2", 1 if name[6] == "h" else 0)
             elif name.startswith("conv_wino"):
                 want = "void conv_wino_kernel<%d, 4, 4>" % (1 if name.endswith("_pool") else 0)
             else:
@@ -250,6 +279,9 @@ def main():
                           "value": crnn_us_per_crop / 1e3, "unit": "ms/crop",
                           "fp32_mfma_floor_ms": 13.444e9 / (FP32_MFMA_PEAK_TF * 1e12) * 1e3},
         }
+        if alt is not None:
+            res["alt_split_mode"] = alt
+        res["config"]["split_mode"] = args.split
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(craft_w, crnn_w, pages[0])
         print(json.dumps(res))

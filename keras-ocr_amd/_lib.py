@@ -69,6 +69,8 @@ def load_library():
         "kocr_pipeline": (ci, [vp, ci, ctypes.POINTER(vp), _c_int_p, _c_int_p, _c_int_p, _c_int_p, ci, ci,
                                ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, ci, vp, ci, vp, ci]),
         "kocr_conv2d_nhwc": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp]),
+        "kocr_set_split_mode": (ci, [vp, ci]),
+        "kocr_get_split_mode": (ci, [vp]),
         "kocr_profile_enable": (ci, [vp, ci]),
         "kocr_profile_reset": (ci, [vp]),
         "kocr_profile_report": (ci, [vp, ci, ctypes.c_char_p, _c_i64_p, _c_dbl_p, _c_dbl_p, _c_dbl_p]),
@@ -348,6 +350,17 @@ class Context:
                                                _ptr(vecs[0]), _ptr(vecs[1]), int(bool(relu)), _ptr(vecs[2]),
                                                _ptr(vecs[3]), _ptr(out)))
         return out
+
+    # -- arithmetic of the wide convolutions (include/kocr.h: KOCR_SPLIT_*) ---------------
+    SPLIT_BF16X3, SPLIT_F16X2 = 0, 1
+
+    def set_split_mode(self, mode):
+        if isinstance(mode, str):
+            mode = {"bf16": 0, "bf16x3": 0, "f16": 1, "fp16": 1, "f16x2": 1}[mode]
+        self._check(self._lib.kocr_set_split_mode(self._h, int(mode)))
+
+    def get_split_mode(self):
+        return self._check(self._lib.kocr_get_split_mode(self._h))
 
     # -- measurement -------------------------------------------------------------------
     def profile_enable(self, on=True):

@@ -114,6 +114,7 @@ int kocr_create(kocr_ctx** out, int hip_device) {
   if (hipGetDeviceCount(&count) != hipSuccess || hip_device < 0 || hip_device >= count) return KOCR_EHIP;
   if (hipSetDevice(hip_device) != hipSuccess) return KOCR_EHIP;
   kocr_ctx* c = new kocr_ctx();
+  if (const char* e = getenv("KOCR_SPLIT")) c->split_mode = (!strcmp(e, "f16") || !strcmp(e, "fp16")) ? KOCR_SPLIT_F16X2 : KOCR_SPLIT_BF16X3;
   c->device = hip_device;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
@@ -400,6 +401,15 @@ int kocr_conv2d_nhwc(kocr_ctx* ctx, const float* in, int N, int H, int W, int Ci
   }
   return rc;
 }
+
+int kocr_set_split_mode(kocr_ctx* ctx, int mode) {
+  if (!ctx) return KOCR_EINVAL;
+  if (mode != KOCR_SPLIT_BF16X3 && mode != KOCR_SPLIT_F16X2) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_set_split_mode: unknown mode");
+  ctx->split_mode = mode;
+  return KOCR_OK;
+}
+
+int kocr_get_split_mode(const kocr_ctx* ctx) { return ctx ? ctx->split_mode : KOCR_EINVAL; }
 
 int kocr_profile_enable(kocr_ctx* ctx, int on) {
   if (!ctx) return KOCR_EINVAL;

@@ -107,6 +107,8 @@ struct kocr_ctx {
   std::string err;
   void set_err(const std::string& s) { err = s; }
 
+  int split_mode = 0;  // KOCR_SPLIT_BF16X3 / KOCR_SPLIT_F16X2
+
   // max-|x| slots of the tensors of the current forward (see Tensor::amax): zeroed by amax_begin()
   unsigned* d_amax = nullptr;
   int amax_used = 0;
@@ -196,8 +198,7 @@ int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
                      bool need_full);
 // Split arithmetic of conv_wsplit.hip / conv_dsplit.hip: 0 = bf16 x 3 pieces / 6 products (exact split),
 // 1 = fp16 x 2 pieces / 3 products (RNE split at 2^-24, exact power-of-two scaling from Tensor::amax).
-// KOCR_SPLIT=bf16|f16 selects; see DESIGN.md for the default.
-int kocr_split_mode();
+// kocr_ctx::split_mode; KOCR_SPLIT=bf16|f16 sets the initial value, kocr_set_split_mode changes it.
 // conv_wsplit.hip
 int prepare_wsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
 bool wsplit_applicable(const ConvLayer& L, const Tensor& in);

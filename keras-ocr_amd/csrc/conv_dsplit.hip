@@ -488,7 +488,7 @@ int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   p.Mtotal = (int)M;
   p.total_tiles = 0;
   p.amax_out = out.amax;
-  const bool half = kocr_split_mode() == 1 && L.d_ds16;
+  const bool half = ctx->split_mode == KOCR_SPLIT_F16X2 && L.d_ds16;
   p.amax_in = nullptr;
   p.w_exp = 0;
   if (half) {

@@ -614,16 +614,6 @@ int prepare_wsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) 
   return KOCR_OK;
 }
 
-int kocr_split_mode() {
-  static const int mode = [] {
-    const char* e = getenv("KOCR_SPLIT");
-    if (e && (!strcmp(e, "f16") || !strcmp(e, "fp16"))) return 1;
-    if (e && (!strcmp(e, "bf16"))) return 0;
-    return 0;
-  }();
-  return mode;
-}
-
 bool wsplit_applicable(const ConvLayer& L, const Tensor& in) {
   static const bool off = getenv("KOCR_WSPLIT") && atoi(getenv("KOCR_WSPLIT")) == 0;
   return !off && L.d_ws && in.W % 2 == 0 && in.cs % 4 == 0 && in.co % 4 == 0 && ((uintptr_t)in.p & 15) == 0 &&
@@ -689,7 +679,7 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   static const int dbg = getenv("KOCR_WS_DBG") ? atoi(getenv("KOCR_WS_DBG")) : 0;
   p.dbg = dbg;
   // fp16x2 mode needs the input's max |x| on the device: tracked by the producer (Tensor::amax) or reduced here
-  const bool half = kocr_split_mode() == 1 && L.d_ws16;
+  const bool half = ctx->split_mode == KOCR_SPLIT_F16X2 && L.d_ws16;
   p.amax_in = nullptr;
   p.w_exp = 0;
   if (half) {

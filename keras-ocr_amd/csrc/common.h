@@ -76,6 +76,7 @@ struct ConvLayer {
   int ws_cout_pad = 0;
   unsigned short* d_ws16 = nullptr;  // the same, 2-way fp16 split of U * 2^ws_wexp (fp16x2 mode)
   int ws_wexp = 0;
+  int ws16_kb = 1;  // 16-channel blocks per K-step of the fp16 Winograd weights' layout (2 when Cin % 32 == 0)
   unsigned short* d_ds = nullptr;  // direct-conv weights, 3-way bf16 split, conv_dsplit.hip order
   int ds_cout_pad = 0;
   unsigned short* d_ds16 = nullptr;  // 2-way fp16 split of w * 2^ds_wexp

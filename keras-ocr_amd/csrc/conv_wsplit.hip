@@ -59,7 +59,7 @@ struct WsParams {
   int w_exp;                // HALF kernels: the weights are stored multiplied by 2^w_exp
   unsigned* amax_out;   // Tensor::amax of the output (and of the pooled output), or nullptr
   unsigned* amax_pool;
-  int dbg;  // developer timing experiments (wrong results): 1 = skip the epilogue
+  int dbg;  // developer timing experiments (wrong results): 1 = no stores, 2 = one K-step's weights, 8 = producers skip transform/split/LDS fill
 };
 
 __device__ __forceinline__ int ws_xcd_remap(int bid, int nwg) {
@@ -141,14 +141,21 @@ __device__ __forceinline__ WsTile ws_tile(const WsParams& p, int L, int total, i
 // already in LDS when the consumers finish the previous tile's epilogue.
 //   WM x WN = 4 consumer waves: wave (wm, wn) owns M-tiles {2wm, 2wm+1} (64 pairs) x 32 couts.
 //   <1,4>: tile 128 px x 128 couts      <2,2>: tile 256 px x 64 couts (weights shared by two waves)
-template <int POOL, int WM, int WN, int HALF>
+//   KB = 16-channel blocks per K-step (1 or 2).  KB = 2 (fp16x2 mode, Cin % 32 == 0, W % 4 == 0): the
+//   step is twice as long again (48 MFMAs, weights prefetched 1536 cycles ahead) and a producer thread
+//   handles TWO adjacent pairs of one channel quad -- 6 raw pixel loads instead of 8.
+template <int POOL, int WM, int WN, int HALF, int KB>
 __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
   constexpr int NP = HALF ? 2 : 3;                   // operand pieces: 2 x fp16 (3 products) or 3 x bf16 (6 products)
   constexpr int NMT = 2 * WM;                        // 32-pair M-tiles per block tile
-  constexpr int IPT = WM;                            // gather items (pair, channel quad) per producer thread
+  constexpr int IPT = WM;                            // gather items per producer thread
+  constexpr int PPI = KB;                            // pairs per gather item
+  constexpr int NPX = 2 * PPI + 2;                   // raw pixels per gather item
+  constexpr int QPS = 4 * KB;                        // channel quads per K-step
   constexpr int KH_STRIDE = 256;                     // ushorts: 32 rows x 8 channels
-  constexpr int PLANE = NMT * 2 * KH_STRIDE;         // one (xi, piece) plane
-  constexpr int BUF = 4 * NP * PLANE;                // one K-step: 24 KB * WM (bf16x3) / 16 KB * WM (fp16x2)
+  constexpr int PLANE = NMT * 2 * KH_STRIDE;         // one (xi, piece, k block) plane
+  constexpr int BUF = 4 * NP * KB * PLANE;           // one K-step: 24 KB * WM (bf16x3) / 16 KB * WM * KB (fp16x2)
+  constexpr int NPH = 4 * KB;                        // consumer phases (point, k block) per K-step
   // As[buf][xi][piece][M-tile][k half][32 rows x 8 ch bf16 = 512 B]: a 32x32x16 A fetch reads 2 x 512
   // contiguous bytes (16 B per lane, conflict-free); the rows of k half 1 are XOR-ed with 64 B so the two
   // k halves a 16-lane ds_write_b64 group touches fall into different halves of the 32 store banks.
@@ -166,19 +173,22 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
   // ==================================================================================================
   if (wave >= 4) {
     const int ptid = tid - 256;
-    const int quad = ptid & 3;
+    const int quad = ptid & (QPS - 1), q4 = quad & 3, kb = quad >> 2;
     constexpr unsigned OOB = 0x80000000u;
     const float in_scale = HALF ? ws_pow2(ws_scale_exp(p.amax_in)) : 1.f;  // exact power of two
     (void)in_scale;
-    int ldst[IPT];
+    // gather item it of this thread: PPI adjacent pairs starting at LDS row idx0, one channel quad
+    int ldst[IPT][PPI];
 #pragma unroll
-    for (int it = 0; it < IPT; ++it) {
-      const int idx = (ptid >> 2) + it * 64;
-      ldst[it] = ((idx >> 5) * 2 + (quad >> 1)) * KH_STRIDE + ((((idx & 31) * 8) ^ ((quad >> 1) * 32)) + (quad & 1) * 4);
-    }
+    for (int it = 0; it < IPT; ++it)
+#pragma unroll
+      for (int pp = 0; pp < PPI; ++pp) {
+        const int idx = ((ptid / QPS) + it * (256 / QPS)) * PPI + pp;
+        ldst[it][pp] = ((idx >> 5) * 2 + (q4 >> 1)) * KH_STRIDE + ((((idx & 31) * 8) ^ ((q4 >> 1) * 32)) + (q4 & 1) * 4);
+      }
     // position of the NEXT K-step to load: tile L_ld, step (ld_cg, ld_ky)
     int L_ld = blockIdx.x, ld_ky = 0, ld_cg = 0;
-    unsigned goff[IPT][4];
+    unsigned goff[IPT][NPX];
     int gy[IPT];
     bool gok[IPT];
     __amdgpu_buffer_rsrc_t rsrc;
@@ -196,8 +206,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
       rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)bbu, 0, 0x80000000, 0x00020000);
 #pragma unroll
       for (int it = 0; it < IPT; ++it) {
-        const int idx = (ptid >> 2) + it * 64;
-        int rel;  // pixel offset of the pair's first pixel from pm0
+        const int idx = ((ptid / QPS) + it * (256 / QPS)) * PPI;  // first LDS row (pair) of the item
+        int rel;  // pixel offset of the item's first pair from pm0
         int x0;
         if constexpr (POOL) {
           const int i = idx & 31, row = i >> 4, pr = (idx >> 5) * 16 + (i & 15);
@@ -213,53 +223,56 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
           gy[it] = (int)((g / p.W) % p.H);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool pad = (i == 0 && x0 == 0) || (i == 3 && x0 + 2 >= p.W);  // d0 / d3 is column zero padding
-          goff[it][i] = pad ? OOB : (unsigned)(((rel + i) * p.in_cs + quad * 4) * 4);
+        for (int i = 0; i < NPX; ++i) {
+          // first / last raw pixel is column zero padding (KB = 2: W % 4 == 0, so the two pairs share a row)
+          const bool pad = (i == 0 && x0 == 0) || (i == NPX - 1 && x0 + 2 * PPI >= p.W);
+          goff[it][i] = pad ? OOB : (unsigned)(((rel + i) * p.in_cs + kb * 16 + q4 * 4) * 4);
         }
       }
     };
-    auto load_raw = [&](v4f (&raw)[IPT][4]) __attribute__((always_inline)) {
-      const int soff = (ld_ky * p.W * p.in_cs + ld_cg * 16) * 4;
+    auto load_raw = [&](v4f (&raw)[IPT][NPX]) __attribute__((always_inline)) {
+      const int soff = (ld_ky * p.W * p.in_cs + ld_cg * 16 * KB) * 4;
 #pragma unroll
       for (int it = 0; it < IPT; ++it) {
         const bool ok = gok[it] && (unsigned)(gy[it] + ld_ky - 1) < (unsigned)p.H;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NPX; ++i)
           raw[it][i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? goff[it][i] : OOB, soff, 0));
       }
       if (++ld_ky == 3) {
         ld_ky = 0;
-        if (++ld_cg == p.Cin / 16) {  // next tile
+        if (++ld_cg == p.Cin / (16 * KB)) {  // next tile
           ld_cg = 0;
           L_ld += G;
           tile_geometry();
         }
       }
     };
-    auto produce = [&](const v4f (&raw)[IPT][4], int buf) __attribute__((always_inline)) {
-      unsigned short* base = As + buf * BUF;
+    auto produce = [&](const v4f (&raw)[IPT][NPX], int buf) __attribute__((always_inline)) {
+      unsigned short* base = As + buf * BUF + kb * PLANE;
 #pragma unroll
-      for (int it = 0; it < IPT; ++it) {
-        const v4f d0 = raw[it][0], d1 = raw[it][1], d2 = raw[it][2], d3 = raw[it][3];
-        const v4f V[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+      for (int it = 0; it < IPT; ++it)
 #pragma unroll
-        for (int xi = 0; xi < 4; ++xi) {
-          unsigned short* dst = base + xi * NP * PLANE + ldst[it];
-          if constexpr (HALF) {
-            u2v h, l;
-            ws_split4_h(V[xi] * in_scale, h, l);
-            *reinterpret_cast<u2v*>(dst) = h;
-            *reinterpret_cast<u2v*>(dst + PLANE) = l;
-          } else {
-            u2v h, m, l;
-            ws_split4(V[xi], h, m, l);
-            *reinterpret_cast<u2v*>(dst) = h;
-            *reinterpret_cast<u2v*>(dst + PLANE) = m;
-            *reinterpret_cast<u2v*>(dst + 2 * PLANE) = l;
+        for (int pp = 0; pp < PPI; ++pp) {
+          const v4f d0 = raw[it][2 * pp], d1 = raw[it][2 * pp + 1], d2 = raw[it][2 * pp + 2], d3 = raw[it][2 * pp + 3];
+          const v4f V[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+#pragma unroll
+          for (int xi = 0; xi < 4; ++xi) {
+            unsigned short* dst = base + xi * NP * KB * PLANE + ldst[it][pp];
+            if constexpr (HALF) {
+              u2v h, l;
+              ws_split4_h(V[xi] * in_scale, h, l);
+              *reinterpret_cast<u2v*>(dst) = h;
+              *reinterpret_cast<u2v*>(dst + KB * PLANE) = l;
+            } else {
+              u2v h, m, l;
+              ws_split4(V[xi], h, m, l);
+              *reinterpret_cast<u2v*>(dst) = h;
+              *reinterpret_cast<u2v*>(dst + KB * PLANE) = m;
+              *reinterpret_cast<u2v*>(dst + 2 * KB * PLANE) = l;
+            }
           }
         }
-      }
     };
     // K-steps this block will run in total
     const int my_tiles = (total - (int)blockIdx.x + G - 1) / G;
@@ -267,15 +280,15 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
     tile_geometry();
     // branch-free two-step pipeline (a conditional load would force s_waitcnt vmcnt(0) at the join): the
     // loads of global step k+1 are always in flight while step k is transformed; past the end they are masked
-    v4f rawA[IPT][4], rawB[IPT][4];
+    v4f rawA[IPT][NPX], rawB[IPT][NPX];
     load_raw(rawA);
     int k = 0;
     for (; k + 2 <= T; k += 2) {
       load_raw(rawB);
-      produce(rawA, 0);
+      if (!(p.dbg & 8)) produce(rawA, 0);
       __syncthreads();
       load_raw(rawA);
-      produce(rawB, 1);
+      if (!(p.dbg & 8)) produce(rawB, 1);
       __syncthreads();
     }
     if (k < T) {  // odd total: the last step is already in rawA
@@ -291,24 +304,27 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
   // ==================================================================================================
   const int wn = (WN == 4) ? wave : (wave % WN), wm = (WM == 1) ? 0 : (wave / WN);
   const int ntiles32 = p.Cout_pad >> 5;
-  const size_t w_step = (size_t)ntiles32 * 4 * NP * 64 * 8;  // ushorts per K-step
-  // weights: [step][ntile32][xi][piece][lane][8 bf16]; 16 B per lane and (xi, piece)
-  auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * WN + wn) * 4 * NP * 64 + lane) * 8; };
+  const size_t w_step = (p.dbg & 2) ? 0 : (size_t)ntiles32 * NPH * NP * 64 * 8;  // ushorts per K-step (dbg 2: one step's weights)
+  // weights: [step][ntile32][xi][k block][piece][lane][8]; 16 B per lane and (xi, k block, piece)
+  auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * WN + wn) * NPH * NP * 64 + lane) * 8; };
 
-  bf8 bw[4][NP];
-  f16v acc[4][2];  // [xi][own M-tile]
+  bf8 bw[NPH][NP];   // [phase = xi * KB + k block][piece]
+  f16v acc[4][2];    // [xi][own M-tile]
   const int a_lane = (wm * 2 * 2 + l5) * KH_STRIDE + ((l31 * 8) ^ (l5 * 32));
-  auto load_a = [&](bf8 (&a)[2][NP], const unsigned short* bufp, int xi) __attribute__((always_inline)) {
-    const unsigned short* base = bufp + xi * NP * PLANE + a_lane;
+  // phase ph = (xi, k block): its operand planes are [(xi * NP + piece) * KB + k block]
+  auto load_a = [&](bf8 (&a)[2][NP], const unsigned short* bufp, int ph) __attribute__((always_inline)) {
+    const int xi = ph / KB, kblk = ph % KB;
+    const unsigned short* base = bufp + (xi * NP * KB + kblk) * PLANE + a_lane;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int s = 0; s < NP; ++s) a[m][s] = *reinterpret_cast<const bf8*>(base + s * PLANE + m * 2 * KH_STRIDE);
+      for (int s = 0; s < NP; ++s) a[m][s] = *reinterpret_cast<const bf8*>(base + s * KB * PLANE + m * 2 * KH_STRIDE);
   };
-  auto mfma6 = [&](const bf8 (&a)[2][NP], int xi) __attribute__((always_inline)) {
+  auto mfma6 = [&](const bf8 (&a)[2][NP], int ph) __attribute__((always_inline)) {
+    const int xi = ph / KB;
     // smallest terms first; the two M-tiles alternate so consecutive MFMAs are independent
     if constexpr (HALF) {
-      const hf8 b0 = __builtin_bit_cast(hf8, bw[xi][0]), b1 = __builtin_bit_cast(hf8, bw[xi][1]);
+      const hf8 b0 = __builtin_bit_cast(hf8, bw[ph][0]), b1 = __builtin_bit_cast(hf8, bw[ph][1]);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
         acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, a[m][1]), b0, acc[xi][m], 0, 0, 0);
@@ -319,7 +335,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
       for (int m = 0; m < 2; ++m)
         acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, a[m][0]), b0, acc[xi][m], 0, 0, 0);
     } else {
-      const bf8 b0 = bw[xi][0], b1 = bw[xi][1], b2 = bw[xi][NP - 1];
+      const bf8 b0 = bw[ph][0], b1 = bw[ph][1], b2 = bw[ph][NP - 1];
 #pragma unroll
       for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][NP - 1], b0, acc[xi][m], 0, 0, 0);
 #pragma unroll
@@ -334,42 +350,40 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
       for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b0, acc[xi][m], 0, 0, 0);
     }
   };
-  // One K-step.  A operands of point xi+1 are fetched from LDS while the 12 MFMAs of point xi run; a
-  // point's weights are re-fetched (next K-step) as soon as its MFMAs are issued.  The block barrier
-  // that publishes the NEXT K-step sits before the last point's MFMAs (all LDS reads of this step have
-  // landed by then), so the next step's first operands are fetched behind those 12 MFMAs instead of
-  // exposing the LDS latency after the barrier.  a0 carries point 0 of the current step on entry.
+  // One K-step = NPH phases (point, k block).  The A operands of phase ph+1 are fetched from LDS while
+  // the MFMAs of phase ph run; a phase's weights are re-fetched (next K-step) as soon as its MFMAs are
+  // issued.  The block barrier that publishes the NEXT K-step sits before the last phase's MFMAs (all
+  // LDS reads of this step have landed by then), so the next step's first operands are fetched behind
+  // those MFMAs instead of exposing the LDS latency after the barrier.  a0 carries phase 0 on entry.
   bf8 a0[2][NP], a1[2][NP];
   auto compute_step = [&](const unsigned short* bufp, const unsigned short* bufn,
                           const unsigned short* w_next) __attribute__((always_inline)) {
-    auto load_b = [&](int xi) __attribute__((always_inline)) {
+    auto load_b = [&](int ph) __attribute__((always_inline)) {
 #pragma unroll
-      for (int s = 0; s < NP; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w_next + (size_t)(xi * NP + s) * 64 * 8);
+      for (int s = 0; s < NP; ++s) bw[ph][s] = *reinterpret_cast<const bf8*>(w_next + (size_t)(ph * NP + s) * 64 * 8);
     };
-    // the fences pin the issue order: LDS fetch of the next point, 12 MFMAs, weight fetch
+    // the fences pin the issue order: LDS fetch of the next phase, its MFMAs, weight fetch
     load_a(a1, bufp, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma6(a0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    load_b(0);
-    load_a(a0, bufp, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma6(a1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    load_b(1);
-    load_a(a1, bufp, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma6(a0, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    load_b(2);
-    // unconditional (a branch here makes the compiler drain vmcnt at the loop head); the producers run
-    // one extra barrier for the last K-step, whose prefetch reads stale but valid LDS
-    __syncthreads();  // waits for this wave's LDS reads too: the current buffer is free, the next one is full
-    load_a(a0, bufn, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma6(a1, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    load_b(3);
+#pragma unroll
+    for (int q = 0; q < NPH / 2; ++q) {
+      __builtin_amdgcn_sched_barrier(0);
+      mfma6(a0, 2 * q);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(2 * q);
+      if (2 * q + 2 < NPH) {
+        load_a(a0, bufp, 2 * q + 2);
+      } else {
+        // unconditional (a branch here makes the compiler drain vmcnt at the loop head); the producers run
+        // one extra barrier for the last K-step, whose prefetch reads stale but valid LDS
+        __syncthreads();  // waits for this wave's LDS reads too: the current buffer is free, the next one is full
+        load_a(a0, bufn, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma6(a1, 2 * q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(2 * q + 1);
+      if (2 * q + 3 < NPH) load_a(a1, bufp, 2 * q + 3);
+    }
   };
 
   int gs = 0;  // global K-step counter of this block (LDS buffer = gs & 1)
@@ -377,9 +391,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
     const WsTile t0 = ws_tile<POOL, WM, WN>(p, blockIdx.x, total, nblk_n);
     const unsigned short* w0 = w_tile(t0.nt);
 #pragma unroll
-    for (int xi = 0; xi < 4; ++xi)
+    for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
-      for (int s = 0; s < NP; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w0 + (size_t)(xi * NP + s) * 64 * 8);
+      for (int s = 0; s < NP; ++s) bw[ph][s] = *reinterpret_cast<const bf8*>(w0 + (size_t)(ph * NP + s) * 64 * 8);
   }
   __syncthreads();  // global step 0 is in LDS
   load_a(a0, As, 0);
@@ -587,6 +601,9 @@ int prepare_wsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) 
     wexp = 13 - E;
   }
   const float wscale = std::ldexp(1.f, wexp);
+  // K-step of the fp16 kernel: 32 channels (two 16-channel blocks) when Cin allows, else 16
+  const int KB = (Cin % 32 == 0) ? 2 : 1;
+  L.ws16_kb = KB;
   std::vector<unsigned short> v((size_t)(Cin / 16) * 3 * nt32 * 8 * 64 * 8, 0);
   for (int c = 0; c < Cin; ++c)
     for (int ky = 0; ky < 3; ++ky)
@@ -596,15 +613,17 @@ int prepare_wsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) 
           g[kx] = w_is_oihw ? w[(((size_t)o * Cin + c) * 3 + ky) * 3 + kx] : w[(((size_t)ky * 3 + kx) * Cin + c) * Cout + o];
         const float U[4] = {g[0], 0.5f * ((g[0] + g[1]) + g[2]), 0.5f * ((g[0] - g[1]) + g[2]), g[2]};
         const int k = c % 16, lane = (k >> 3) * 32 + (o & 31), j = k & 7;
-        const size_t step = (size_t)(c / 16) * 3 + ky;
+        const int kblk = (c / 16) % KB;
+        const size_t step = (size_t)(c / (16 * KB)) * 3 + ky;
         for (int xi = 0; xi < 4; ++xi) {
           const float x = U[xi] * wscale;
           const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
           unsigned short hb, lb;
           memcpy(&hb, &h, 2);
           memcpy(&lb, &l, 2);
-          v[((((step * nt32 + o / 32) * 4 + xi) * 2 + 0) * 64 + lane) * 8 + j] = hb;
-          v[((((step * nt32 + o / 32) * 4 + xi) * 2 + 1) * 64 + lane) * 8 + j] = lb;
+          const size_t ph = (size_t)xi * KB + kblk;  // [step][ntile32][phase][piece][lane][8]
+          v[((((step * nt32 + o / 32) * 4 * KB + ph) * 2 + 0) * 64 + lane) * 8 + j] = hb;
+          v[((((step * nt32 + o / 32) * 4 * KB + ph) * 2 + 1) * 64 + lane) * 8 + j] = lb;
         }
       }
   L.ws_wexp = wexp;
@@ -620,13 +639,13 @@ bool wsplit_applicable(const ConvLayer& L, const Tensor& in) {
          L.Cin % 16 == 0;
 }
 
-template <int POOL, int WM, int WN, int HALF>
+template <int POOL, int WM, int WN, int HALF, int KB>
 static int ws_launch(kocr_ctx* ctx, WsParams& p, size_t M) {
-  constexpr int LDS_BYTES = 2 * 4 * (HALF ? 2 : 3) * (2 * WM) * 2 * 256 * 2;  // 48 / 96 KB (bf16x3), 32 / 64 KB (fp16x2)
+  constexpr int LDS_BYTES = 2 * 4 * (HALF ? 2 : 3) * KB * (2 * WM) * 2 * 256 * 2;  // 48 / 96 KB (bf16x3), 32 / 64 KB * KB (fp16x2)
   static bool attr_done[64] = {};  // per device: one process may hold contexts on several GPUs
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
-    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_ws_kernel<POOL, WM, WN, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_ws_kernel<POOL, WM, WN, HALF, KB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       LDS_BYTES));
     attr_done[dev] = true;
   }
@@ -640,7 +659,7 @@ static int ws_launch(kocr_ctx* ctx, WsParams& p, size_t M) {
   const size_t mtiles = POOL ? M / (size_t)(128 * WM) : (M + 128 * WM - 1) / (128 * WM);
   p.total_tiles = (int)(mtiles * (p.Cout_pad / (32 * WN)));
   const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;  // persistent: one block per CU
-  hipLaunchKernelGGL((conv_ws_kernel<POOL, WM, WN, HALF>), dim3(grid), dim3(512), LDS_BYTES, ctx->stream, p);
+  hipLaunchKernelGGL((conv_ws_kernel<POOL, WM, WN, HALF, KB>), dim3(grid), dim3(512), LDS_BYTES, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }
@@ -669,7 +688,7 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   p.out_cs = out.cs;
   p.out_co = out.co;
   p.relu = L.relu;
-  p.nsteps = 3 * (L.Cin / 16);
+  p.nsteps = 3 * (L.Cin / 16);  // divided by the K-step's 16-channel blocks below
   p.Mtotal = (int)M;
   p.pool_out = nullptr;
   p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
@@ -679,7 +698,9 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   static const int dbg = getenv("KOCR_WS_DBG") ? atoi(getenv("KOCR_WS_DBG")) : 0;
   p.dbg = dbg;
   // fp16x2 mode needs the input's max |x| on the device: tracked by the producer (Tensor::amax) or reduced here
-  const bool half = ctx->split_mode == KOCR_SPLIT_F16X2 && L.d_ws16;
+  // the 32-channel-step fp16 kernel pairs two adjacent pairs per producer thread: needs W % 4 == 0 (else bf16x3)
+  const bool half = ctx->split_mode == KOCR_SPLIT_F16X2 && L.d_ws16 && (L.ws16_kb == 1 || in.W % 4 == 0);
+  const int kb = half ? L.ws16_kb : 1;
   p.amax_in = nullptr;
   p.w_exp = 0;
   if (half) {
@@ -693,6 +714,7 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
     p.amax_in = slot;
     p.w_exp = L.ws_wexp;
     p.wgt = L.d_ws16;
+    p.nsteps /= kb;
   }
   if (fuse) {
     p.pool_out = pool->p;
@@ -711,28 +733,40 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   {
     ProfScope ps(ctx, nm, flops, bytes);
-    if (half) {
+    if (half && kb == 2) {
       if (wcls == 128) {
         if (fuse)
-          KOCR_TRY((ws_launch<1, 1, 4, 1>(ctx, p, M)));
+          KOCR_TRY((ws_launch<1, 1, 4, 1, 2>(ctx, p, M)));
         else
-          KOCR_TRY((ws_launch<0, 1, 4, 1>(ctx, p, M)));
+          KOCR_TRY((ws_launch<0, 1, 4, 1, 2>(ctx, p, M)));
       } else {
         if (fuse)
-          KOCR_TRY((ws_launch<1, 2, 2, 1>(ctx, p, M)));
+          KOCR_TRY((ws_launch<1, 2, 2, 1, 2>(ctx, p, M)));
         else
-          KOCR_TRY((ws_launch<0, 2, 2, 1>(ctx, p, M)));
+          KOCR_TRY((ws_launch<0, 2, 2, 1, 2>(ctx, p, M)));
+      }
+    } else if (half) {
+      if (wcls == 128) {
+        if (fuse)
+          KOCR_TRY((ws_launch<1, 1, 4, 1, 1>(ctx, p, M)));
+        else
+          KOCR_TRY((ws_launch<0, 1, 4, 1, 1>(ctx, p, M)));
+      } else {
+        if (fuse)
+          KOCR_TRY((ws_launch<1, 2, 2, 1, 1>(ctx, p, M)));
+        else
+          KOCR_TRY((ws_launch<0, 2, 2, 1, 1>(ctx, p, M)));
       }
     } else if (wcls == 128) {
       if (fuse)
-        KOCR_TRY((ws_launch<1, 1, 4, 0>(ctx, p, M)));
+        KOCR_TRY((ws_launch<1, 1, 4, 0, 1>(ctx, p, M)));
       else
-        KOCR_TRY((ws_launch<0, 1, 4, 0>(ctx, p, M)));
+        KOCR_TRY((ws_launch<0, 1, 4, 0, 1>(ctx, p, M)));
     } else {
       if (fuse)
-        KOCR_TRY((ws_launch<1, 2, 2, 0>(ctx, p, M)));
+        KOCR_TRY((ws_launch<1, 2, 2, 0, 1>(ctx, p, M)));
       else
-        KOCR_TRY((ws_launch<0, 2, 2, 0>(ctx, p, M)));
+        KOCR_TRY((ws_launch<0, 2, 2, 0, 1>(ctx, p, M)));
     }
   }
   if (pool && !fuse) return launch_maxpool2x2(ctx, out, *pool);

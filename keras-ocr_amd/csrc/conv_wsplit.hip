@@ -315,10 +315,11 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
   auto load_a = [&](bf8 (&a)[2][NP], const unsigned short* bufp, int ph) __attribute__((always_inline)) {
     const int xi = ph / KB, kblk = ph % KB;
     const unsigned short* base = bufp + (xi * NP * KB + kblk) * PLANE + a_lane;
+    // fetch order = use order: the lowest piece of both M-tiles first (mfma6 starts with the smallest terms)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int s = NP - 1; s >= 0; --s)
 #pragma unroll
-      for (int s = 0; s < NP; ++s) a[m][s] = *reinterpret_cast<const bf8*>(base + s * KB * PLANE + m * 2 * KH_STRIDE);
+      for (int m = 0; m < 2; ++m) a[m][s] = *reinterpret_cast<const bf8*>(base + s * KB * PLANE + m * 2 * KH_STRIDE);
   };
   auto mfma6 = [&](const bf8 (&a)[2][NP], int ph) __attribute__((always_inline)) {
     const int xi = ph / KB;

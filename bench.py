@@ -226,7 +226,7 @@ def main():
         if cands:
             pm = json.load(open(cands[-1]))
             if split:
-                want = "void conv_%ss_kernel<%s%s, %d>" % (name[5], ("%d, " % (1 if name.endswith("_pool") else 0)) if name[5] == "w" else "", "1, 4" if "x128" in name[8:] else "2, 2", 1 if name[6] == "h" else 0)
+                want = "void conv_%ss_kernel<%s%s, %d" % (name[5], ("%d, " % (1 if name.endswith("_pool") else 0)) if name[5] == "w" else "", "1, 4" if "x128" in name[8:] else "2, 2", 1 if name[6] == "h" else 0)
             elif name.startswith("conv_wino"):
                 want = "void conv_wino_kernel<%d, 4, 4>" % (1 if name.endswith("_pool") else 0)
             else:

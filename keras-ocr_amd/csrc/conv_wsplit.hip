@@ -59,7 +59,7 @@ struct WsParams {
   int w_exp;                // HALF kernels: the weights are stored multiplied by 2^w_exp
   unsigned* amax_out;   // Tensor::amax of the output (and of the pooled output), or nullptr
   unsigned* amax_pool;
-  int dbg;  // developer timing experiments (wrong results): 1 = no stores, 2 = one K-step's weights, 8 = producers skip transform/split/LDS fill
+  int dbg;  // developer timing experiments (wrong results): 1 = no stores, 2 = one K-step's weights
 };
 
 __device__ __forceinline__ int ws_xcd_remap(int bid, int nwg) {
@@ -285,10 +285,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
     int k = 0;
     for (; k + 2 <= T; k += 2) {
       load_raw(rawB);
-      if (!(p.dbg & 8)) produce(rawA, 0);
+      produce(rawA, 0);
       __syncthreads();
       load_raw(rawA);
-      if (!(p.dbg & 8)) produce(rawB, 1);
+      produce(rawB, 1);
       __syncthreads();
     }
     if (k < T) {  // odd total: the last step is already in rawA

@@ -164,8 +164,9 @@ int kocr_conv2d_nhwc(kocr_ctx* ctx, const float* in, int N, int H, int W, int Ci
 /* ---- arithmetic of the wide convolutions --------------------------------------------- */
 /* The 3x3 / 1x1 / dilated convolutions with Cout > 32 run on the 16-bit matrix cores with fp32
  * operands split into 16-bit pieces and fp32 accumulation:
- *   KOCR_SPLIT_BF16X3 (default): 3 bf16 pieces, exact split, 6 products (dropped terms <= 2^-23 |ab|);
- *   KOCR_SPLIT_F16X2: 2 fp16 pieces, round-to-nearest split (<= 2^-24 |a| while the low piece is a
+ *   KOCR_SPLIT_BF16X3 (default): 3 bf16 pieces, exact split, 6 products (dropped terms < 2^-21 |ab| worst case,
+ *                                2^-25 |ab| rms);
+ *   KOCR_SPLIT_F16X2: 2 fp16 pieces, round-to-nearest split (<= 2^-22 |a| worst case, 2^-24 rms, while the low piece is a
  *                     normal fp16), 3 products, exact power-of-two scaling from the tensor's tracked
  *                     max |x| -- about 1.3x faster end to end, same measured error against fp64.
  * The environment variable KOCR_SPLIT=bf16|f16 sets the initial mode of new contexts.  There is no

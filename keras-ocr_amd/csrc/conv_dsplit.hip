@@ -51,7 +51,10 @@ __device__ __forceinline__ int ds_xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-// exact 3-way truncation split of four fp32 values, packed as 4 bf16 (8 bytes) per piece
+// Exact 3-way split of four fp32 values by TRUNCATION, packed as 4 bf16 (8 bytes) per piece: h = top 8
+// significand bits of v, m = top 8 bits of v - h, l = the rest; |m| < 2^-7 |v|, |l| < 2^-14 |v|.  (A
+// round-to-nearest split -- the weights use one, on the host -- would give |m| <= 2^-9, |l| <= 2^-18 at the
+// same instruction count, but its mixed-sign pieces cost 5 % end to end on this power-bound kernel.)
 __device__ __forceinline__ void ds_split4(const v4f v, u2v& h, u2v& m, u2v& l) {
   unsigned uh[4], um[4], ul[4];
 #pragma unroll
@@ -61,6 +64,7 @@ __device__ __forceinline__ void ds_split4(const v4f v, u2v& h, u2v& m, u2v& l) {
     um[c] = __float_as_uint(r) & 0xFFFF0000u;
     ul[c] = __float_as_uint(r - __uint_as_float(um[c]));
   }
+  // perm(a, b, 0x07060302) = (a & 0xFFFF0000) | (b >> 16)
   h = u2v{__builtin_amdgcn_perm(uh[1], uh[0], 0x07060302u), __builtin_amdgcn_perm(uh[3], uh[2], 0x07060302u)};
   m = u2v{__builtin_amdgcn_perm(um[1], um[0], 0x07060302u), __builtin_amdgcn_perm(um[3], um[2], 0x07060302u)};
   l = u2v{__builtin_amdgcn_perm(ul[1], ul[0], 0x07060302u), __builtin_amdgcn_perm(ul[3], ul[2], 0x07060302u)};
@@ -361,10 +365,10 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
 // ---------------------------------------------------------------------------------------
 static inline void ds_split3_host(float v, unsigned short out[3]) {
   float r = v;
-  for (int s = 0; s < 3; ++s) {
+  for (int s = 0; s < 3; ++s) {  // round to nearest even at 8 significand bits (finite inputs)
     uint32_t u;
     memcpy(&u, &r, 4);
-    u &= 0xFFFF0000u;
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
     float h;
     memcpy(&h, &u, 4);
     out[s] = (unsigned short)(u >> 16);

@@ -4,10 +4,12 @@
 // Why: on CDNA4 the fp32 MFMA runs at the vector rate (157 TF), the bf16 MFMA 16x faster.  Every
 // fp32 value v is cut EXACTLY into three bf16 pieces v = h + m + l (8 significand bits each, by
 // truncation: h = top 8 bits of v, m = top 8 bits of v-h, l = v-h-m), and
-//     a*b = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh)  [+ am*bl + al*bm + al*bl <= 2^-23 |ab|]
+//     a*b = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh)  [+ am*bl + al*bm + al*bl]
 // is evaluated with SIX v_mfma_f32_32x32x16_bf16 (products exact, fp32 accumulation inside the
 // matrix core) instead of eight fp32 MFMAs of the same shape-equivalent: 6 x 32 cycles against
-// 16 x 32 for a 32x32x16 block.  The dropped terms are below one fp32 ulp of the product; measured
+// 16 x 32 for a 32x32x16 block.  The dropped terms are < 2^-21 |ab| in the worst case and 2^-25 |ab| rms
+// (activations split by truncation: |am| < 2^-7, |al| < 2^-14; weights by round-to-nearest on the host:
+// |bm| <= 2^-8, |bl| <= 2^-16), i.e. of the order of an fp32 ulp of the product (tests/test_split_arith_cpu.py); measured
 // on hardware (scripts/probes/probe_bf16x3.hip, K = 4608 dot products of post-ReLU-like data):
 // max error 1.56e-7 / rms 3.4e-8 of sum|ab| against 1.76e-7 / 2.9e-8 for the fp32 MFMA (== fmaf
 // chain) — the same accuracy class, which tests/test_conv_gpu.py asserts against an fp64 oracle.
@@ -68,7 +70,10 @@ __device__ __forceinline__ int ws_xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-// exact 3-way truncation split of four fp32 values, packed as 4 bf16 (8 bytes) per piece
+// Exact 3-way split of four fp32 values by TRUNCATION, packed as 4 bf16 (8 bytes) per piece: h = top 8
+// significand bits of v, m = top 8 bits of v - h, l = the rest; |m| < 2^-7 |v|, |l| < 2^-14 |v|.  (A
+// round-to-nearest split -- the weights use one, on the host -- would give |m| <= 2^-9, |l| <= 2^-18 at the
+// same instruction count, but its mixed-sign pieces cost 5 % end to end on this power-bound kernel.)
 __device__ __forceinline__ void ws_split4(const v4f v, u2v& h, u2v& m, u2v& l) {
   unsigned uh[4], um[4], ul[4];
 #pragma unroll
@@ -92,7 +97,7 @@ struct WsTile {
   int nt;        // output-channel tile
 };
 
-// fp16 mode (HALF = 1): 2-way RNE fp16 split of four values, v ~ h + l with |v - h - l| <= 2^-24 |v| while l
+// fp16 mode (HALF = 1): 2-way RNE fp16 split of four values, v ~ h + l with |v - h - l| <= 2^-22 |v| (2^-24 rms) while l
 // is a normal fp16 (the caller scales the tensor by an exact power of two so that max |v| ~ 2^14)
 __device__ __forceinline__ void ws_split4_h(const v4f v, u2v& h, u2v& l) {
   _Float16 hh[4], ll[4];
@@ -543,10 +548,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
 // ---------------------------------------------------------------------------------------
 static inline void split3_host(float v, unsigned short out[3]) {
   float r = v;
-  for (int s = 0; s < 3; ++s) {
+  for (int s = 0; s < 3; ++s) {  // round to nearest even at 8 significand bits (finite inputs)
     uint32_t u;
     memcpy(&u, &r, 4);
-    u &= 0xFFFF0000u;
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
     float h;
     memcpy(&h, &u, 4);
     out[s] = (unsigned short)(u >> 16);

@@ -1,0 +1,129 @@
+"""The arithmetic of the split convolutions (csrc/conv_wsplit.hip, conv_dsplit.hip), restated in numpy.
+
+No GPU: these tests pin the CLAIMS the kernels rely on -- the bf16 three-way split is exact, the fp16
+two-way round-to-nearest split is good to 2^-22 (2^-24 typical) once the tensor is scaled by the exact power of two the
+kernels derive from its tracked max |x|, the kept products are exact in fp32, and a long dot product
+evaluated that way is as close to fp64 as a plain fp32 fma chain.  The GPU side of the same statements
+is tests/test_split_modes_gpu.py.
+"""
+import numpy as np
+
+
+def bf16_split3(x, rne=False):
+    """h, m, l: 8 significand bits each.  Activations are split by truncation on the device (csrc: ws_split4),
+    weights by round-to-nearest-even on the host (split3_host)."""
+    x = np.asarray(x, np.float32)
+    out, r = [], x.copy()
+    for _ in range(3):
+        u = r.view(np.uint32).astype(np.uint64)
+        if rne:
+            u = u + 0x7FFF + ((u >> 16) & 1)
+        h = (u & 0xFFFF0000).astype(np.uint32).view(np.float32)
+        out.append(h)
+        r = (r - h).astype(np.float32)
+    return out, r
+
+
+def f16_split2(x):
+    """h, l by round-to-nearest (csrc: ws_split4_h)."""
+    x = np.asarray(x, np.float32)
+    h = x.astype(np.float16)
+    l = (x - h.astype(np.float32)).astype(np.float32).astype(np.float16)
+    return h, l
+
+
+def scale_exp(amax, margin_bits):
+    """csrc ws_scale_exp (margin 2: Winograd-transformed inputs, |V| <= 2 max|x|) / ds_scale_exp (margin 1)."""
+    b = np.float32(amax).view(np.uint32)
+    if b == 0:
+        return 0
+    e = (14 - margin_bits) - (int(b >> 23) - 127)
+    return max(-100, min(100, e))
+
+
+def test_bf16_three_way_split_is_exact():
+    rng = np.random.default_rng(0)
+    # normal fp32 values whose low piece (~2^-18 |v|) is still a normal number; below that the fp32
+    # subtraction v - h underflows and the split degrades gracefully (nothing in a network lives there)
+    x = np.concatenate([rng.standard_normal(100000) * 10.0 ** rng.integers(-25, 30, 100000),
+                        [0.0, -0.0, 1.0, -1.0, 3.0e38, 1.0e-25, np.float32(1) + np.float32(2 ** -23),
+                         np.float32(2) - np.float32(2 ** -23)]]).astype(np.float32)
+    for rne, bm, bl in ((False, 2.0 ** -7, 2.0 ** -14), (True, 2.0 ** -8, 2.0 ** -16)):
+        (h, m, l), r = bf16_split3(x, rne)
+        assert np.all(r == 0)                                # nothing left after three pieces
+        assert np.all(np.abs(m) <= bm * np.abs(x)) and np.all(np.abs(l) <= bl * np.abs(x))
+        assert np.array_equal((h.astype(np.float64) + m + l).astype(np.float32), x)
+        for p in (h, m, l):                                  # each piece is a bf16 value
+            assert np.all((p.view(np.uint32) & np.uint32(0xFFFF)) == 0)
+
+
+def test_bf16_piece_products_are_exact_in_fp32_and_dropped_terms_are_small():
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal(50000).astype(np.float32)
+    b = rng.standard_normal(50000).astype(np.float32)
+    (ah, am, al), _ = bf16_split3(a)             # activations: truncation
+    (bh, bm, bl), _ = bf16_split3(b, rne=True)   # weights: round to nearest
+    for p, q in ((ah, bh), (ah, bm), (am, bh), (am, bm), (ah, bl), (al, bh)):
+        assert np.array_equal((p * q).astype(np.float32).astype(np.float64), p.astype(np.float64) * q)  # 8 x 8 bits
+    kept = sum(p.astype(np.float64) * q for p, q in ((ah, bh), (ah, bm), (am, bh), (am, bm), (ah, bl), (al, bh)))
+    exact = a.astype(np.float64) * b
+    # dropped: am*bl + al*bm + al*bl < (2^-7 2^-16 + 2^-14 2^-8 + 2^-30) |ab| = 2^-21.4 |ab| in the worst case
+    assert np.all(np.abs(exact - kept) <= 2.0 ** -21 * np.abs(exact) + 1e-300)
+    assert float(np.sqrt(np.mean(((exact - kept) / np.maximum(np.abs(exact), 1e-30)) ** 2))) <= 2.0 ** -24
+
+
+def test_f16_two_way_split_after_power_of_two_scaling():
+    rng = np.random.default_rng(2)
+    for mag in (1e-25, 1e-6, 1.0, 3e4, 1e20):
+        x = (rng.standard_normal(20000) * mag).astype(np.float32)
+        amax = float(np.abs(x).max())
+        for margin in (1, 2):
+            e = scale_exp(amax, margin)
+            xs = (x * np.float32(2.0) ** e).astype(np.float32)          # exact: power of two, no overflow
+            assert np.array_equal(xs.astype(np.float64), x.astype(np.float64) * 2.0 ** e)
+            assert float(np.abs(xs).max()) * 2 ** (margin - 1) < 2 ** 14 < 65504
+            h, l = f16_split2(xs)
+            assert np.isfinite(h.astype(np.float32)).all()
+            err = np.abs(xs.astype(np.float64) - h.astype(np.float64) - l.astype(np.float64))
+            # <= 2^-22 relative in the worst case (value at the bottom, residual at the top of their binades;
+            # 2^-24 typical) while the low piece is a normal fp16, 2^-25 absolute (scaled units) below
+            assert np.all(err <= np.maximum(2.0 ** -22 * np.abs(xs), 2.0 ** -25))
+            assert float(np.sqrt(np.mean((err / np.maximum(np.abs(xs), 1e-30)) ** 2))) <= 2.0 ** -23
+
+
+def _chain32(a, b, kb):
+    acc = np.zeros((a.shape[0], b.shape[1]), np.float32)
+    for k in range(0, a.shape[1], kb):
+        acc = (acc + a[:, k:k + kb].astype(np.float64) @ b[k:k + kb].astype(np.float64)).astype(np.float32)
+    return acc
+
+
+def test_long_dot_products_are_fp32_class_in_both_modes():
+    """K = 4608 (3x3 x 512 channels): error against fp64 relative to sum |a||b|, fp32 accumulation per MFMA."""
+    rng = np.random.default_rng(3)
+    K, M, N = 4608, 64, 32
+    a = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    b = (rng.standard_normal((K, N)) * 0.02).astype(np.float32)
+    truth = a.astype(np.float64) @ b.astype(np.float64)
+    s = np.abs(a.astype(np.float64)) @ np.abs(b.astype(np.float64))
+    ref = float((np.abs(_chain32(a, b, 4) - truth) / s).max())          # fp32 MFMA 16x16x4 chain
+
+    (ah, am, al), _ = bf16_split3(a)
+    (bh, bm, bl), _ = bf16_split3(b, rne=True)
+    acc = np.zeros((M, N), np.float32)
+    for k in range(0, K, 16):
+        for p, q in ((al, bh), (ah, bl), (am, bm), (am, bh), (ah, bm), (ah, bh)):
+            acc = (acc + p[:, k:k + 16].astype(np.float64) @ q[k:k + 16].astype(np.float64)).astype(np.float32)
+    e_bf16 = float((np.abs(acc - truth) / s).max())
+
+    ea, eb = scale_exp(float(np.abs(a).max()), 1), scale_exp(float(np.abs(b).max()), 1)
+    ah16, al16 = f16_split2(a * np.float32(2.0) ** ea)
+    bh16, bl16 = f16_split2(b * np.float32(2.0) ** eb)
+    acc = np.zeros((M, N), np.float32)
+    for k in range(0, K, 16):
+        for p, q in ((al16, bh16), (ah16, bl16), (ah16, bh16)):
+            acc = (acc + p[:, k:k + 16].astype(np.float64) @ q[k:k + 16].astype(np.float64)).astype(np.float32)
+    e_f16 = float((np.abs(acc.astype(np.float64) * 2.0 ** -(ea + eb) - truth) / s).max())
+
+    assert ref < 1e-6 and e_bf16 < 1e-6 and e_f16 < 1e-6
+    assert e_bf16 <= 3 * ref and e_f16 <= 3 * ref            # same class as the plain fp32 chain

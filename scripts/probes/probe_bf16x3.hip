@@ -106,11 +106,12 @@ int main() {
     hipMemcpy(C.data(), dC, 4096, hipMemcpyDeviceToHost);
     char nm[32]; snprintf(nm, sizeof nm, "bf16 split x%d", terms); report(nm, C.data());
   }
-  // integer layout check: A[i][k] = i + 3k (exact in bf16 for small), B[k][j] = 2k - j: asymmetric
-  for (int i = 0; i < 32; ++i) for (int k = 0; k < K; ++k) A[i * K + k] = k < 16 ? (float)(i + 3 * k) : 0.f;
-  for (int k = 0; k < K; ++k) for (int j = 0; j < 32; ++j) B[k * 32 + j] = k < 16 ? (float)(2 * k - j) : 0.f;
-  hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
-  hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+  // integer layout check (K = 16, so A is stored with stride 16): A[i][k] = i + 3k, B[k][j] = 2k - j: asymmetric
+  std::vector<float> A2(32 * 16), B2(16 * 32);
+  for (int i = 0; i < 32; ++i) for (int k = 0; k < 16; ++k) A2[i * 16 + k] = (float)(i + 3 * k);
+  for (int k = 0; k < 16; ++k) for (int j = 0; j < 32; ++j) B2[k * 32 + j] = (float)(2 * k - j);
+  hipMemcpy(dA, A2.data(), A2.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dB, B2.data(), B2.size() * 4, hipMemcpyHostToDevice);
   hipLaunchKernelGGL(k_split, dim3(1), dim3(64), 0, 0, dA, dB, dC, 16, 1);
   hipMemcpy(C.data(), dC, 4096, hipMemcpyDeviceToHost);
   int bad = 0;

@@ -181,3 +181,35 @@ def test_recognize_from_boxes_contract(pipe):
     assert len(res) == 2 and len(res[0]) == 1 and len(res[1]) == 1
     same = pipe.recognizer.recognize_from_boxes([a], [box])
     assert same[0] == res[0]
+
+
+def test_baseline_cfg4_size_properties(pipe, ctx):
+    """BASELINE configs[3] at full size (32 pages of 768x768, scale 2 -> detector input 1536x1536), through
+    size-independent properties instead of the CPU oracle (which needs ~3 s per page): the result of an
+    image does not depend on its position in the batch, on the batch size, or on the micro-batching --
+    exactly, in the default (bf16x3) arithmetic; at round-off level with the fp16x2 split, whose input
+    scale follows the micro-batch."""
+    pages = np.stack([synth.text_page(768, 768, 12, seed=100 + i) for i in range(32)])
+    full = pipe.recognize(list(pages))
+    assert len(full) == 32
+    n_words = sum(len(g) for g in full)
+    assert n_words > 0
+    exact = ctx.get_split_mode() == ctx.SPLIT_BF16X3
+
+    def same(ga, gb):
+        assert len(ga) == len(gb)
+        for (ta, ba), (tb, bb) in zip(ga, gb):
+            if exact:
+                assert ta == tb and np.array_equal(ba, bb)
+            else:
+                assert np.allclose(ba, bb, atol=1.0)
+
+    perm = np.random.default_rng(0).permutation(32)
+    shuffled = pipe.recognize([pages[i] for i in perm])
+    for j, i in enumerate(perm):
+        same(shuffled[j], full[i])
+    halves = pipe.recognize(list(pages[:16])) + pipe.recognize(list(pages[16:]))
+    for a, b in zip(halves, full):
+        same(a, b)
+    single = pipe.recognize([pages[7]])[0]
+    same(single, full[7])

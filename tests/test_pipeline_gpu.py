@@ -213,3 +213,40 @@ def test_baseline_cfg4_size_properties(pipe, ctx):
         same(a, b)
     single = pipe.recognize([pages[7]])[0]
     same(single, full[7])
+
+
+def test_baseline_cfg5_share_properties(ctx, calibrated, crnn_weights):
+    """BASELINE configs[4], one GPU's kind of work at full image size: 1536x1536 pages with scale 3, which
+    `tools.resize_image` caps at max_size 2048 (reference tools.py:387-392) -- the largest detector input of
+    the five configs.  Batch of 2 == the two images alone (exact in the default arithmetic)."""
+    import keras_ocr_amd
+
+    det = keras_ocr_amd.detection.Detector(weights=calibrated, ctx=ctx)
+    rec = keras_ocr_amd.recognition.Recognizer(weights=crnn_weights, ctx=ctx)
+    pipe3 = keras_ocr_amd.pipeline.Pipeline(detector=det, recognizer=rec, scale=3)
+    pages = [synth.text_page(1536, 1536, 30, seed=300 + i, scale=2.0) for i in range(2)]
+    both = pipe3.recognize(pages)
+    alone = [pipe3.recognize([p])[0] for p in pages]
+    assert sum(len(g) for g in both) > 0
+    exact = ctx.get_split_mode() == ctx.SPLIT_BF16X3
+    for ga, gb in zip(both, alone):
+        assert len(ga) == len(gb)
+        for (ta, ba), (tb, bb) in zip(ga, gb):
+            if exact:
+                assert ta == tb and np.array_equal(ba, bb)
+            else:
+                assert np.allclose(ba, bb, atol=1.0)
+
+
+def test_baseline_cfg3_size_crnn_order_independence(ctx, crnn_weights):
+    """BASELINE configs[2]: 512 crops; labels of a crop do not depend on its position in the batch."""
+    ctx.load_crnn(crnn_weights)
+    rng = np.random.default_rng(9)
+    crops = rng.random((512, 31, 200), dtype=np.float32)
+    a = ctx.crnn_forward(crops)
+    perm = rng.permutation(512)
+    b = ctx.crnn_forward(crops[perm])
+    if ctx.get_split_mode() == ctx.SPLIT_BF16X3:
+        assert np.array_equal(b, a[perm])
+    else:
+        assert float((b == a[perm]).mean()) > 0.99

@@ -1,8 +1,9 @@
-"""Import shim: ``import keras_ocr_amd`` -> the package that lives in ``keras-ocr_amd/``."""
-import os as _os
+"""keras-ocr_amd — the MI355X-native hot path of keras_ocr.pipeline.Pipeline.recognize().
 
-__path__.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "keras-ocr_amd"))
-_init = _os.path.join(__path__[0], "__init__.py")
-with open(_init, "r", encoding="utf-8") as _f:
-    exec(compile(_f.read(), _init, "exec"))  # pylint: disable=exec-used
-del _os, _f, _init
+The package directory is ``keras_ocr_amd/`` (``keras-ocr_amd`` at the repo root is a symlink to
+it, kept for the layout the build contract names).  Same surface as the reference's
+``keras_ocr`` for the inference path: ``pipeline.Pipeline``, ``detection.Detector``,
+``recognition.Recognizer``, ``tools``.
+"""
+from . import _lib, weights, tools, detection, recognition, pipeline, dist, evaluation  # noqa: F401
+from ._lib import Context, KocrError, load_library, default_context  # noqa: F401

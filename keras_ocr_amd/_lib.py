@@ -1,7 +1,7 @@
 """ctypes binding of libkocr.so (the C-ABI declared in include/kocr.h).
 
 The shared library is built in-tree by ``__graft_entry__.build()`` /
-``make -C keras-ocr_amd/csrc``.  There is NO CPU fallback: if the library is missing or
+``make -C keras_ocr_amd/csrc``.  There is NO CPU fallback: if the library is missing or
 no HIP device is visible, the product fails loudly here.
 """
 import ctypes
@@ -34,7 +34,7 @@ def load_library():
     if not os.path.isfile(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build the HIP extension first "
-            "(python -c 'import __graft_entry__ as g; g.build()' or make -C keras-ocr_amd/csrc). "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C keras_ocr_amd/csrc). "
             "keras-ocr_amd has no CPU fallback.")
     # PyTorch's wheel bundles its own HIP/HSA runtime.  If libkocr (linked against the system ROCm)
     # initialises HIP first, a later `import torch` finds "No HIP GPUs" in its private runtime; the

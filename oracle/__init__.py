@@ -3,7 +3,7 @@
 A restatement, on torch-CPU / numpy / scipy, of the algorithm behind
 ``keras_ocr.pipeline.Pipeline.recognize`` (reference ``keras_ocr/pipeline.py:28-75``).
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
-import this package; the product (``keras-ocr_amd/``) never does.
+import this package; the product (``keras_ocr_amd/``) never does.
 
 Pinning status (see DESIGN.md "Oracle"):
   * ``oracle.craft``  — pinned against the reference's own PyTorch statement of CRAFT

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_python_binding_covers_the_header(lib):
     import keras_ocr_amd
 
-    src = open(os.path.join(ROOT, "keras-ocr_amd", "_lib.py")).read()
+    src = open(os.path.join(ROOT, "keras_ocr_amd", "_lib.py")).read()
     for n in _declared():
         assert f'"{n}"' in src, f"{n} has no ctypes signature"
     del keras_ocr_amd
@@ -59,7 +59,7 @@ def test_no_gpu_fails_loudly():
 
 
 def test_product_never_imports_the_oracle():
-    pkg = os.path.join(ROOT, "keras-ocr_amd")
+    pkg = os.path.join(ROOT, "keras_ocr_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".cpp", ".hip", ".h")):

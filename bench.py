@@ -3,18 +3,26 @@
 metric; workload = configs[3]: full pipeline, batch 32 x 768x768, scale=2, one MI355X per rank).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 without a torchrun environment: bench.py re-launches itself as
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`` (and
+fails loudly when fewer than N GPUs are visible).  Under torchrun it reads RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment.  The process group (backend nccl = RCCL) is created at
+N = 1 too, so the collective path that N > 1 uses is the one exercised on a single-GPU box.
 
 One step = one Pipeline.recognize pass (resize x2 -> CRAFT @1536x1536 -> boxes -> crops -> CRNN ->
-CTC) over a 32-image batch that is already resident in HBM.  Each rank processes its own batch
-(weak scaling, no data-path collective); value = N * 32 * K / max-over-ranks time.
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the Winograd 3x3 convolution on the
-bf16 matrix cores with exact bf16x3 operand splitting, HIP-event timed inside the timed region) and
-`cpu_baseline` (the CPU oracle on a bounded sample).
+CTC) over a 32-image batch already resident in HBM.  Each rank processes its own batch (weak
+scaling, no data-path collective); value = N * 32 * K / max-over-ranks time of the HEADLINE loop,
+which runs with the HIP-event profiler OFF.  A second loop of the same K steps with the profiler ON
+gives `stage_ms_per_step` and the `roofline` of the dominant kernel; further legs (never `value`):
+host-array input (`value_host_arrays`, PCIe inclusive), the other split mode, CRNN only (configs[2]),
+CRAFT only (configs[1]) and one rank's share of configs[4].  `parity` compares page 0 of the timed
+batch with the CPU oracle run of the `cpu_baseline` leg.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,12 +35,14 @@ if ROOT not in sys.path:
 BATCH = 32
 SIDE = 768
 SCALE = 2
+WORDS_PER_PAGE = 20       # SURVEY.md 8(d) cfg 4: "~20 words each"
 FP32_MFMA_PEAK_TF = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
-BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak, same table
+BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 / fp16 MFMA peak, same table
 
 
-def make_pages(n, side, seed):
-    """Seeded synthetic pages: white background, ~20 rendered words (PIL DejaVuSans if present)."""
+def make_pages(n, side, seed, words=WORDS_PER_PAGE):
+    """Seeded synthetic pages: white background, `words` well-separated rendered words on a jittered grid
+    (PIL DejaVuSans if present), so that the detector finds about that many boxes per page."""
     rng = np.random.default_rng(seed)
     try:
         from PIL import Image, ImageDraw, ImageFont
@@ -43,19 +53,25 @@ def make_pages(n, side, seed):
         fonts = None
     alphabet = "abcdefghijklmnopqrstuvwxyz0123456789"
     pages = np.full((n, side, side, 3), 255, np.uint8)
+    cols = max(1, side // 190)
+    rows = max(1, -(-words // cols))
+    cw, ch = side // cols, side // rows
     for i in range(n):
+        cells = [(r, c) for r in range(rows) for c in range(cols)]
+        picks = [cells[j] for j in rng.permutation(len(cells))[:words]]
         if fonts:
             im = Image.fromarray(pages[i])
             dr = ImageDraw.Draw(im)
-            for _ in range(20):
-                word = "".join(rng.choice(list(alphabet), size=int(rng.integers(3, 9))))
-                x, y = int(rng.integers(10, side - 160)), int(rng.integers(10, side - 40))
+            for r, c in picks:
+                word = "".join(rng.choice(list(alphabet), size=int(rng.integers(3, 8))))
+                x = c * cw + int(rng.integers(6, max(7, cw - 150)))
+                y = r * ch + int(rng.integers(4, max(5, ch - 34)))
                 dr.text((x, y), word, fill=(int(rng.integers(0, 90)),) * 3, font=fonts[int(rng.integers(0, 3))])
             pages[i] = np.asarray(im)
         else:
-            for _ in range(20):
-                w, h = int(rng.integers(40, 140)), int(rng.integers(14, 26))
-                x, y = int(rng.integers(0, side - w)), int(rng.integers(0, side - h))
+            for r, c in picks:
+                w, h = int(rng.integers(40, 120)), int(rng.integers(14, 26))
+                x, y = c * cw + int(rng.integers(0, max(1, cw - w))), r * ch + int(rng.integers(0, max(1, ch - h)))
                 patch = rng.integers(0, 120, (h, w, 3), dtype=np.uint8)
                 patch[:, ::7] = 255
                 pages[i, y:y + h, x:x + w] = patch
@@ -75,7 +91,41 @@ def cpu_baseline(craft_w, crnn_w, page):
     dt = time.perf_counter() - t
     return {"value": 1.0 / dt, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"1 synthetic {SIDE}x{SIDE} page, scale={SCALE}, full pipeline, {len(out[0])} words, "
-                      f"{dt:.1f} s on torch-CPU oracle (not TF)"}
+                      f"{dt:.1f} s on torch-CPU oracle (not TF)"}, out[0]
+
+
+def parity_of(gpu_page, oracle_page):
+    """Page 0 of the timed batch: GPU pipeline vs the CPU oracle (strings exact, boxes in input pixels)."""
+    gs, os_ = [t for t, _ in gpu_page], [t for t, _ in oracle_page]
+    same_n = len(gpu_page) == len(oracle_page)
+    diff = None
+    if same_n and gpu_page:
+        diff = float(max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max()
+                         for (_, a), (_, b) in zip(gpu_page, oracle_page)))
+    return {"page": 0, "words_gpu": len(gpu_page), "words_oracle": len(oracle_page),
+            "strings_equal": gs == os_, "boxes_max_abs_diff_px": diff,
+            "ok": bool(same_n and gs == os_ and (diff is None or diff <= 1e-3)),
+            "note": "oracle = oracle/ (CPU restatement of the reference path); box tolerance 1e-3 px, strings exact"}
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` outside torchrun: launch N ranks of this script on this node."""
+    import socket
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node; refusing to "
+                         "report a multi-GPU number from fewer devices")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -88,39 +138,52 @@ def main():
     ap.add_argument("--split", choices=["bf16x3", "f16x2"], default="bf16x3",
                     help="arithmetic of the wide convolutions for the headline number (include/kocr.h KOCR_SPLIT_*)")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the extra leg in the other split mode")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] / configs[4]-share / host-array legs")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        respawn_under_torchrun(args)
+    # stdout carries exactly ONE JSON line: RCCL / HIP banners written to fd 1 by native code go to stderr
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     import keras_ocr_amd as k
 
-    rank, world = k.dist.init_from_env()
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (no CPU fallback)")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
-    ctx = k.default_context()
+    rank, world = k.dist.init_from_env(backend="nccl", force=True)  # RCCL, also at N = 1
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the process group has {world} rank(s)")
+    seen = k.dist.ranks_seen()  # all-reduce of 1 over RCCL
+    if seen != world:
+        raise SystemExit(f"bench.py: all-reduce saw {seen} ranks, expected {world}")
+    ctx = k.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_split_mode(args.split)
-    # the HIP-event profiler runs for the WHOLE process (calibration, warm-up, timed region, CRNN-only
-    # leg) so that its per-kernel averages can be cross-checked against the rocprofv3 summary of the
-    # same command in profiles/; the timed region is isolated by differencing two reports
-    ctx.profile_reset()
-    ctx.profile_enable(True)
+    ctx.profile_enable(False)
 
     pages = make_pages(args.batch, SIDE, seed=4 + rank)
     craft_w = k.weights.synthetic_craft_weights(1234)
     crnn_w = k.weights.synthetic_crnn_weights(4321)
-    # calibrate the random-init head on one page so that the detector emits ~20 boxes per page
+    # calibrate the random-init head (same on every rank) so that the detector emits ~20 boxes per page
     ctx.load_craft(craft_w)
-    sample = ctx.resize_pad(make_pages(1, SIDE, seed=4), (SIDE * SCALE, SIDE * SCALE))
+    cal_pages = make_pages(4, SIDE, seed=1004)
+    sample = ctx.resize_pad(cal_pages, (SIDE * SCALE, SIDE * SCALE))
     raw = ctx.craft_forward(sample)
     best = None
-    for frac in (0.05, 0.035, 0.025, 0.018, 0.012, 0.008, 0.005, 0.003):  # aim at ~20 words / page
+    for frac in (0.08, 0.06, 0.05, 0.04, 0.03, 0.022, 0.016, 0.012, 0.008, 0.005):
         cand = k.weights.calibrate_craft_head(craft_w, raw, text_frac=frac, link_frac=frac / 3)
         a = cand["conv_cls.8.weight"].reshape(2, -1)[:, :1] / craft_w["conv_cls.8.weight"].reshape(2, -1)[:, :1]
         heat = (raw - craft_w["conv_cls.8.bias"]) * a.ravel() + cand["conv_cls.8.bias"]
-        nb = len(ctx.get_boxes(heat.astype(np.float32))[0])
-        if best is None or abs(nb - 22) < abs(best[0] - 22):
+        nb = np.mean([len(b) for b in ctx.get_boxes(heat.astype(np.float32))])
+        if rank == 0:
+            print(f"[bench] head calibration: text_frac {frac}: {nb:.1f} boxes/page", file=sys.stderr)
+        if best is None or abs(nb - WORDS_PER_PAGE) < abs(best[0] - WORDS_PER_PAGE):
             best = (nb, cand)
     craft_w = best[1]
     det = k.detection.Detector(weights=craft_w, ctx=ctx)
@@ -133,64 +196,63 @@ def main():
     def step():
         return pipe.recognize_device(d_pages.data_ptr(), n, h, w)
 
+    def barrier():
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps):
+        """barrier + synchronize on both sides, max over ranks"""
+        barrier()
+        t0 = time.perf_counter()
+        res = None
+        for _ in range(steps):
+            res = fn()
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        return float(tt.item()), res
+
     out = None
     for _ in range(args.warmup):
         out = step()
-    n_words = sum(len(g) for g in out) if out is not None else 0
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    prof0 = ctx.profile_report()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    prof1 = ctx.profile_report()
+    # ---- headline: profiler off ----------------------------------------------------------------------
+    dt, out = timed(step, args.steps)
     n_words = sum(len(g) for g in out)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
-    # the other arithmetic mode of the wide convolutions (include/kocr.h KOCR_SPLIT_*), same workload, same
-    # barrier / max-over-ranks timing; reported beside the headline, never as `value`
+    # ---- the same K steps with the HIP-event profiler on: stage times + roofline of the dominant kernel --
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    dt_prof, _ = timed(step, args.steps)
+    prof = {kk: v for kk, v in ctx.profile_report().items() if v["launches"]}
+    ctx.profile_enable(False)
+
+    # ---- other arithmetic mode of the wide convolutions, same workload; reported beside the headline ------
     alt = None
     if not args.no_alt_mode:
         alt_mode = "f16x2" if args.split == "bf16x3" else "bf16x3"
         ctx.set_split_mode(alt_mode)
         step()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            out_alt = step()
-        barrier()
-        dt_alt = time.perf_counter() - t1
-        if world > 1:
-            tt = torch.tensor([dt_alt], dtype=torch.float64, device="cuda")
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            dt_alt = float(tt.item())
+        dt_alt, out_alt = timed(step, args.steps)
         same = sum(1 for ga, gb in zip(out, out_alt) for (ta, _), (tb, _) in zip(ga, gb) if ta == tb)
         alt = {"mode": alt_mode, "value": world * args.batch * args.steps / dt_alt, "unit": "images/s",
                "ms_per_step": dt_alt / args.steps * 1e3,
                "words": sum(len(g) for g in out_alt), "identical_strings_vs_headline_mode": same,
                "note": "f16x2 = 2 round-to-nearest fp16 pieces per fp32 operand, 3 products, exact power-of-two "
                        "scaling; bf16x3 = 3 exact bf16 pieces, 6 products; both within fp32 round-off of an fp64 "
-                       "reference (tests/test_split_modes_gpu.py)"}
+                       "reference (tests/test_split_modes_gpu.py); the whole GPU suite passes in either mode"}
         ctx.set_split_mode(args.split)
-    prof = {}
-    for kk, v in prof1.items():
-        b = prof0.get(kk, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
-        d = {f: v[f] - b[f] for f in ("launches", "ms", "flops", "bytes")}
-        if d["launches"]:
-            prof[kk] = d
 
-    # secondary BASELINE metric: ms/crop of the CRNN alone (configs[2]: 512 pre-cropped 31x200 strips)
+    extra = {}
+    if not args.no_extra:
+        # host-array input, the reference's calling convention: H2D of the batch inside the timed region
+        pipe.recognize(pages)
+        dt_host, out_host = timed(lambda: pipe.recognize(pages), args.steps)
+        extra["value_host_arrays"] = {
+            "value": world * args.batch * args.steps / dt_host, "unit": "images/s", "ms_per_step": dt_host / args.steps * 1e3,
+            "same_result_as_device_path": [[t for t, _ in g] for g in out_host] == [[t for t, _ in g] for g in out],
+            "note": "pipe.recognize(numpy pages): 56.6 MB H2D per 32 pages + the result D2H inside the timed region"}
     crnn_us_per_crop = None
     if rank == 0:
+        # secondary BASELINE metric: ms/crop of the CRNN alone (configs[2]: 512 pre-cropped 31x200 strips)
         m = 512
         crops = torch.rand((m, 31, 200), dtype=torch.float32, device="cuda")
         labels = torch.empty((m, 48), dtype=torch.int32, device="cuda")
@@ -201,93 +263,117 @@ def main():
             ctx.crnn_forward_device(crops.data_ptr(), m, labels.data_ptr())
         torch.cuda.synchronize()
         crnn_us_per_crop = (time.perf_counter() - t1) / 3 / m * 1e6
+        del crops, labels
+    if rank == 0 and not args.no_extra:
+        # configs[1]: CRAFT detector only, batch 8 x 768x768 (no resize), heat-maps stay in HBM
+        x8 = torch.from_numpy(make_pages(8, SIDE, seed=2)).cuda()
+        heat8 = torch.empty((8, SIDE // 2, SIDE // 2, 2), dtype=torch.float32, device="cuda")
+        ctx.craft_forward_device(x8.data_ptr(), 0, 8, SIDE, SIDE, heat8.data_ptr())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            ctx.craft_forward_device(x8.data_ptr(), 0, 8, SIDE, SIDE, heat8.data_ptr())
+        torch.cuda.synchronize()
+        d2 = (time.perf_counter() - t1) / 5
+        extra["cfg2_craft_only"] = {"workload": "BASELINE configs[1]: CRAFT forward only, 8 x 768x768 u8, input and heat-maps in HBM",
+                                    "value": 8 / d2, "unit": "images/s", "ms_per_batch": d2 * 1e3,
+                                    "algorithmic_tflops": 8 * 419.624e9 / d2 / 1e12}
+        del x8, heat8
+        # configs[4], one rank's share scaled to a bounded sample: 8 x 1536x1536 pages, scale=3 -> capped to 2048x2048
+        p5 = torch.from_numpy(make_pages(8, 1536, seed=5, words=80)).cuda()
+        pipe3 = k.pipeline.Pipeline(detector=det, recognizer=rec, scale=3)
+        pipe3.recognize_device(p5.data_ptr(), 8, 1536, 1536)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            o5 = pipe3.recognize_device(p5.data_ptr(), 8, 1536, 1536)
+        torch.cuda.synchronize()
+        d5 = (time.perf_counter() - t1) / 2
+        extra["cfg5_share"] = {"workload": "BASELINE configs[4] per-GPU share, sample of 8 (of 32) pages 1536x1536, scale=3 "
+                                           "(internally 2048x2048), full pipeline, single rank",
+                               "value": 8 / d5, "unit": "images/s per GPU", "ms_per_8_pages": d5 * 1e3,
+                               "words": sum(len(g) for g in o5)}
+        del p5
 
-    prof_all = ctx.profile_report()  # whole process, CRNN-only leg included
-    ctx.profile_enable(False)
     if rank == 0:
         dom = max((kv for kv in prof.items() if kv[0].startswith("conv_")), key=lambda kv: kv[1]["ms"])
         name, r = dom
         achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
         conv_ms = sum(v["ms"] for kk, v in prof.items() if kk.startswith("conv_"))
         conv_fl = sum(v["flops"] for kk, v in prof.items() if kk.startswith("conv_"))
-        # the Winograd F(2,3) kernel executes 2/3 of the algorithmic (direct-convolution) multiply-adds
-        executed = achieved * (2.0 / 3.0 if name.startswith("conv_wino") else 1.0)
-        split = name.startswith("conv_ws") or name.startswith("conv_wh") or name.startswith("conv_ds") or name.startswith("conv_dh")
-        if split:
-            # conv_wsplit.hip: Winograd F(2,3) (2/3 of the multiplies); every fp32 product as 6 bf16 (or 3 fp16) MFMA products
-            executed = achieved * (2.0 / 3.0 if name[5] == "w" else 1.0) * (3.0 if name[6] == "h" else 6.0)
+        # issued matrix-core work per algorithmic FLOP of the kernel family
+        issue = k.perfmodel.issued_per_algorithmic(name)
+        split = issue["pipe"] != "fp32"
+        executed = achieved * issue["factor"]
         peak = BF16_MFMA_PEAK_TF if split else FP32_MFMA_PEAK_TF
         stage_ms = {kk: round(v["ms"] / args.steps, 3) for kk, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         # HBM traffic of the dominant kernel: PMC passes cannot run inside this process; the number
         # is read from the committed summary of scripts/pmc_bench.sh over this same command
-        traffic, traffic_src = None, "no profiles/*_pmc_traffic.json found"
+        traffic, traffic_src = None, "no profiles/*_pmc_traffic.json entry for this kernel"
         import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-        if cands:
-            pm = json.load(open(cands[-1]))
-            if split:
-                want = "void conv_%ss_kernel<%s%s, %d" % (name[5], ("%d, " % (1 if name.endswith("_pool") else 0)) if name[5] == "w" else "", "1, 4" if "x128" in name[8:] else "2, 2", 1 if name[6] == "h" else 0)
-            elif name.startswith("conv_wino"):
-                want = "void conv_wino_kernel<%d, 4, 4>" % (1 if name.endswith("_pool") else 0)
-            else:
-                want = "void conv_mfma_kernel<128, 128, 2, 2, 0, 16, 0, %d>" % (1 if name.endswith("_pool") else 0)
-            for kname, row in pm["kernels"].items():
-                if kname.startswith(want) and "hbm_bytes_per_launch" in row:
-                    traffic = row["hbm_bytes_per_launch"]
-                    traffic_src = "profiles/" + os.path.basename(cands[-1]) + f", average over {row['launches']} launches of the bench process"
-                    break
+        for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+            pm = json.load(open(cand))
+            row = pm.get("by_prof_name", {}).get(name)
+            if row and "hbm_bytes_per_launch" in row:
+                traffic = row["hbm_bytes_per_launch"]
+                traffic_src = "profiles/" + os.path.basename(cand) + f", average over {row['launches']} launches of the bench process"
+                break
         res = {
             "metric": "images/sec end-to-end Pipeline.recognize() @768x768",
             "value": world * args.batch * args.steps / dt,
             "unit": "images/s",
             "n_gpus": world,
+            "ranks_seen": seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_profiled": dt_prof / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (3x3 convolutions: fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMA products, "
-                     "fp32 accumulation -- fp32-class accuracy, tests/test_conv_gpu.py; everything else fp32 MFMA/VALU)",
+            "dtype": ("f32 (wide 3x3 / 1x1 convolutions: fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMA products, "
+                      "fp32 accumulation -- fp32-class accuracy, tests/test_conv_gpu.py; everything else fp32 MFMA/VALU)")
+            if args.split == "bf16x3" else
+            "f32 (wide convolutions: 2 round-to-nearest fp16 pieces per operand, 3 fp16 MFMA products, fp32 accumulation)",
             "data": "synthetic (seeded rendered-text pages; random-init weights of the reference "
                     "architectures, detector head calibrated to emit word boxes)",
             "config": {"workload": f"Pipeline.recognize full pipeline, batch {args.batch} x {SIDE}x{SIDE} RGB u8 per GPU, "
                                    f"scale={SCALE} (detector input {SIDE*SCALE}x{SIDE*SCALE}), BASELINE configs[3]",
                        "global_batch": world * args.batch, "words_per_batch": n_words,
-                       "parallelism": f"dp{world} (images sharded, no data-path collective)"},
+                       "parallelism": f"dp{world} (images sharded, one process per GPU, RCCL process group; no data-path collective)",
+                       "split_mode": args.split},
             "roofline": {"bound": "mfma", "kernel": name,
-                         "achieved": executed if split else achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": (executed if split else achieved) / peak,
-                         "note": ("achieved = bf16 FLOPs issued to the matrix pipe (algorithmic direct-convolution fp32 "
-                                  "FLOPs x 2/3 Winograd x 6 split products) / kernel time, against the dense bf16 MFMA peak; "
-                                  "algorithmic_fp32_tflops = the same launches priced as plain fp32 convolutions"
-                                  if split else
-                                  "achieved = ALGORITHMIC direct-convolution FLOPs / kernel time; "
-                                  "mfma_executed_tflops = FLOPs actually issued to the matrix pipe"),
+                         "achieved": executed, "peak": peak,
+                         "unit": "TFLOP/s", "frac": executed / peak,
+                         "note": "achieved = matrix-core FLOPs ISSUED (algorithmic direct-convolution fp32 FLOPs x "
+                                 + issue["why"] + ") / kernel time (HIP events, profiled loop of the same K steps) against the "
+                                 "dense peak of the pipe the kernel runs on; algorithmic_* = the same launches priced as plain "
+                                 "fp32 direct convolutions (SURVEY.md 8(d))",
+                         "issued_frac_of_pipe_peak": executed / peak,
                          "algorithmic_fp32_tflops": achieved,
+                         "algorithmic_frac_of_bf16_peak": achieved / BF16_MFMA_PEAK_TF,
                          "algorithmic_vs_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TF,
-                         "mfma_executed_tflops": executed, "mfma_executed_frac": executed / peak,
                          "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE*2 + WRITE_SIZE, " + traffic_src + ")",
-                         "algorithmic_bytes_per_launch": prof_all[name]["bytes"] / prof_all[name]["launches"],
+                         "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
                          "avg_launch_ms": r["ms"] / r["launches"], "launches": r["launches"],
-                         "avg_launch_ms_process": prof_all[name]["ms"] / prof_all[name]["launches"],
-                         "launches_process": prof_all[name]["launches"],
                          "all_conv_tflops": conv_fl / (conv_ms * 1e-3) / 1e12},
             "stage_ms_per_step": stage_ms,
             "crnn_only": {"metric": "ms/crop CRNN (BASELINE configs[2]: 512 crops 31x200, CTC greedy)",
                           "value": crnn_us_per_crop / 1e3, "unit": "ms/crop",
                           "fp32_mfma_floor_ms": 13.444e9 / (FP32_MFMA_PEAK_TF * 1e12) * 1e3},
         }
+        res.update(extra)
         if alt is not None:
             res["alt_split_mode"] = alt
-        res["config"]["split_mode"] = args.split
         if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(craft_w, crnn_w, pages[0])
-        print(json.dumps(res))
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+            res["cpu_baseline"], oracle_page = cpu_baseline(craft_w, crnn_w, pages[0])
+            res["parity"] = parity_of(out[0], oracle_page)
+        json_out.write(json.dumps(res) + "\n")
+        json_out.flush()
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    ctx.close()
 
 
 if __name__ == "__main__":

@@ -13,20 +13,28 @@ import os
 import numpy as np
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun's contract)."""
+LABEL_WIDTH = 48  # CTC rows: 50 time-steps minus the 2 discarded (recognition.py:175-182, 328)
+
+
+def init_from_env(backend=None, force=False):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun's contract).
+    ``force`` creates the process group even for a single rank, so that the RCCL path is the one that
+    runs (and is exercised) at N = 1 too."""
     import torch
     import torch.distributed as dist
 
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and not force:
         return 0, 1
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group(backend=backend)
@@ -40,15 +48,76 @@ def shard_bounds(n_items, world_size, rank):
     return start, min(start + per, n_items)
 
 
-def gather_lists(local, group=None):
-    """All-gather per-rank result lists (arbitrary picklable objects) and concatenate in rank order."""
+def _comm_device(group=None):
+    """Tensors handed to a collective live where the backend wants them: HBM for nccl (= RCCL), host for gloo."""
+    import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return list(local)
-    out = [None] * dist.get_world_size(group)
-    dist.all_gather_object(out, list(local), group=group)
-    return [item for part in out for item in part]
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def ranks_seen(group=None):
+    """All-reduce of 1 over the group: the number of ranks that really took part (1 without a group)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    one = torch.ones(1, dtype=torch.int32, device=_comm_device(group))
+    dist.all_reduce(one, op=dist.ReduceOp.SUM, group=group)
+    return int(one.item())
+
+
+def gather_packed(box_groups, labels, per_rank_images, group=None):
+    """all-gather of the per-image box counts, then of fixed-capacity packed results.
+
+    Every rank contributes ``per_rank_images`` count slots (its shard, zero padded), a (cap, 8) float32
+    box tensor and a (cap, 48) int32 label tensor, where cap = the largest crop count of any rank (known
+    after the counts exchange).  Three collectives, no pickling; on the nccl backend the tensors stay in
+    HBM and travel over xGMI.  Returns (box_groups, labels) of the whole batch in image order.
+    """
+    import torch
+    import torch.distributed as dist
+
+    counts_local = [len(b) for b in box_groups]
+    m_local = int(sum(counts_local))
+    labels = np.asarray(labels, np.int32).reshape(m_local, LABEL_WIDTH)
+    boxes_local = (np.concatenate([np.asarray(b, np.float32).reshape(-1, 8) for b in box_groups if len(b)])
+                   if m_local else np.zeros((0, 8), np.float32))
+    if not (dist.is_available() and dist.is_initialized()):
+        return [np.asarray(b) for b in box_groups], labels
+    world = dist.get_world_size(group)
+    dev = _comm_device(group)
+    # 1. counts: per_rank_images + 1 ints per rank (last slot = number of images this rank really had)
+    c = torch.zeros(per_rank_images + 1, dtype=torch.int32)
+    c[:len(counts_local)] = torch.tensor(counts_local, dtype=torch.int32)
+    c[-1] = len(counts_local)
+    c = c.to(dev)
+    all_c = torch.empty(world * (per_rank_images + 1), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(all_c, c, group=group)
+    all_c = all_c.cpu().numpy().reshape(world, per_rank_images + 1)
+    cap = max(int(all_c[:, :-1].sum(axis=1).max()), 1)
+    # 2. + 3. packed boxes and label rows, capacity = the busiest rank's crop count
+    b = torch.zeros((cap, 8), dtype=torch.float32)
+    b[:m_local] = torch.from_numpy(boxes_local)
+    l = torch.full((cap, LABEL_WIDTH), -1, dtype=torch.int32)
+    l[:m_local] = torch.from_numpy(labels)
+    all_b = torch.empty((world * cap, 8), dtype=torch.float32, device=dev)
+    all_l = torch.empty((world * cap, LABEL_WIDTH), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(all_b, b.to(dev), group=group)
+    dist.all_gather_into_tensor(all_l, l.to(dev), group=group)
+    all_b = all_b.cpu().numpy().reshape(world, cap, 4, 2)
+    all_l = all_l.cpu().numpy().reshape(world, cap, LABEL_WIDTH)
+    out_boxes, out_labels = [], []
+    for r in range(world):
+        pos = 0
+        for i in range(int(all_c[r, -1])):
+            n = int(all_c[r, i])
+            # an image without boxes is np.array([]) in the reference (detection.py:286)
+            out_boxes.append(all_b[r, pos:pos + n].copy() if n else np.zeros((0,), np.float32))
+            pos += n
+        out_labels.append(all_l[r, :pos])
+    return out_boxes, np.concatenate(out_labels) if out_labels else np.zeros((0, LABEL_WIDTH), np.int32)
 
 
 class ShardedPipeline:
@@ -71,10 +140,17 @@ class ShardedPipeline:
         if not isinstance(images, np.ndarray):
             images = [tools.read(image) for image in images]
         images = list(images)
+        if not images:
+            return []
         rank, world = self._rank_world()
         # the padded size comes from the WHOLE batch (pipeline.py:48-57), not from the shard
-        _, dhs, dws, hmax, wmax = self.pipeline._plan([im.shape for im in images])  # pylint: disable=protected-access
+        _, _, _, hmax, wmax = self.pipeline._plan([im.shape for im in images])  # pylint: disable=protected-access
         start, end = shard_bounds(len(images), world, rank)
-        local = self.pipeline.recognize_padded(images[start:end], hmax, wmax, detection_kwargs, recognition_kwargs) \
-            if end > start else []
-        return gather_lists(local, self.group)
+        if end > start:
+            box_groups, labels = self.pipeline.recognize_raw(images[start:end], hmax, wmax, detection_kwargs,
+                                                             recognition_kwargs)
+        else:
+            box_groups, labels = [], np.zeros((0, LABEL_WIDTH), np.int32)
+        per = -(-len(images) // world)
+        box_groups, labels = gather_packed(box_groups, labels, per, self.group)
+        return self.pipeline.assemble(box_groups, labels)

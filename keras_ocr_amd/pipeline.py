@@ -39,16 +39,31 @@ class Pipeline:
     def recognize_padded(self, images, hmax, wmax, detection_kwargs=None, recognition_kwargs=None):
         """recognize() with the padded detector-input size imposed by the caller (used when a
         larger batch is sharded across GPUs: every shard pads to the WHOLE batch's size)."""
+        box_groups, labels = self.recognize_raw(images, hmax, wmax, detection_kwargs, recognition_kwargs)
+        return self.assemble(box_groups, labels)
+
+    def recognize_raw(self, images, hmax=None, wmax=None, detection_kwargs=None, recognition_kwargs=None):
+        """The fused device path up to (but not including) string assembly: returns
+        ``(box_groups, label_rows)`` -- per image an (n_i,4,2) float32 array in INPUT-image pixels
+        (adjust_boxes already applied, pipeline.py:66-71) and one (sum n_i, 48) int32 array of decoded
+        label rows (-1 padded, recognition.py:177-182) in image order.  This fixed-width form is what
+        crosses ranks in ``dist.ShardedPipeline``."""
         if not isinstance(images, np.ndarray):
             images = [tools.read(image) for image in images]
-        images = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        images = list(images)
+        for im in images:
+            if getattr(im, "dtype", None) != np.uint8:
+                raise TypeError("Pipeline.recognize expects uint8 RGB images (what tools.read returns); "
+                                f"got {getattr(im, 'dtype', type(im))}")
+        images = [np.ascontiguousarray(im) for im in images]
         if not images:
-            return []
+            return [], np.zeros((0, 48), np.int32)
         detection_kwargs = dict(detection_kwargs or {})
         del recognition_kwargs  # Keras predict kwargs: no effect on results
-        ctx = self.detector._ctx  # pylint: disable=protected-access
-        if self.recognizer._ctx is not ctx:  # pylint: disable=protected-access
-            raise ValueError("detector and recognizer must share one libkocr context (one GPU)")
+        ctx = getattr(self.detector, "_ctx", None)
+        if ctx is None or getattr(self.recognizer, "_ctx", None) is not ctx:
+            # duck-typed / separately-placed stages: the reference's stage-wise path (pipeline.py:44-75)
+            return self._recognize_stagewise(images, detection_kwargs)
         scales, dhs, dws, hmax_, wmax_ = self._plan([im.shape for im in images])
         hmax = hmax_ if hmax is None else max(hmax, hmax_)
         wmax = wmax_ if wmax is None else max(wmax, wmax_)
@@ -56,7 +71,23 @@ class Pipeline:
         box_groups, labels = ctx.pipeline(
             images, [im.shape[0] for im in images], [im.shape[1] for im in images], dhs, dws, hmax, wmax,
             micro_batch=micro_batch, **detection_kwargs)
-        return self._assemble(box_groups, labels, scales)
+        return self._adjust(box_groups, scales), labels
+
+    def _recognize_stagewise(self, images, detection_kwargs):
+        """pipeline.py:44-75 with the public stage APIs only (any object with ``detect`` /
+        ``recognize_from_boxes``); strings are mapped back to label rows through the recognizer's alphabet."""
+        resized = [tools.resize_image(image, max_scale=self.scale, max_size=self.max_size) for image in images]
+        max_height, max_width = np.array([image.shape[:2] for image, _ in resized]).max(axis=0)
+        scales = [scale for _, scale in resized]
+        padded = np.array([tools.pad(image, width=max_width, height=max_height) for image, _ in resized])
+        box_groups = self.detector.detect(images=padded, **detection_kwargs)
+        texts = self.recognizer.recognize_from_boxes(images=padded, box_groups=box_groups)
+        alphabet = self.recognizer.alphabet
+        rows = [t for group in texts for t in group]
+        labels = np.full((len(rows), 48), -1, np.int32)
+        for r, t in enumerate(rows):
+            labels[r, :len(t)] = [alphabet.index(ch) for ch in t]
+        return self._adjust(box_groups, scales), labels
 
     def recognize_device(self, d_ptr, n, h, w, detection_kwargs=None):
         """Same as recognize() for a batch already resident in HBM: ``d_ptr`` = device pointer of an
@@ -68,16 +99,21 @@ class Pipeline:
         stride = h * w * 3
         box_groups, labels = ctx.pipeline([int(d_ptr) + i * stride for i in range(n)], [h] * n, [w] * n, dhs, dws,
                                           hmax, wmax, micro_batch=micro_batch, on_device=True, **detection_kwargs)
-        return self._assemble(box_groups, labels, scales)
+        return self.assemble(self._adjust(box_groups, scales), labels)
 
-    def _assemble(self, box_groups, labels, scales):
-        predictions = self.recognizer._decode(labels)  # pylint: disable=protected-access
-        prediction_groups, start = [], 0
-        for boxes in box_groups:
-            prediction_groups.append(predictions[start:start + len(boxes)])
-            start += len(boxes)
-        box_groups = [
+    @staticmethod
+    def _adjust(box_groups, scales):
+        """pipeline.py:66-71: boxes back to input-image pixels (identity when scale == 1)."""
+        return [
             tools.adjust_boxes(boxes=boxes, boxes_format="boxes", scale=1 / scale) if scale != 1 else boxes
             for boxes, scale in zip(box_groups, scales)
         ]
-        return [list(zip(predictions, boxes)) for predictions, boxes in zip(prediction_groups, box_groups)]
+
+    def assemble(self, box_groups, labels):
+        """(box_groups, label rows) -> the reference's return value (pipeline.py:72-75)."""
+        predictions = self.recognizer._decode(labels)  # pylint: disable=protected-access
+        out, start = [], 0
+        for boxes in box_groups:
+            out.append(list(zip(predictions[start:start + len(boxes)], boxes)))
+            start += len(boxes)
+        return out

@@ -26,8 +26,25 @@ class _FakePipeline:
 
         return keras_ocr_amd.pipeline.Pipeline._plan(self, shapes)
 
-    def recognize_padded(self, images, hmax, wmax, detection_kwargs=None, recognition_kwargs=None):
-        return [[(f"{im.shape[0]}x{im.shape[1]}@{hmax}x{wmax}", np.zeros((4, 2), np.float32))] for im in images]
+    def recognize_raw(self, images, hmax, wmax, detection_kwargs=None, recognition_kwargs=None):
+        # image i yields (i % 3) boxes whose coordinates and label rows encode what the rank saw
+        groups, rows = [], []
+        for im in images:
+            n = im.shape[0] % 3
+            groups.append(np.full((n, 4, 2), im.shape[0], np.float32) if n else np.array([]))
+            for j in range(n):
+                row = np.full(48, -1, np.int32)
+                row[:4] = [im.shape[0], im.shape[1], hmax, wmax]
+                row[4] = j
+                rows.append(row)
+        return groups, (np.array(rows, np.int32) if rows else np.zeros((0, 48), np.int32))
+
+    def assemble(self, box_groups, labels):
+        out, pos = [], 0
+        for boxes in box_groups:
+            out.append([(tuple(int(v) for v in labels[pos + j, :5]), boxes[j]) for j in range(len(boxes))])
+            pos += len(boxes)
+        return out
 
 
 def _worker(rank, world, port, n_images, q):
@@ -41,12 +58,13 @@ def _worker(rank, world, port, n_images, q):
     images = [np.zeros((10 + i, 20 + 2 * i, 3), np.uint8) for i in range(n_images)]
     sp = keras_ocr_amd.dist.ShardedPipeline(_FakePipeline())
     out = sp.recognize(images)
-    q.put((rank, [o[0][0] for o in out], keras_ocr_amd.dist.shard_bounds(n_images, world, rank)))
+    q.put((rank, [[(t, float(b[0, 0])) for t, b in o] for o in out], keras_ocr_amd.dist.shard_bounds(n_images, world, rank),
+           keras_ocr_amd.dist.ranks_seen()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_images", [5, 2, 1])
+@pytest.mark.parametrize("n_images", [5, 2, 1, 7])
 def test_sharded_recognize_gloo_world2(n_images):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -61,8 +79,9 @@ def test_sharded_recognize_gloo_world2(n_images):
     res.sort()
     # every rank returns the SAME full list, in input order, padded to the WHOLE batch's size
     hmax, wmax = 2 * (10 + n_images - 1), 2 * (20 + 2 * (n_images - 1))
-    want = [f"{10 + i}x{20 + 2 * i}@{hmax}x{wmax}" for i in range(n_images)]
+    want = [[((10 + i, 20 + 2 * i, hmax, wmax, j), float(10 + i)) for j in range((10 + i) % 3)] for i in range(n_images)]
     assert res[0][1] == want and res[1][1] == want
+    assert res[0][3] == 2 and res[1][3] == 2  # both ranks took part in the collectives
     # contiguous blocks of ceil(n/2)
     per = -(-n_images // 2)
     assert res[0][2] == (0, min(per, n_images)) and res[1][2] == (min(per, n_images), n_images)

@@ -22,7 +22,14 @@ whose arithmetic does NOT depend on the missing libraries:
   * ``tools.warpBox``'s scalar logic (:86-106) through recording stand-ins of
     ``cv2.getPerspectiveTransform`` / ``cv2.warpPerspective`` (captures src/dst quads and dsize).
 
-Nothing here pins OpenCV/TensorFlow numerics (parity unpinned for those, see oracle/__init__.py).
+  * ``recognition._transform`` / ``_meshgrid`` / ``_repeat`` (recognition.py:54-166): the STN bilinear sampler
+    is IN-REPO code written against ~20 elementary TensorFlow ops (reshape, tile, matmul, floor, clip_by_value,
+    gather, add_n ...).  A float32 numpy stand-in of exactly those ops (``_TfShim`` below; each op is a one-line
+    numpy call with the documented TF semantics) lets the reference's own function run; its output pins
+    ``oracle/crnn.py::stn_transform``.
+
+Nothing here pins OpenCV/TensorFlow *library* numerics (see tests/golden/make_golden_3p.py for the independent
+cross-checks of those, and oracle/__init__.py for the status table).
 """
 import os
 import sys
@@ -91,6 +98,31 @@ def install_stubs():
     layers.__getattr__ = lambda n: _Any
     keras = mod("tensorflow.keras", layers=layers, models=_Any(), backend=_Any(), utils=_Any())
     tf = mod("tensorflow", keras=keras)
+    # the elementary ops recognition._transform uses, on float32 / int32 numpy arrays (TF semantics)
+    f32, i32 = np.float32, np.int32
+    _dt = {"float32": f32, "int32": i32}
+    shim = dict(
+        ones=lambda shape, dtype="float32": np.ones(shape, _dt[dtype]),
+        zeros=lambda shape, dtype="float32": np.zeros(shape, _dt[dtype]),
+        ones_like=np.ones_like,
+        reshape=lambda x, shape: np.reshape(x, [int(v) for v in np.asarray(shape).ravel()]),
+        matmul=lambda a, b: np.matmul(a, b),
+        linspace=lambda a, b, n: np.linspace(f32(a), f32(b), int(n), dtype=f32),
+        meshgrid=lambda x, y: np.meshgrid(x, y),  # tf.meshgrid default indexing='xy', as numpy
+        concat=lambda xs, axis: np.concatenate(xs, axis),
+        shape=lambda x: np.array(x.shape, i32),
+        cast=lambda x, dtype=None: np.asarray(x).astype(_dt[dtype]),
+        expand_dims=lambda x, axis: np.expand_dims(x, axis),
+        tile=lambda x, multiples: np.tile(x, [int(v) for v in np.asarray(multiples).ravel()]),
+        stack=lambda xs: np.array([int(v) for v in xs], i32),
+        slice=lambda x, begin, size: x[tuple(slice(b, None if sz == -1 else b + sz) for b, sz in zip(begin, size))],
+        floor=np.floor,
+        clip_by_value=lambda x, lo, hi: np.clip(x, lo, hi),
+        range=lambda n: np.arange(int(n), dtype=i32),
+        gather=lambda params, indices: params[indices],
+        add_n=lambda xs: ((xs[0] + xs[1]) + xs[2]) + xs[3] if len(xs) == 4 else sum(xs[1:], xs[0]),
+    )
+    tf.__dict__.update(shim)
     tf.__getattr__ = lambda n: _Any()
     mod("efficientnet")
     mod("efficientnet.tfkeras")
@@ -121,7 +153,7 @@ def main():
     import torch
 
     install_stubs()
-    from keras_ocr import tools, detection  # the reference's modules  # noqa: E402
+    from keras_ocr import tools, detection, recognition  # the reference's modules  # noqa: E402
     import keras_ocr_amd  # noqa: E402
 
     out = {}
@@ -190,6 +222,19 @@ def main():
     out["pad_in"] = im
     out["pad_out"] = tools.pad(im, width=9, height=8)
     out["adjust_out"] = tools.adjust_boxes(boxes, scale=1 / 2)
+    # ---------------- STN sampler: the reference's own _transform through the numpy tf stand-in ----------------
+    srng = np.random.default_rng(77)
+    stn_x = srng.standard_normal((5, 50, 7, 6)).astype(np.float32)
+    stn_theta = np.stack([
+        [1, 0, 0, 0, 1, 0],                      # identity
+        [0.9, 0.05, 0.02, -0.03, 0.9, 0.01],      # what a trained STN looks like
+        [1.3, 0.2, -0.4, 0.1, 1.2, 0.5],          # samples far outside the map (clipped corners)
+        [0.5, 0, 0.7, 0, 0.5, -0.7],
+        [-1, 0, 0, 0, -1, 0],                     # flip
+    ]).astype(np.float32)
+    out["stn_x"] = stn_x
+    out["stn_theta"] = stn_theta
+    out["stn_out"] = np.asarray(recognition._transform([stn_x, stn_theta]), np.float32)  # pylint: disable=protected-access
     np.savez_compressed(os.path.join(HERE, "reference_golden.npz"), **out)
     print("wrote", os.path.join(HERE, "reference_golden.npz"), {k: v.shape for k, v in out.items()})
 

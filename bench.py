@@ -176,7 +176,7 @@ def main():
     sample = ctx.resize_pad(cal_pages, (SIDE * SCALE, SIDE * SCALE))
     raw = ctx.craft_forward(sample)
     best = None
-    for frac in (0.08, 0.06, 0.05, 0.04, 0.03, 0.022, 0.016, 0.012, 0.008, 0.005):
+    for frac in (0.03, 0.016, 0.008, 0.005, 0.0035, 0.0025, 0.0018, 0.0013, 0.0009, 0.0006, 0.0004):
         cand = k.weights.calibrate_craft_head(craft_w, raw, text_frac=frac, link_frac=frac / 3)
         a = cand["conv_cls.8.weight"].reshape(2, -1)[:, :1] / craft_w["conv_cls.8.weight"].reshape(2, -1)[:, :1]
         heat = (raw - craft_w["conv_cls.8.bias"]) * a.ravel() + cand["conv_cls.8.bias"]

@@ -123,35 +123,36 @@ def read_and_fit(filepath_or_array, width: int, height: int, cval: int = 255, mo
 
 
 def sha256sum(filename):
-    """tools.sha256sum (tools.py:484-492)."""
-    h = hashlib.sha256()
-    with open(filename, "rb", buffering=0) as f:
-        for chunk in iter(lambda: f.read(128 * 1024), b""):
-            h.update(chunk)
-    return h.hexdigest()
+    """tools.sha256sum (tools.py:484-492): hex digest of a file, read in blocks."""
+    digest = hashlib.sha256()
+    with open(filename, "rb") as f:
+        while True:
+            block = f.read(1 << 20)
+            if not block:
+                return digest.hexdigest()
+            digest.update(block)
 
 
 def get_default_cache_dir():
-    """tools.get_default_cache_dir (tools.py:495-498)."""
-    return os.environ.get("KERAS_OCR_CACHE_DIR", os.path.expanduser(os.path.join("~", ".keras-ocr")))
+    """tools.get_default_cache_dir (tools.py:495-498): $KERAS_OCR_CACHE_DIR or ~/.keras-ocr."""
+    return os.environ.get("KERAS_OCR_CACHE_DIR") or os.path.join(os.path.expanduser("~"), ".keras-ocr")
 
 
 def download_and_verify(url, sha256=None, cache_dir=None, verbose=True, filename=None):
-    """tools.download_and_verify (tools.py:501-530): same cache + hash semantics."""
-    if cache_dir is None:
-        cache_dir = get_default_cache_dir()
-    if filename is None:
-        filename = os.path.basename(urllib.parse.urlparse(url).path)
-    filepath = os.path.join(cache_dir, filename)
-    os.makedirs(os.path.split(filepath)[0], exist_ok=True)
-    if verbose:
-        print("Looking for " + filepath)
-    if not os.path.isfile(filepath) or (sha256 and sha256sum(filepath) != sha256):
-        if verbose:
-            print("Downloading " + filepath)
-        urllib.request.urlretrieve(url, filepath)
-    assert sha256 is None or sha256 == sha256sum(filepath), "Error occurred verifying sha256."
-    return filepath
+    """tools.download_and_verify (tools.py:501-530).  Contract: the file lives at ``cache_dir/filename`` (default
+    name = last URL path component); it is fetched when missing OR when a hash is given and the cached copy does not
+    match; after that a given hash must match (AssertionError otherwise); the path is returned."""
+    target = os.path.join(cache_dir or get_default_cache_dir(),
+                          filename or os.path.basename(urllib.parse.urlparse(url).path))
+    os.makedirs(os.path.dirname(target), exist_ok=True)
+    say = print if verbose else (lambda *_: None)
+    say("Looking for " + target)
+    cached_ok = os.path.isfile(target) and (not sha256 or sha256sum(target) == sha256)
+    if not cached_ok:
+        say("Downloading " + target)
+        urllib.request.urlretrieve(url, target)
+    assert sha256 is None or sha256sum(target) == sha256, "Error occurred verifying sha256."
+    return target
 
 
 def drawBoxes(image, boxes, color=(255, 0, 0), thickness=5, boxes_format="boxes"):  # pylint: disable=invalid-name

@@ -131,60 +131,61 @@ def synthetic_fc12(n_classes, seed=99):
     }
 
 
+def _h5_datasets(path):
+    """{HDF5 path: float32 array} of every dataset in the file: h5py when it is importable, otherwise the
+    built-in reader (h5lite) -- Keras weight files need nothing more than old-style groups and contiguous data."""
+    try:
+        import h5py  # pylint: disable=import-outside-toplevel
+    except ImportError:
+        from . import h5lite  # pylint: disable=import-outside-toplevel
+
+        tensors = h5lite.read_datasets(path)
+    else:
+        tensors = {}
+
+        def visit(name, obj):
+            if isinstance(obj, h5py.Dataset):
+                tensors[name] = np.array(obj)
+
+        with h5py.File(path, "r") as f:
+            f.visititems(visit)
+    # a full-model file (model.save) keeps the same tree under "model_weights/"
+    strip = "model_weights/"
+    return {(k[len(strip):] if k.startswith(strip) else k): np.asarray(v, dtype=np.float32)
+            for k, v in tensors.items() if not k.startswith("optimizer_weights")}
+
+
+_CRAFT_VARS = {"kernel": ".weight", "bias": ".bias", "gamma": ".weight", "beta": ".bias",
+               "moving_mean": ".running_mean", "moving_variance": ".running_var"}
+_STN_BY_SHAPE = {  # the localisation net's layers are unnamed (recognition.py:268-278): identified by shape
+    (5, 5, 512, 16): "stn_conv_1/kernel", (16,): "stn_conv_1/bias", (5, 5, 16, 32): "stn_conv_2/kernel", (32,): "stn_conv_2/bias",
+    (11200, 64): "stn_dense_1/kernel", (64,): "stn_dense_1/bias", (64, 6): "stn_dense_2/kernel", (6,): "stn_dense_2/bias"}
+
+
 def read_keras_h5(path, kind):
     """Keras HDF5 weight file -> the tensor names kocr_load_craft / kocr_load_crnn expect.
 
-    ``kind='craft'``: craft_mlt_25k.h5 (layer names = PyTorch keys, detection.py:647-658);
-    ``kind='crnn'``: crnn_kurapan[_notop].h5 (recognition.py:27-44).  Needs ``h5py``, which this
-    image does not ship and the files cannot be downloaded here: this reader follows the Keras
-    HDF5 layout (``layer/layer/variable:0``) but could not be exercised — see DESIGN.md."""
-    try:
-        import h5py  # pylint: disable=import-outside-toplevel
-    except ImportError as e:  # pragma: no cover
-        raise ImportError("reading Keras .h5 weights needs h5py; convert the file to a dict of arrays "
-                          "(see keras_ocr_amd.weights) or use load_from_torch=True for the detector") from e
-    tensors = {}
-
-    def visit(name, obj):
-        if isinstance(obj, h5py.Dataset):
-            tensors[name] = np.array(obj, dtype=np.float32)
-
-    with h5py.File(path, "r") as f:
-        (f["model_weights"] if "model_weights" in f else f).visititems(visit)
+    ``kind='craft'``: craft_mlt_25k.h5 -- layer (= group) names are the PyTorch keys (detection.py:432-461), so the
+    result is the state dict ``load_torch_weights`` would have started from, conv kernels back in OIHW (:461).
+    ``kind='crnn'``: crnn_kurapan[_notop].h5 (recognition.py:27-44, 383-404) -- ``<layer>/<variable>`` for the named
+    layers; the variables of the nested, unnamed STN model are recognised by their (unique) shapes.
+    Dataset paths look like ``conv_1/conv_1/kernel:0`` or ``lstm_10/lstm_10/lstm_cell_3/recurrent_kernel:0``: first
+    component = layer, last = variable."""
     out = {}
-    if kind == "craft":
-        for name, arr in tensors.items():
-            parts = name.split("/")
-            layer, var = parts[0], parts[-1].split(":")[0]
-            if var == "kernel":
-                out[layer + ".weight"] = arr.transpose(3, 2, 0, 1)  # HWIO -> OIHW (detection.py:461)
-            elif var == "bias":
-                out[layer + ".bias"] = arr
-            elif var == "gamma":
-                out[layer + ".weight"] = arr
-            elif var == "beta":
-                out[layer + ".bias"] = arr
-            elif var == "moving_mean":
-                out[layer + ".running_mean"] = arr
-            elif var == "moving_variance":
-                out[layer + ".running_var"] = arr
-        return out
-    stn = {}
-    for name, arr in tensors.items():
+    for name, arr in _h5_datasets(path).items():
         parts = name.split("/")
         layer, var = parts[0], parts[-1].split(":")[0]
-        if layer.startswith(("conv_", "bn_", "fc_", "lstm_")):
+        if kind == "craft":
+            if var not in _CRAFT_VARS:
+                raise ValueError(f"{path}: unexpected variable {name}")
+            out[layer + _CRAFT_VARS[var]] = arr.transpose(3, 2, 0, 1) if var == "kernel" else arr  # HWIO -> OIHW
+        elif layer.startswith(("conv_", "bn_", "fc_", "lstm_")):
             out[f"{layer}/{var}"] = arr
-        else:  # the unnamed layers of the nested localisation model
-            stn[(arr.shape, var)] = arr
-    for (shape, var), arr in stn.items():
-        if var == "kernel" and len(shape) == 4:
-            out[("stn_conv_1" if shape[2] == 512 else "stn_conv_2") + "/kernel"] = arr
-        elif var == "kernel":
-            out[("stn_dense_1" if shape[0] == 11200 else "stn_dense_2") + "/kernel"] = arr
-        elif var == "bias":
-            key = {16: "stn_conv_1", 32: "stn_conv_2", 64: "stn_dense_1", 6: "stn_dense_2"}[shape[0]]
-            out[key + "/bias"] = arr
+        else:
+            key = _STN_BY_SHAPE.get(tuple(arr.shape))
+            if key is None or key.split("/")[1] != var or key in out:
+                raise ValueError(f"{path}: cannot place {name} with shape {arr.shape} in the localisation network")
+            out[key] = arr
     return out
 
 

@@ -65,7 +65,9 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
-                assert "oracle/" not in text.replace("oracle/tools.py", "").replace("oracle/postproc.py", "") or True
+                # no dlopen / subprocess / path of anything under oracle/ either; comments may cite oracle files
+                code = "\n".join(ln for ln in text.splitlines() if not ln.lstrip().startswith(("#", "//", "*", '"')))
+                assert not re.search(r"(dlopen|CDLL|subprocess|popen|system)\s*\(.*oracle", code), f
 
 
 def test_reference_api_surface():

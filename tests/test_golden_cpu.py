@@ -102,7 +102,8 @@ def test_pad_and_adjust_boxes(gold):
         assert np.array_equal(mod.pad(gold["pad_in"], width=9, height=8), gold["pad_out"])
         got = mod.adjust_boxes(gold["rot_in"], scale=1 / 2)
         assert got.dtype == gold["adjust_out"].dtype and np.array_equal(got, gold["adjust_out"])
-        assert mod.adjust_boxes(gold["rot_in"], scale=1) is gold["rot_in"] or True
+        same = gold["rot_in"]
+        assert mod.adjust_boxes(same, scale=1) is same  # identity, not a copy (tools.py:249-250)
     # the reference's asserts compare the target with itself (tools.py:371-372), so an
     # undersized target surfaces as numpy's broadcasting ValueError — mirrored as is
     with pytest.raises(ValueError):

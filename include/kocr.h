@@ -105,6 +105,16 @@ int kocr_get_boxes(kocr_ctx* ctx, const float* heat, int N, int h, int w, float 
 int kocr_warp_crops(kocr_ctx* ctx, const uint8_t* img_rgb, int N, int H, int W, const float* boxes,
                     const int32_t* counts, int target_h, int target_w, float* crops, int on_device);
 
+/* The general form of tools.warpBox (tools.py:61-117: margin, skip_rotate, target size taken from the box,
+ * return_transform): the caller states the ordered source quad and the destination quad of each of the M crops;
+ * cv2.getPerspectiveTransform (8x8 float64 LU, on the device) + cv2.warpPerspective as above.  All buffers are HOST
+ * arrays: src_quads / dst_quads float32 [M][4][2]; image_index int32[M] (which of the N images); crop_w / crop_h
+ * int32[M] = dsize of the warp (clipped to the target); crops M x target_h x target_w float32 gray/255, zero
+ * outside the crop; transforms (optional) float64 [M][3][3] = the matrices M the reference returns. */
+int kocr_warp_quads(kocr_ctx* ctx, const uint8_t* img_rgb, int N, int H, int W, int M, const float* src_quads,
+                    const float* dst_quads, const int32_t* image_index, const int32_t* crop_w, const int32_t* crop_h,
+                    int target_h, int target_w, float* crops, double* transforms);
+
 /* ---- inner seam #2: recognizer.prediction_model.predict (recognition.py:535) ------------ */
 /* crops: M x 31 x 200 float32 in [0,1] (the (M,31,200,1) array recognize_from_boxes builds,
  * recognition.py:524-526).  labels: M x 48 int32, the CTCDecoder output: greedy decode,

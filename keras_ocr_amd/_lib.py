@@ -63,6 +63,7 @@ def load_library():
         "kocr_crnn_classes": (ci, [vp]),
         "kocr_get_boxes": (ci, [vp, vp, ci, ci, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, vp, vp, ci, ci]),
         "kocr_warp_crops": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, ci, vp, ci]),
+        "kocr_warp_quads": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, vp]),
         "kocr_detect": (ci, [vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, ci, ci]),
         "kocr_recognize_boxes": (ci, [vp, vp, ci, ci, ci, vp, vp, vp, ci]),
         "kocr_resize_pad": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci]),
@@ -286,6 +287,28 @@ class Context:
             raise ZeroDivisionError("division by zero")  # tools.py:95
         self._check(rc)
         return out
+
+    def warp_quads(self, images, src_quads, dst_quads, image_index, crop_wh, target_height, target_width,
+                   return_transforms=False):
+        """General tools.warpBox: images (N,H,W,3) uint8; src_quads / dst_quads (M,4,2) float32 (source already
+        ordered tl,tr,br,bl); crop_wh (M,2) = the warp's dsize.  Returns crops (M,th,tw) float32 gray/255
+        [, transforms (M,3,3) float64]."""
+        x = np.ascontiguousarray(images, dtype=np.uint8)
+        n, h, w, c = x.shape
+        if c != 3:
+            raise ValueError("images must be RGB")
+        src = np.ascontiguousarray(src_quads, dtype=np.float32).reshape(-1, 4, 2)
+        dst = np.ascontiguousarray(dst_quads, dtype=np.float32).reshape(-1, 4, 2)
+        m = len(src)
+        idx = np.ascontiguousarray(image_index, dtype=np.int32).reshape(m)
+        wh = np.asarray(crop_wh, dtype=np.int64).reshape(m, 2)
+        cw = np.ascontiguousarray(np.minimum(wh[:, 0], target_width), dtype=np.int32)
+        chh = np.ascontiguousarray(np.minimum(wh[:, 1], target_height), dtype=np.int32)
+        out = np.zeros((m, target_height, target_width), dtype=np.float32)
+        tf = np.zeros((m, 3, 3), dtype=np.float64) if return_transforms else None
+        self._check(self._lib.kocr_warp_quads(self._h, _ptr(x), n, h, w, m, _ptr(src), _ptr(dst), _ptr(idx), _ptr(cw),
+                                              _ptr(chh), int(target_height), int(target_width), _ptr(out), _ptr(tf)))
+        return (out, tf) if return_transforms else out
 
     # -- tools.resize_image + pad --------------------------------------------------------------
     def resize_pad(self, images, dsize, out_hw=None, cval=255):

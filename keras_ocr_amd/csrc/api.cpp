@@ -358,6 +358,54 @@ int kocr_warp_crops(kocr_ctx* ctx, const uint8_t* img_rgb, int N, int H, int W, 
   return KOCR_OK;
 }
 
+int kocr_warp_quads(kocr_ctx* ctx, const uint8_t* img_rgb, int N, int H, int W, int M, const float* src_quads,
+                    const float* dst_quads, const int32_t* image_index, const int32_t* crop_w, const int32_t* crop_h,
+                    int target_h, int target_w, float* crops, double* transforms) {
+  if (!ctx) return KOCR_EINVAL;
+  if (N <= 0 || M < 0 || target_h <= 0 || target_w <= 0 || !img_rgb)
+    KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_warp_quads: bad argument");
+  if (M == 0) return KOCR_OK;
+  if (!src_quads || !dst_quads || !image_index || !crop_w || !crop_h || !crops)
+    KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_warp_quads: null buffer");
+  for (int m = 0; m < M; ++m)
+    if (image_index[m] < 0 || image_index[m] >= N || crop_w[m] < 0 || crop_h[m] < 0 || crop_w[m] > target_w ||
+        crop_h[m] > target_h)
+      KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_warp_quads: image index or crop size out of range");
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t ib = (size_t)N * H * W * 3, cb = (size_t)M * target_h * target_w * sizeof(float);
+  const size_t qb = (size_t)M * 8 * sizeof(float), nb = (size_t)M * sizeof(int), tb = (size_t)M * 9 * sizeof(double);
+  KOCR_TRY(arena_reserve(ctx, ctx->io, ib + cb + 2 * qb + 3 * nb + tb + (size_t)M * sizeof(WarpParam) + 8192));
+  ctx->io.off = 0;
+  uint8_t* d_img = (uint8_t*)arena_alloc(ctx->io, ib);
+  float* d_crops = (float*)arena_alloc(ctx->io, cb);
+  float* d_src = (float*)arena_alloc(ctx->io, qb);
+  float* d_dst = (float*)arena_alloc(ctx->io, qb);
+  int* d_idx = (int*)arena_alloc(ctx->io, nb);
+  int* d_cw = (int*)arena_alloc(ctx->io, nb);
+  int* d_ch = (int*)arena_alloc(ctx->io, nb);
+  double* d_tf = (double*)arena_alloc(ctx->io, tb);
+  WarpParam* d_prm = (WarpParam*)arena_alloc(ctx->io, (size_t)M * sizeof(WarpParam));
+  int* d_status = (int*)arena_alloc(ctx->io, 256);
+  if (!d_status) KOCR_FAIL(ctx, KOCR_ENOMEM, "kocr_warp_quads: arena exhausted");
+  hipStream_t s = ctx->stream;
+  KOCR_HIP(ctx, hipMemcpyAsync(d_img, img_rgb, ib, hipMemcpyHostToDevice, s));
+  KOCR_HIP(ctx, hipMemcpyAsync(d_src, src_quads, qb, hipMemcpyHostToDevice, s));
+  KOCR_HIP(ctx, hipMemcpyAsync(d_dst, dst_quads, qb, hipMemcpyHostToDevice, s));
+  KOCR_HIP(ctx, hipMemcpyAsync(d_idx, image_index, nb, hipMemcpyHostToDevice, s));
+  KOCR_HIP(ctx, hipMemcpyAsync(d_cw, crop_w, nb, hipMemcpyHostToDevice, s));
+  KOCR_HIP(ctx, hipMemcpyAsync(d_ch, crop_h, nb, hipMemcpyHostToDevice, s));
+  KOCR_HIP(ctx, hipMemsetAsync(d_status, 0, sizeof(int), s));
+  KOCR_TRY(launch_warp_quads(ctx, d_src, d_dst, d_idx, d_cw, d_ch, M, d_prm, d_tf, d_status));
+  KOCR_TRY(launch_warp(ctx, d_img, H, W, d_prm, M, target_h, target_w, d_crops));
+  int status = 0;
+  KOCR_HIP(ctx, hipMemcpyAsync(crops, d_crops, cb, hipMemcpyDeviceToHost, s));
+  if (transforms) KOCR_HIP(ctx, hipMemcpyAsync(transforms, d_tf, tb, hipMemcpyDeviceToHost, s));
+  KOCR_HIP(ctx, hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+  KOCR_HIP(ctx, hipStreamSynchronize(s));
+  if (status != 0) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_warp_quads: singular perspective transform");
+  return KOCR_OK;
+}
+
 int kocr_conv2d_nhwc(kocr_ctx* ctx, const float* in, int N, int H, int W, int Cin, const float* w_hwio,
                      int KH, int KW, int dilation, int Cout, const float* pre_a, const float* pre_b,
                      int relu, const float* post_a, const float* post_b, float* out) {

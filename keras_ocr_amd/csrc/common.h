@@ -238,9 +238,16 @@ size_t crnn_workspace_bytes(int M, int n_classes);
 int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, float* d_probs);
 
 // postproc.hip
+// dev (optional): device-side results for a caller that keeps going on the stream -- the per-image counts and the
+// totals block (totals[2] = components whose contour list is empty); with dev set, the final synchronisation that
+// fetches n_empty is skipped and the caller reads totals[2] itself.  Both pointers live until the next call.
+struct PPDeviceOut {
+  int* d_counts = nullptr;
+  int* d_totals = nullptr;
+};
 int postproc_get_boxes(kocr_ctx* ctx, const float* d_heat, int N, int h, int w, float det_thr,
                        float text_thr, float link_thr, int size_thr, float* d_boxes, int cap,
-                       int* h_counts, int* n_empty_out);
+                       int* h_counts, int* n_empty_out, PPDeviceOut* dev = nullptr);
 
 // warp.hip
 struct WarpParam {
@@ -252,6 +259,12 @@ struct WarpParam {
 int warp_prepare(const float* box, int target_h, int target_w, WarpParam* out, float* ordered_box);
 int launch_warp(kocr_ctx* ctx, const uint8_t* d_img, int H, int W, const WarpParam* d_prm, int M, int th,
                 int tw, float* d_crops);
+// the same set-up on the device, one thread per box slot of d_boxes[N][cap][4][2] (d_counts[N] on the device);
+// *d_status = max return code of warp_prepare over all boxes (caller zeroes it)
+int launch_warp_prepare(kocr_ctx* ctx, const float* d_boxes, const int* d_counts, int N, int cap, int th, int tw,
+                        WarpParam* d_prm, int* d_status);
+int launch_warp_quads(kocr_ctx* ctx, const float* d_src, const float* d_dst, const int* d_img, const int* d_cw,
+                      const int* d_ch, int M, WarpParam* d_prm, double* d_mfwd, int* d_status);
 
 // imgproc.hip
 int launch_resize_pad(kocr_ctx* ctx, const uint8_t* d_src, int n, int sh, int sw, uint8_t* d_dst, int dh, int dw,

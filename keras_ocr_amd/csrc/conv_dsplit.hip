@@ -14,16 +14,9 @@
 // couts (128 accumulator registers).  K-step = one (16-channel group, tap): 48 MFMA 32x32x16 per wave.
 // LDS: As[buf][piece][M-tile][k half][32 rows x 8 ch] bf16, 24 KB * WM per buffer, the same
 // conflict-free layout as conv_wsplit.hip.  Weights: [16-ch group][tap][32-cout tile][piece][lane][8].
-#include "common.h"
+#include "split_common.h"
 #include <cmath>
 #include <algorithm>
-
-typedef short bf8 __attribute__((ext_vector_type(8)));
-typedef _Float16 hf8 __attribute__((ext_vector_type(8)));
-typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef unsigned u2v __attribute__((ext_vector_type(2)));
 
 struct DsParams {
   const float* in;
@@ -44,50 +37,6 @@ struct DsParams {
   int w_exp;                // HALF kernels: the weights are stored multiplied by 2^w_exp
   unsigned* amax_out;  // Tensor::amax of the output or nullptr
 };
-
-__device__ __forceinline__ int ds_xcd_remap(int bid, int nwg) {
-  const int xcd = bid & 7;
-  const int q = nwg >> 3, r = nwg & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
-
-// Exact 3-way split of four fp32 values by TRUNCATION, packed as 4 bf16 (8 bytes) per piece: h = top 8
-// significand bits of v, m = top 8 bits of v - h, l = the rest; |m| < 2^-7 |v|, |l| < 2^-14 |v|.  (A
-// round-to-nearest split -- the weights use one, on the host -- would give |m| <= 2^-9, |l| <= 2^-18 at the
-// same instruction count, but its mixed-sign pieces cost 5 % end to end on this power-bound kernel.)
-__device__ __forceinline__ void ds_split4(const v4f v, u2v& h, u2v& m, u2v& l) {
-  unsigned uh[4], um[4], ul[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    uh[c] = __float_as_uint(v[c]) & 0xFFFF0000u;
-    const float r = v[c] - __uint_as_float(uh[c]);
-    um[c] = __float_as_uint(r) & 0xFFFF0000u;
-    ul[c] = __float_as_uint(r - __uint_as_float(um[c]));
-  }
-  // perm(a, b, 0x07060302) = (a & 0xFFFF0000) | (b >> 16)
-  h = u2v{__builtin_amdgcn_perm(uh[1], uh[0], 0x07060302u), __builtin_amdgcn_perm(uh[3], uh[2], 0x07060302u)};
-  m = u2v{__builtin_amdgcn_perm(um[1], um[0], 0x07060302u), __builtin_amdgcn_perm(um[3], um[2], 0x07060302u)};
-  l = u2v{__builtin_amdgcn_perm(ul[1], ul[0], 0x07060302u), __builtin_amdgcn_perm(ul[3], ul[2], 0x07060302u)};
-}
-
-// fp16 mode: see conv_wsplit.hip (ws_split4_h / ws_scale_exp); here |x 2^e| < 2^14 with e = 13 - E
-__device__ __forceinline__ void ds_split4_h(const v4f v, u2v& h, u2v& l) {
-  _Float16 hh[4], ll[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    hh[c] = (_Float16)v[c];
-    ll[c] = (_Float16)(v[c] - (float)hh[c]);
-  }
-  h = u2v{__builtin_bit_cast(unsigned, hf2{hh[0], hh[1]}), __builtin_bit_cast(unsigned, hf2{hh[2], hh[3]})};
-  l = u2v{__builtin_bit_cast(unsigned, hf2{ll[0], ll[1]}), __builtin_bit_cast(unsigned, hf2{ll[2], ll[3]})};
-}
-__device__ __forceinline__ int ds_scale_exp(const unsigned* amax) {
-  const unsigned b = *amax;
-  if (b == 0) return 0;
-  int e = 13 - ((int)(b >> 23) - 127);
-  return e < -100 ? -100 : (e > 100 ? 100 : e);
-}
-__device__ __forceinline__ float ds_pow2(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
 
 template <int WM, int WN, int HALF>
 __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
@@ -115,7 +64,7 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
     const int ptid = tid - 256;
     const int quad = ptid & 3;
     constexpr unsigned OOB = 0x80000000u;
-    const float in_scale = HALF ? ds_pow2(ds_scale_exp(p.amax_in)) : 1.f;  // exact power of two
+    const float in_scale = HALF ? kocr_pow2(kocr_scale_exp(p.amax_in, 13)) : 1.f;  // exact power of two
     (void)in_scale;
     int ldst[IPT];
 #pragma unroll
@@ -131,7 +80,7 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
     __amdgpu_buffer_rsrc_t rsrc;
     // buffer resource based (pad_y rows + pad_x pixels) BEFORE the tile: every tap offset is >= 0
     auto tile_geometry = [&]() __attribute__((always_inline)) {
-      const int tile = ds_xcd_remap(L_ld < total ? L_ld : 0, total);
+      const int tile = kocr_xcd_remap(L_ld < total ? L_ld : 0, total);
       const long pm0 = (long)(tile / nblk_n) * TILE_PX;
       const float* bbase_v = p.in + (pm0 * p.in_cs + p.in_co) - (long)(pad_y * p.W + pad_x) * p.in_cs;
       const unsigned long long bb = (unsigned long long)bbase_v;
@@ -175,12 +124,12 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
         unsigned short* dst = base + ldst[it];
         if constexpr (HALF) {
           u2v h, l;
-          ds_split4_h(raw[it] * in_scale, h, l);
+          kocr_split4_h(raw[it] * in_scale, h, l);
           *reinterpret_cast<u2v*>(dst) = h;
           *reinterpret_cast<u2v*>(dst + PLANE) = l;
         } else {
           u2v h, m, l;
-          ds_split4(raw[it], h, m, l);
+          kocr_split4(raw[it], h, m, l);
           *reinterpret_cast<u2v*>(dst) = h;
           *reinterpret_cast<u2v*>(dst + PLANE) = m;
           *reinterpret_cast<u2v*>(dst + 2 * PLANE) = l;
@@ -286,7 +235,7 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
 
   int gs = 0;
   {
-    const int tile0 = ds_xcd_remap(blockIdx.x, total);
+    const int tile0 = kocr_xcd_remap(blockIdx.x, total);
     const unsigned short* w0 = w_tile(tile0 % nblk_n);
 #pragma unroll
     for (int s = 0; s < NP; ++s) bw[s] = *reinterpret_cast<const bf8*>(w0 + (size_t)s * 64 * 8);
@@ -294,11 +243,11 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
   __syncthreads();  // global step 0 is in LDS
   load_a(a0, As, 0);
   for (int L = blockIdx.x; L < total; L += G) {
-    const int tile = ds_xcd_remap(L, total);
+    const int tile = kocr_xcd_remap(L, total);
     const int mt = tile / nblk_n, nt = tile - mt * nblk_n;
     const long pm0 = (long)mt * TILE_PX;
     const unsigned short* w_ptr = w_tile(nt);
-    const unsigned short* w_after = (L + G < total) ? w_tile(ds_xcd_remap(L + G, total) % nblk_n) : w_ptr;
+    const unsigned short* w_after = (L + G < total) ? w_tile(kocr_xcd_remap(L + G, total) % nblk_n) : w_ptr;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -314,7 +263,7 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
     {
       const int n = (nt * WN + wn) * 32 + l31;
       const int nc = n < p.Cout ? n : p.Cout - 1;
-      const float unscale = HALF ? ds_pow2(-(ds_scale_exp(p.amax_in) + p.w_exp)) : 1.f;  // exact
+      const float unscale = HALF ? kocr_pow2(-(kocr_scale_exp(p.amax_in, 13) + p.w_exp)) : 1.f;  // exact
       const float pa = p.pre_a[nc] * unscale, pb = p.pre_b[nc];
       const bool has_post = p.post_a != nullptr;
       const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
@@ -363,21 +312,6 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-static inline void ds_split3_host(float v, unsigned short out[3]) {
-  float r = v;
-  for (int s = 0; s < 3; ++s) {  // round to nearest even at 8 significand bits (finite inputs)
-    uint32_t u;
-    memcpy(&u, &r, 4);
-    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-    float h;
-    memcpy(&h, &u, 4);
-    out[s] = (unsigned short)(u >> 16);
-    r = r - h;
-  }
-}
-
-// Built for every layer the Winograd split kernel does not take (1x1, dilated, 5x5 ...) whose GEMM is
-// wide enough to fill the 32-cout wave tiles.
 int prepare_dsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
   if (L.Cin % 16 != 0 || L.Cout <= 32 || (L.KH == 3 && L.KW == 3 && L.dil == 1)) return KOCR_OK;
   const int Cin = L.Cin, Cout = L.Cout, ntaps = L.KH * L.KW;
@@ -393,7 +327,7 @@ int prepare_dsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) 
         const int k = c % 16, lane = (k >> 3) * 32 + (o & 31), j = k & 7;
         const size_t step = (size_t)(c / 16) * ntaps + tap;
         unsigned short pc[3];
-        ds_split3_host(g, pc);
+        kocr_split3_host(g, pc);
         for (int s = 0; s < 3; ++s) u[(((step * nt32 + o / 32) * 3 + s) * 64 + lane) * 8 + j] = pc[s];
       }
   L.ds_cout_pad = cp;

@@ -30,16 +30,9 @@
 // [16-ch group][ky][32-cout tile][xi][piece][lane][8], fetched straight into registers with a rolling
 // per-point prefetch; weights never touch LDS.  Requires W even.  POOL variant: tile = 2 image rows x
 // 64*WM columns with the 2x2 max taken in-lane.  Details at the kernel below; measurements in DESIGN.md.
-#include "common.h"
+#include "split_common.h"
 #include <cmath>
 #include <algorithm>
-
-typedef short bf8 __attribute__((ext_vector_type(8)));
-typedef _Float16 hf8 __attribute__((ext_vector_type(8)));
-typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef unsigned u2v __attribute__((ext_vector_type(2)));
 
 struct WsParams {
   const float* in;
@@ -61,33 +54,10 @@ struct WsParams {
   int w_exp;                // HALF kernels: the weights are stored multiplied by 2^w_exp
   unsigned* amax_out;   // Tensor::amax of the output (and of the pooled output), or nullptr
   unsigned* amax_pool;
+#ifdef KOCR_DEV_SWITCHES
   int dbg;  // developer timing experiments (wrong results): 1 = no stores, 2 = one K-step's weights
+#endif
 };
-
-__device__ __forceinline__ int ws_xcd_remap(int bid, int nwg) {
-  const int xcd = bid & 7;
-  const int q = nwg >> 3, r = nwg & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
-
-// Exact 3-way split of four fp32 values by TRUNCATION, packed as 4 bf16 (8 bytes) per piece: h = top 8
-// significand bits of v, m = top 8 bits of v - h, l = the rest; |m| < 2^-7 |v|, |l| < 2^-14 |v|.  (A
-// round-to-nearest split -- the weights use one, on the host -- would give |m| <= 2^-9, |l| <= 2^-18 at the
-// same instruction count, but its mixed-sign pieces cost 5 % end to end on this power-bound kernel.)
-__device__ __forceinline__ void ws_split4(const v4f v, u2v& h, u2v& m, u2v& l) {
-  unsigned uh[4], um[4], ul[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    uh[c] = __float_as_uint(v[c]) & 0xFFFF0000u;
-    const float r = v[c] - __uint_as_float(uh[c]);
-    um[c] = __float_as_uint(r) & 0xFFFF0000u;
-    ul[c] = __float_as_uint(r - __uint_as_float(um[c]));
-  }
-  // perm(a, b, 0x07060302) = (a & 0xFFFF0000) | (b >> 16)
-  h = u2v{__builtin_amdgcn_perm(uh[1], uh[0], 0x07060302u), __builtin_amdgcn_perm(uh[3], uh[2], 0x07060302u)};
-  m = u2v{__builtin_amdgcn_perm(um[1], um[0], 0x07060302u), __builtin_amdgcn_perm(um[3], um[2], 0x07060302u)};
-  l = u2v{__builtin_amdgcn_perm(ul[1], ul[0], 0x07060302u), __builtin_amdgcn_perm(ul[3], ul[2], 0x07060302u)};
-}
 
 // Tile geometry shared by both roles.  POOL == 0: 128*WM consecutive pixels of the flattened (n, y, x)
 // order.  POOL == 1: 2 image rows x 64*WM columns.
@@ -97,32 +67,10 @@ struct WsTile {
   int nt;        // output-channel tile
 };
 
-// fp16 mode (HALF = 1): 2-way RNE fp16 split of four values, v ~ h + l with |v - h - l| <= 2^-22 |v| (2^-24 rms) while l
-// is a normal fp16 (the caller scales the tensor by an exact power of two so that max |v| ~ 2^14)
-__device__ __forceinline__ void ws_split4_h(const v4f v, u2v& h, u2v& l) {
-  _Float16 hh[4], ll[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    hh[c] = (_Float16)v[c];
-    ll[c] = (_Float16)(v[c] - (float)hh[c]);
-  }
-  h = u2v{__builtin_bit_cast(unsigned, hf2{hh[0], hh[1]}), __builtin_bit_cast(unsigned, hf2{hh[2], hh[3]})};
-  l = u2v{__builtin_bit_cast(unsigned, hf2{ll[0], ll[1]}), __builtin_bit_cast(unsigned, hf2{ll[2], ll[3]})};
-}
-// exponent e of the exact input scale 2^e: the Winograd-transformed inputs satisfy |V| <= 2 max|x| < 2^(E+2)
-// (E = exponent of the tracked max), so |V 2^e| < 2^14 with e = 12 - E.  amax == 0 -> e = 0.
-__device__ __forceinline__ int ws_scale_exp(const unsigned* amax) {
-  const unsigned b = *amax;
-  if (b == 0) return 0;
-  int e = 12 - ((int)(b >> 23) - 127);
-  return e < -100 ? -100 : (e > 100 ? 100 : e);
-}
-__device__ __forceinline__ float ws_pow2(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
-
 template <int POOL, int WM, int WN>
 __device__ __forceinline__ WsTile ws_tile(const WsParams& p, int L, int total, int nblk_n) {
   WsTile t;
-  const int tile = ws_xcd_remap(L, total);
+  const int tile = kocr_xcd_remap(L, total);
   const int mt = tile / nblk_n;
   t.nt = tile - mt * nblk_n;
   t.y0t = t.x0t = 0;
@@ -180,7 +128,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
     const int ptid = tid - 256;
     const int quad = ptid & (QPS - 1), q4 = quad & 3, kb = quad >> 2;
     constexpr unsigned OOB = 0x80000000u;
-    const float in_scale = HALF ? ws_pow2(ws_scale_exp(p.amax_in)) : 1.f;  // exact power of two
+    const float in_scale = HALF ? kocr_pow2(kocr_scale_exp(p.amax_in, 12)) : 1.f;  // exact power of two
     (void)in_scale;
     // gather item it of this thread: PPI adjacent pairs starting at LDS row idx0, one channel quad
     int ldst[IPT][PPI];
@@ -266,12 +214,12 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
             unsigned short* dst = base + xi * NP * KB * PLANE + ldst[it][pp];
             if constexpr (HALF) {
               u2v h, l;
-              ws_split4_h(V[xi] * in_scale, h, l);
+              kocr_split4_h(V[xi] * in_scale, h, l);
               *reinterpret_cast<u2v*>(dst) = h;
               *reinterpret_cast<u2v*>(dst + KB * PLANE) = l;
             } else {
               u2v h, m, l;
-              ws_split4(V[xi], h, m, l);
+              kocr_split4(V[xi], h, m, l);
               *reinterpret_cast<u2v*>(dst) = h;
               *reinterpret_cast<u2v*>(dst + KB * PLANE) = m;
               *reinterpret_cast<u2v*>(dst + 2 * KB * PLANE) = l;
@@ -309,7 +257,11 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
   // ==================================================================================================
   const int wn = (WN == 4) ? wave : (wave % WN), wm = (WM == 1) ? 0 : (wave / WN);
   const int ntiles32 = p.Cout_pad >> 5;
-  const size_t w_step = (p.dbg & 2) ? 0 : (size_t)ntiles32 * NPH * NP * 64 * 8;  // ushorts per K-step (dbg 2: one step's weights)
+#ifdef KOCR_DEV_SWITCHES
+  const size_t w_step = (p.dbg & 2) ? 0 : (size_t)ntiles32 * NPH * NP * 64 * 8;  // dbg 2: one step's weights
+#else
+  const size_t w_step = (size_t)ntiles32 * NPH * NP * 64 * 8;  // ushorts per K-step
+#endif
   // weights: [step][ntile32][xi][k block][piece][lane][8]; 16 B per lane and (xi, k block, piece)
   auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * WN + wn) * NPH * NP * 64 + lane) * 8; };
 
@@ -431,7 +383,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
       const int n = (t.nt * WN + wn) * 32 + l31;
       const int nc = n < p.Cout ? n : p.Cout - 1;
       // HALF: the accumulators carry the exact factor 2^(input scale + weight scale); undo it in pre_a
-      const float unscale = HALF ? ws_pow2(-(ws_scale_exp(p.amax_in) + p.w_exp)) : 1.f;
+      const float unscale = HALF ? kocr_pow2(-(kocr_scale_exp(p.amax_in, 12) + p.w_exp)) : 1.f;
       const float pa = p.pre_a[nc] * unscale, pb = p.pre_b[nc];
       const bool has_post = p.post_a != nullptr;
       const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
@@ -450,7 +402,11 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
         }
       };
       constexpr unsigned OOB = 0x80000000u;
+#ifdef KOCR_DEV_SWITCHES
       const bool live = n < p.Cout && !(p.dbg & 1);
+#else
+      const bool live = n < p.Cout;
+#endif
       auto uniform_rsrc = [&](const float* base, unsigned bytes) {
         const unsigned long long bb = (unsigned long long)base;
         const unsigned long long bbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)) << 32) |
@@ -546,19 +502,6 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsParams p) {
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-static inline void split3_host(float v, unsigned short out[3]) {
-  float r = v;
-  for (int s = 0; s < 3; ++s) {  // round to nearest even at 8 significand bits (finite inputs)
-    uint32_t u;
-    memcpy(&u, &r, 4);
-    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-    float h;
-    memcpy(&h, &u, 4);
-    out[s] = (unsigned short)(u >> 16);
-    r = r - h;
-  }
-}
-
 int prepare_wsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
   if (L.KH != 3 || L.KW != 3 || L.dil != 1 || L.Cin % 16 != 0 || L.Cout <= 32) return KOCR_OK;
   const int Cin = L.Cin, Cout = L.Cout;
@@ -578,7 +521,7 @@ int prepare_wsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) 
         const size_t step = (size_t)(c / 16) * 3 + ky;
         for (int xi = 0; xi < 4; ++xi) {
           unsigned short pc[3];
-          split3_host(U[xi], pc);
+          kocr_split3_host(U[xi], pc);
           for (int s = 0; s < 3; ++s)
             u[((((step * nt32 + o / 32) * 4 + xi) * 3 + s) * 64 + lane) * 8 + j] = pc[s];
         }
@@ -701,8 +644,10 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   p.total_tiles = 0;
   p.amax_out = out.amax;
   p.amax_pool = (fuse && pool) ? pool->amax : nullptr;
+#ifdef KOCR_DEV_SWITCHES
   static const int dbg = getenv("KOCR_WS_DBG") ? atoi(getenv("KOCR_WS_DBG")) : 0;
   p.dbg = dbg;
+#endif
   // fp16x2 mode needs the input's max |x| on the device: tracked by the producer (Tensor::amax) or reduced here
   // the 32-channel-step fp16 kernel pairs two adjacent pairs per producer thread: needs W % 4 == 0 (else bf16x3)
   const bool half = ctx->split_mode == KOCR_SPLIT_F16X2 && L.d_ws16 && (L.ws16_kb == 1 || in.W % 4 == 0);

@@ -193,36 +193,40 @@ extern "C" int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, c
     KOCR_TRY(craft_forward(ctx, d_bat + (size_t)s * Hmax * Wmax * 3, KOCR_U8, nb, Hmax, Wmax,
                            d_heat + (size_t)s * h2 * w2 * 2));
   }
-  // ---- boxes ----
-  int n_empty = 0;
+  // ---- boxes: the host learns only the per-image counts here (needed to size the crop batch); the boxes themselves
+  // go to the caller asynchronously while the device already derives the crop homographies from its own copy ----
+  PPDeviceOut dv;
   KOCR_TRY(postproc_get_boxes(ctx, d_heat, N, h2, w2, detection_threshold, text_threshold, link_threshold,
-                              size_threshold, d_boxes, cap, counts, &n_empty));
-  if (n_empty > 0)
-    KOCR_FAIL(ctx, KOCR_EEMPTYCONTOUR, "kocr_pipeline: empty contour list (IndexError at detection.py:272)");
+                              size_threshold, d_boxes, cap, counts, nullptr, &dv));
   KOCR_HIP(ctx, hipMemcpyAsync(boxes, d_boxes, box_b, hipMemcpyDeviceToHost, ctx->stream));
-  KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   long M = 0;
   for (int k = 0; k < N; ++k) M += counts[k];
   if (n_crops) *n_crops = (int32_t)M;
-  if (M == 0) return KOCR_OK;
-  if (!labels || M > max_crops) KOCR_FAIL(ctx, KOCR_ECAPACITY, "kocr_pipeline: more crops than max_crops");
-  // ---- crops ----
-  std::vector<WarpParam> prm((size_t)M);
-  long m = 0;
-  for (int k = 0; k < N; ++k)
-    for (int b = 0; b < counts[k]; ++b, ++m) {
-      const int rc = warp_prepare(boxes + ((size_t)k * cap + b) * 8, 31, 200, &prm[m], nullptr);
-      if (rc == 1) KOCR_FAIL(ctx, KOCR_EZERODIV, "kocr_pipeline: box with zero width or height (tools.py:95)");
-      if (rc != 0) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_pipeline: singular perspective transform");
-      prm[m].img = k;
-    }
+  int host_flags[5] = {0, 0, 0, 0, 0};  // totals[0..3] of the post-processing, warp status
+  auto finish = [&]() -> int {
+    KOCR_HIP(ctx, hipMemcpyAsync(host_flags, dv.d_totals, 16, hipMemcpyDeviceToHost, ctx->stream));
+    KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (host_flags[2] > 0)
+      KOCR_FAIL(ctx, KOCR_EEMPTYCONTOUR, "kocr_pipeline: empty contour list (IndexError at detection.py:272)");
+    if (host_flags[4] == 1) KOCR_FAIL(ctx, KOCR_EZERODIV, "kocr_pipeline: box with zero width or height (tools.py:95)");
+    if (host_flags[4] != 0) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_pipeline: singular perspective transform");
+    return KOCR_OK;
+  };
+  if (M == 0) return finish();
+  if (!labels || M > max_crops) {
+    KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    KOCR_FAIL(ctx, KOCR_ECAPACITY, "kocr_pipeline: more crops than max_crops");
+  }
+  // ---- crops: homographies on the device (warp.hip), no host round trip ----
   const size_t crop_b = (size_t)M * 31 * 200 * sizeof(float), lab_b = (size_t)M * 48 * sizeof(int32_t);
-  KOCR_TRY(arena_reserve(ctx, ctx->io, (size_t)M * sizeof(WarpParam) + crop_b + lab_b + 4096));
+  KOCR_TRY(arena_reserve(ctx, ctx->io, (size_t)M * sizeof(WarpParam) + crop_b + lab_b + 8192));
   ctx->io.off = 0;
   WarpParam* d_prm = (WarpParam*)arena_alloc(ctx->io, (size_t)M * sizeof(WarpParam));
   float* d_crops = (float*)arena_alloc(ctx->io, crop_b);
   int32_t* d_lab = (int32_t*)arena_alloc(ctx->io, lab_b);
-  KOCR_HIP(ctx, hipMemcpyAsync(d_prm, prm.data(), (size_t)M * sizeof(WarpParam), hipMemcpyHostToDevice, ctx->stream));
+  int* d_status = (int*)arena_alloc(ctx->io, 256);
+  KOCR_HIP(ctx, hipMemsetAsync(d_status, 0, sizeof(int), ctx->stream));
+  KOCR_TRY(launch_warp_prepare(ctx, d_boxes, dv.d_counts, N, cap, 31, 200, d_prm, d_status));
   KOCR_TRY(launch_warp(ctx, d_bat, Hmax, Wmax, d_prm, (int)M, 31, 200, d_crops));
   // ---- recogniser ----
   const int C = crnn_classes(ctx);
@@ -234,6 +238,6 @@ extern "C" int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, c
     KOCR_TRY(crnn_forward(ctx, d_crops + (size_t)s * 31 * 200, nb, d_lab + (size_t)s * 48, nullptr));
   }
   KOCR_HIP(ctx, hipMemcpyAsync(labels, d_lab, lab_b, hipMemcpyDeviceToHost, ctx->stream));
-  KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return KOCR_OK;
+  KOCR_HIP(ctx, hipMemcpyAsync(&host_flags[4], d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  return finish();
 }

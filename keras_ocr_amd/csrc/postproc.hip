@@ -604,7 +604,7 @@ dim3 grid_for(size_t n, int block = 256) {
 // Returns KOCR_OK, or KOCR_ECAPACITY (counts still filled with the true numbers).
 int postproc_get_boxes(kocr_ctx* ctx, const float* d_heat, int N, int h, int w, float det_thr,
                        float text_thr, float link_thr, int size_thr, float* d_boxes, int cap,
-                       int* h_counts, int* n_empty_out) {
+                       int* h_counts, int* n_empty_out, PPDeviceOut* dev) {
   if (n_empty_out) *n_empty_out = 0;
   if (N <= 0) return KOCR_OK;
   if (h <= 0 || w <= 0 || h > 4096 || w > 4096)
@@ -645,6 +645,10 @@ int postproc_get_boxes(kocr_ctx* ctx, const float* d_heat, int N, int h, int w, 
   p.img_base = (int*)A((size_t)(N + 1) * 4);
   p.totals = (int*)A(64);
   if (!p.totals) KOCR_FAIL(ctx, KOCR_ENOMEM, "kocr_get_boxes: scratch exhausted");
+  if (dev) {
+    dev->d_counts = p.counts;
+    dev->d_totals = p.totals;
+  }
 
   const double hb = 8.0 * NP;
   {
@@ -710,7 +714,7 @@ int postproc_get_boxes(kocr_ctx* ctx, const float* d_heat, int N, int h, int w, 
     hipLaunchKernelGGL(k_boxes, grid_for(ncomp, 64), dim3(64), 0, s, a);
   }
   KOCR_HIP(ctx, hipGetLastError());
-  if (n_empty_out) {
+  if (n_empty_out && !dev) {
     KOCR_HIP(ctx, hipMemcpyAsync(totals, p.totals, 16, hipMemcpyDeviceToHost, s));
     KOCR_HIP(ctx, hipStreamSynchronize(s));
     *n_empty_out = totals[2];

@@ -2,7 +2,6 @@
 polygon IoU and precision/recall scoring of pipeline output.  SURVEY.md §8(f) item 4 — off the hot
 path, pure numpy/Python: pyclipper, cv2.contourArea and editdistance are re-stated (simple polygons
 are triangulated by ear clipping and intersected triangle by triangle with Sutherland-Hodgman)."""
-import copy
 import typing
 import warnings
 
@@ -116,50 +115,45 @@ def _edit_distance(a, b):
     return prev[-1]
 
 
+def _text_similarity(a, b):
+    """1 - normalised Levenshtein distance (evaluation.py:119-127); two empty strings are identical."""
+    longest = max(len(a), len(b))
+    return 1 if longest == 0 else 1 - _edit_distance(a, b) / longest
+
+
 def score(true, pred, iou_threshold=0.5, similarity_threshold=0.5, translator=None):
-    """evaluation.score (evaluation.py:56-147): same arguments, same return value
-    ``(results, (precision, recall))``."""
-    true_ids = sorted(true)
-    pred_ids = sorted(pred)
-    assert all(true_id == pred_id for true_id, pred_id in zip(true_ids, pred_ids)), \
-        "true and pred dictionaries must have the same keys"
-    results: typing.Dict[str, typing.List[dict]] = {
-        "true_positives": [], "false_positives": [], "near_true_positives": [], "false_negatives": []}
-    for image_id in true_ids:
-        true_anns = true[image_id]
-        pred_anns = copy.deepcopy(pred[image_id])
-        pred_matched = set()
-        for true_index, true_ann in enumerate(true_anns):
-            match = None
-            for pred_index, pred_ann in enumerate(pred_anns):
-                iou = iou_score(true_ann["vertices"], pred_ann["vertices"])
-                if iou >= iou_threshold:
-                    match = {"true_idx": true_index, "pred_idx": pred_index, "image_id": image_id}
-                    pred_matched.add(pred_index)
-                    true_text = true_ann["text"]
-                    pred_text = pred_ann["text"]
-                    if true_ann.get("ignore", False):
-                        continue
-                    if translator is not None:
-                        true_text = true_text.translate(translator)
-                        pred_text = pred_text.translate(translator)
-                    edit_distance_norm = max(len(true_text), len(pred_text))
-                    if edit_distance_norm == 0:
-                        similarity = 1
-                    else:
-                        similarity = 1 - (_edit_distance(true_text, pred_text) / edit_distance_norm)
-                    if similarity >= similarity_threshold:
-                        results["true_positives"].append(match)
-                    else:
-                        results["near_true_positives"].append(match)
-            if match is None and not true_ann.get("ignore", False):
-                results["false_negatives"].append({"image_id": image_id, "true_idx": true_index})
-        results["false_positives"].extend(
-            {"pred_index": pred_index, "image_id": image_id}
-            for pred_index, _ in enumerate(pred_anns) if pred_index not in pred_matched)
-    fns = len(results["false_negatives"])
-    fps = len(results["false_positives"])
-    tps = len(set((tp["image_id"], tp["true_idx"]) for tp in results["true_positives"]))
-    precision = tps / (tps + fps)
-    recall = tps / (tps + fns)
-    return results, (precision, recall)
+    """evaluation.score (evaluation.py:56-147): detection + recognition precision / recall.
+
+    ``true`` / ``pred``: ``{image_id: [{"text", "vertices"[, "ignore"]}]}`` with the same keys.  Returns
+    ``(results, (precision, recall))``; ``results`` lists ``true_positives`` / ``near_true_positives`` (one entry per
+    (truth, prediction) pair whose IoU reaches ``iou_threshold``, split by text similarity), ``false_negatives``
+    (truths no prediction overlaps) and ``false_positives`` (predictions overlapping no truth).  An ``ignore``d truth
+    absorbs the predictions it overlaps and is itself never counted.  Precision and recall count distinct matched
+    truths, as the reference does (so two predictions on one truth are one true positive).
+
+    Written as: IoU table per image -> pair classification -> bookkeeping (the reference interleaves the three)."""
+    image_ids = sorted(true)
+    assert all(a == b for a, b in zip(image_ids, sorted(pred))), "true and pred dictionaries must have the same keys"
+    clean = (lambda t: t.translate(translator)) if translator is not None else (lambda t: t)
+    results = {"true_positives": [], "false_positives": [], "near_true_positives": [], "false_negatives": []}
+    for image_id in image_ids:
+        truths, preds = true[image_id], pred[image_id]
+        overlaps = [[iou_score(t["vertices"], p["vertices"]) >= iou_threshold for p in preds] for t in truths]
+        for ti, (truth, row) in enumerate(zip(truths, overlaps)):
+            ignored = bool(truth.get("ignore", False))
+            partners = [pi for pi, hit in enumerate(row) if hit]
+            if not partners:
+                if not ignored:
+                    results["false_negatives"].append({"image_id": image_id, "true_idx": ti})
+                continue
+            if ignored:
+                continue
+            for pi in partners:
+                pair = {"true_idx": ti, "pred_idx": pi, "image_id": image_id}
+                good = _text_similarity(clean(truth["text"]), clean(preds[pi]["text"])) >= similarity_threshold
+                results["true_positives" if good else "near_true_positives"].append(pair)
+        claimed = {pi for row in overlaps for pi, hit in enumerate(row) if hit}
+        results["false_positives"] += [{"pred_index": pi, "image_id": image_id} for pi in range(len(preds)) if pi not in claimed]
+    n_fn, n_fp = len(results["false_negatives"]), len(results["false_positives"])
+    n_tp = len({(m["image_id"], m["true_idx"]) for m in results["true_positives"]})
+    return results, (n_tp / (n_tp + n_fp), n_tp / (n_tp + n_fn))

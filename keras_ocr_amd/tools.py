@@ -70,15 +70,100 @@ def adjust_boxes(boxes, scale=1, boxes_format="boxes"):
     raise NotImplementedError(f"Unsupported boxes format: {boxes_format}")
 
 
-def warpBox(image, box, target_height=None, target_width=None, ctx=None):  # pylint: disable=invalid-name
-    """tools.warpBox (tools.py:61-117) for the recogniser's use: RGB image -> gray crop, uint8."""
-    assert target_width is not None and target_height is not None, \
-        "keras-ocr_amd warps to a fixed target size (the recogniser's input)."
+def get_rotated_width_height(box):
+    """tools.get_rotated_width_height (tools.py:41-57): integer mean of opposite side lengths of [tl, tr, br, bl]."""
+    p = np.asarray(box, dtype=np.float64)
+    side = lambda i, j: float(np.sqrt(((p[i] - p[j]) ** 2).sum()))  # noqa: E731
+    return int((side(0, 1) + side(2, 3)) / 2), int((side(0, 3) + side(1, 2)) / 2)
+
+
+def _min_area_rectangle(points):
+    """What shapely's ``MultiPoint(points).minimum_rotated_rectangle`` returns for the 4 box points (tools.py:543-547):
+    the smallest rectangle having a side on the convex hull.  Degenerate input -> None (the reference's
+    AttributeError fallback to the raw points, :548-550)."""
+    pts = sorted({(float(x), float(y)) for x, y in np.asarray(points, dtype=np.float64)})
+    if len(pts) < 3:
+        return None
+    turn = lambda o, a, b: (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])  # noqa: E731
+    hull = []
+    for seq in (pts, pts[::-1]):
+        chain = []
+        for q in seq:
+            while len(chain) >= 2 and turn(chain[-2], chain[-1], q) <= 0:
+                chain.pop()
+            chain.append(q)
+        hull += chain[:-1]
+    if len(hull) < 3:
+        return None
+    h = np.array(hull)
+    best = None
+    for i in range(len(h)):
+        edge = h[(i + 1) % len(h)] - h[i]
+        ux, uy = edge / np.sqrt((edge ** 2).sum())
+        u, v = h[:, 0] * ux + h[:, 1] * uy, -h[:, 0] * uy + h[:, 1] * ux
+        area = (u.max() - u.min()) * (v.max() - v.min())
+        if best is None or area < best[0]:
+            best = (area, ux, uy, u.min(), u.max(), v.min(), v.max())
+    _, ux, uy, u0, u1, v0, v1 = best
+    return np.array([[u * ux - v * uy, u * uy + v * ux] for u, v in ((u0, v0), (u1, v0), (u1, v1), (u0, v1))])
+
+
+def get_rotated_box(points):
+    """tools.get_rotated_box (tools.py:533-581) -> (box float32 [tl, tr, br, bl], rotation in radians)."""
+    rect = _min_area_rectangle(points)
+    pts = np.asarray(points) if rect is None else rect
+    by_x = pts[np.argsort(pts[:, 0], kind="stable")]
+    left = by_x[:2][np.argsort(by_x[:2, 1], kind="stable")]
+    tl, bl = left
+    right = by_x[2:]
+    far_first = right[np.argsort(np.sqrt(((right.astype(np.float64) - tl.astype(np.float64)) ** 2).sum(1)), kind="stable")[::-1]]
+    br, tr = far_first
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rotation = np.arctan((tl[0] - bl[0]) / (tl[1] - bl[1]))
+    return np.array([tl, tr, br, bl], dtype="float32"), rotation
+
+
+def warpBox(image, box, target_height=None, target_width=None, margin=0, cval=None, return_transform=False,  # pylint: disable=invalid-name
+            skip_rotate=False, ctx=None):
+    """tools.warpBox (tools.py:61-117), full signature: warp the quadrilateral ``box`` of ``image`` (HxW or HxWx3
+    uint8) into a ``target_height x target_width`` rectangle (default: the box's own integer size), ``margin`` pixels
+    inside it, the rest filled with ``cval``.  The homography and the warp run on the GPU (kocr_warp_quads); an RGB
+    image is warped channel by channel with the same fixed-point arithmetic cv2.warpPerspective applies per channel."""
+    if cval is None:
+        cval = (0, 0, 0) if len(image.shape) == 3 else 0
+    if not skip_rotate:
+        box, _ = get_rotated_box(box)
+    box = np.asarray(box, dtype=np.float32)
+    w, h = get_rotated_width_height(box)
+    assert (target_width is None and target_height is None) or (target_width is not None and target_height is not None), \
+        "Either both or neither of target width and height must be provided."
+    if target_width is None and target_height is None:
+        target_width, target_height = w, h
+    scale = min(target_width / w, target_height / h)  # ZeroDivisionError for an empty box, as in the reference
+    dst = np.array([[margin, margin], [scale * w - margin, margin], [scale * w - margin, scale * h - margin],
+                    [margin, scale * h - margin]]).astype("float32")
+    dsize = (int(scale * w), int(scale * h))
     ctx = ctx or _lib.default_context()
+    image = np.asarray(image)
+    if image.dtype != np.uint8:
+        raise TypeError("warpBox expects a uint8 image")
+    # channel c as a gray RGB image: OpenCV's RGB->gray of (v, v, v) is v, so the crop is channel c's warp, bit for bit
+    planes = [image] if image.ndim == 2 else [image[..., c] for c in range(image.shape[2])]
+    stack = np.stack([np.repeat(p[..., None], 3, -1) for p in planes])
+    n = len(planes)
+    crops, tf = ctx.warp_quads(stack, [box] * n, [dst] * n, np.arange(n), [dsize] * n, int(target_height),
+                               int(target_width), return_transforms=True)
+    crops = np.rint(crops * 255).astype(np.uint8)
+    target_shape = (target_height, target_width, 3) if len(image.shape) == 3 else (target_height, target_width)
+    full = (np.zeros(target_shape) + cval).astype("uint8")
+    ch, cw = min(dsize[1], target_height), min(dsize[0], target_width)
     if image.ndim == 2:
-        image = np.repeat(image[..., None], 3, -1)
-    crops = ctx.warp_crops(image[np.newaxis], [np.asarray(box, np.float32)[np.newaxis]], target_height, target_width)
-    return np.rint(crops[0] * 255).astype(np.uint8)
+        full[:ch, :cw] = crops[0, :ch, :cw]
+    else:
+        full[:ch, :cw] = np.moveaxis(crops[:, :ch, :cw], 0, -1)
+    if return_transform:
+        return full, tf[0]
+    return full
 
 
 def fit_params(shape, width, height, mode="letterbox"):
@@ -100,17 +185,21 @@ def fit_params(shape, width, height, mode="letterbox"):
 
 
 def fit(image, width: int, height: int, cval: int = 255, mode="letterbox", return_scale=False, ctx=None):
-    """tools.fit (tools.py:402-452), letterbox mode: cv2.resize + paste on a cval canvas, on the GPU."""
+    """tools.fit (tools.py:402-452), modes "letterbox" and "crop": cv2.resize on the GPU + paste / window."""
     prm = fit_params(image.shape, width, height, mode)
     if prm is None:
         fitted, scale = image, 1
     else:
         resize_width, resize_height, scale = prm
-        if mode != "letterbox":
-            raise NotImplementedError(f"Unsupported mode: {mode}")
         ctx = ctx or _lib.default_context()
-        # letterbox: one side equals the target, the other is not larger
-        fitted = ctx.resize_pad(image[np.newaxis], (resize_width, resize_height), out_hw=(height, width), cval=cval)[0]
+        if mode == "letterbox":
+            # one side equals the target, the other is not larger: resized image pasted top-left on a cval canvas
+            fitted = ctx.resize_pad(image[np.newaxis], (resize_width, resize_height), out_hw=(height, width), cval=cval)[0]
+        elif mode == "crop":
+            # one side equals the target, the other is not smaller: the top-left height x width window of the resize
+            fitted = ctx.resize_pad(image[np.newaxis], (resize_width, resize_height))[0][:height, :width]
+        else:
+            raise NotImplementedError(f"Unsupported mode: {mode}")
     if not return_scale:
         return fitted
     return fitted, scale
@@ -174,24 +263,25 @@ def drawBoxes(image, boxes, color=(255, 0, 0), thickness=5, boxes_format="boxes"
 
 
 def drawAnnotations(image, predictions, ax=None):  # pylint: disable=invalid-name
-    """tools.drawAnnotations (tools.py:150-186): boxes + arrowed text labels on a matplotlib axis."""
+    """tools.drawAnnotations (tools.py:150-186): the image with its boxes, every word written in the left or right
+    margin (whichever side its box starts on), top to bottom, with an arrow to the box's first corner."""
     import matplotlib.pyplot as plt  # pylint: disable=import-outside-toplevel
 
     if ax is None:
         _, ax = plt.subplots()
     ax.imshow(drawBoxes(image=image, boxes=predictions, boxes_format="predictions"))
-    predictions = sorted(predictions, key=lambda p: p[1][:, 1].min())
-    left, right = [], []
-    for word, box in predictions:
-        (left if box[:, 0].min() < image.shape[1] / 2 else right).append((word, box))
-    ax.set_yticks([])
     ax.set_xticks([])
-    for side, group in zip(["left", "right"], [left, right]):
-        for index, (text, box) in enumerate(group):
-            y = 1 - (index / len(group))
-            xy = box[0] / np.array([image.shape[1], image.shape[0]])
-            xy[1] = 1 - xy[1]
-            ax.annotate(text=text, xy=xy, xytext=(-0.05 if side == "left" else 1.05, y), xycoords="axes fraction",
+    ax.set_yticks([])
+    height, width = image.shape[:2]
+    columns = {"left": [], "right": []}
+    for word, box in sorted(predictions, key=lambda wb: wb[1][:, 1].min()):
+        columns["left" if box[:, 0].min() < width / 2 else "right"].append((word, box))
+    label_x = {"left": -0.05, "right": 1.05}
+    align = {"left": "right", "right": "left"}
+    for side, entries in columns.items():
+        for rank, (word, box) in enumerate(entries):
+            anchor = (box[0, 0] / width, 1 - box[0, 1] / height)  # axes fraction, y upwards
+            ax.annotate(text=word, xy=anchor, xytext=(label_x[side], 1 - rank / len(entries)), xycoords="axes fraction",
                         arrowprops={"arrowstyle": "->", "color": "r"}, color="r", fontsize=14,
-                        horizontalalignment="right" if side == "left" else "left")
+                        horizontalalignment=align[side])
     return ax

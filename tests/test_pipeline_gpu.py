@@ -130,16 +130,35 @@ def test_end_to_end_vs_oracle(pipe, ctx, calibrated, crnn_weights):
     assert report["flipped_pixels"] <= 2
 
 
-def test_recognizer_single_image_api(pipe):
-    """Recognizer.recognize (recognition.py:467-489) == recognize_from_boxes on the letterboxed image."""
-    img = synth.text_page(40, 180, 3, seed=4)
-    s = pipe.recognizer.recognize(img)
-    assert isinstance(s, str)
+def test_recognizer_single_image_api(pipe, crnn_weights):
+    """Recognizer.recognize (recognition.py:467-489) against the oracle: letterbox with cval 0 (tools.fit :402-452,
+    cv2.resize restated), RGB->gray, /255, CRNN, CTC -- identical string wherever the oracle's argmax margin is safe."""
+    from oracle import crnn as ocrnn, tools as otools
+
+    import keras_ocr_amd
+    n_checked = 0
+    for seed, shape in ((4, (40, 180)), (5, (31, 200)), (6, (62, 400)), (7, (25, 90))):
+        img = synth.text_page(shape[0], shape[1], 3, seed=seed)
+        got = pipe.recognizer.recognize(img)
+        assert isinstance(got, str)
+        prm = keras_ocr_amd.tools.fit_params(img.shape, 200, 31)
+        if prm is None:
+            fitted = img
+        else:
+            resized = otools.cv_resize_linear_u8(img, (prm[0], prm[1]))
+            fitted = np.zeros((31, 200, 3), np.uint8)
+            fitted[:resized.shape[0], :resized.shape[1]] = resized[:31, :200]
+        x = otools.rgb2gray_u8(fitted).astype(np.float32)[None, ..., None] / 255
+        probs = ocrnn.crnn_forward(crnn_weights, x)
+        srt = np.sort(probs, -1)
+        if ((srt[..., -1] - srt[..., -2]) > 1e-3).all():
+            n_checked += 1
+            assert got == ocrnn.decode_strings(ocrnn.ctc_greedy_decode(probs))[0], shape
+    assert n_checked >= 2
     # an image that already has the model's input size goes through unchanged (tools.py:426-428)
     img2 = synth.text_page(31, 200, 3, seed=5)
-    s2 = pipe.recognizer.recognize(img2)
     box = np.array([[0, 0], [200, 0], [200, 31], [0, 31]], np.float32)
-    assert s2 == pipe.recognizer.recognize_from_boxes([img2], [box[None]])[0][0]
+    assert pipe.recognizer.recognize(img2) == pipe.recognizer.recognize_from_boxes([img2], [box[None]])[0][0]
 
 
 def test_device_resident_batch_equals_host_batch(pipe):

@@ -202,7 +202,7 @@ int kocr_craft_forward(kocr_ctx* ctx, const void* img, int dtype, int N, int H, 
   KOCR_HIP(ctx, hipSetDevice(ctx->device));
   int mb = micro_batch > 0 ? micro_batch : 32;  // Keras predict default batch_size (detection.py:779)
   // keep the per-micro-batch workspace under ~64 GiB of the 288 GB HBM
-  while (mb > 1 && craft_workspace_bytes(mb, H, W) > ((size_t)64 << 30)) mb = (mb + 1) / 2;
+  while (mb > 1 && craft_workspace_bytes(mb, H, W) > ((size_t)96 << 30)) mb = (mb + 1) / 2;
   mb = std::min(mb, N);
   const size_t esz = dtype == KOCR_U8 ? 1 : 4;
   const size_t in_img = (size_t)H * W * 3 * esz;

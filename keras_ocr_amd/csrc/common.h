@@ -77,6 +77,8 @@ struct ConvLayer {
   unsigned short* d_ws16 = nullptr;  // the same, 2-way fp16 split of U * 2^ws_wexp (fp16x2 mode)
   int ws_wexp = 0;
   int ws16_kb = 1;  // 16-channel blocks per K-step of the fp16 Winograd weights' layout (2 when Cin % 32 == 0)
+  unsigned short* d_w4 = nullptr;  // Winograd F(4,3) weights, 3-way bf16 split, conv_w43.hip order (Cout > 64, Cin % 32 == 0)
+  int w4_cout_pad = 0;
   unsigned short* d_ds = nullptr;  // direct-conv weights, 3-way bf16 split, conv_dsplit.hip order
   int ds_cout_pad = 0;
   unsigned short* d_ds16 = nullptr;  // 2-way fp16 split of w * 2^ds_wexp
@@ -205,6 +207,11 @@ int prepare_wsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
 bool wsplit_applicable(const ConvLayer& L, const Tensor& in);
 int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
                        bool need_full);
+// conv_w43.hip: Winograd F(4,3) on the bf16 cores (bf16x3 mode; 3.0 issued FLOPs per algorithmic FLOP instead of 4.0)
+int prepare_w43(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
+bool w43_applicable(const kocr_ctx* ctx, const ConvLayer& L, const Tensor& in);
+int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
+                    bool need_full);
 // conv_dsplit.hip
 int prepare_dsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
 bool dsplit_applicable(const ConvLayer& L, const Tensor& in);

@@ -492,6 +492,7 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
   KOCR_TRY(ctx->upload(&L.d_w, wp));
   KOCR_TRY(prepare_wino(ctx, L, w, w_is_oihw));
   KOCR_TRY(prepare_wsplit(ctx, L, w, w_is_oihw));
+  KOCR_TRY(prepare_w43(ctx, L, w, w_is_oihw));
   KOCR_TRY(prepare_dsplit(ctx, L, w, w_is_oihw));
   if (Cin == 3 && KH == 3 && KW == 3 && dil == 1) {  // uint8 first layer: K order [tap][R,G,B,0], 48 rows
     std::vector<float> w4((size_t)48 * L.Cout_pad, 0.f);
@@ -634,6 +635,8 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
                          conv_variant() != 10;
   if (!out.p) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": no output buffer");
   // bf16x3-split Winograd on the bf16 matrix cores (fp32-class accuracy, see conv_wsplit.hip)
+  if (!in_u8 && variant == 0 && conv_variant() == 0 && w43_applicable(ctx, L, in))
+    return launch_conv_w43(ctx, L, in, out, pool, need_full);
   if (!in_u8 && variant == 0 && conv_variant() == 0 && wsplit_applicable(L, in))
     return launch_conv_wsplit(ctx, L, in, out, pool, need_full);
   if (!in_u8 && variant == 0 && conv_variant() == 0 && dsplit_applicable(L, in)) {

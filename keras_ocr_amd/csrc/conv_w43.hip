@@ -9,20 +9,20 @@
 // per SIMD (256 threads, up to 512 VGPRs) and every wave both produces (gather, input transform, split, LDS fill:
 // VALU work that issues in the shadow of the wave's own MFMAs) and consumes.
 //
-// Algebra (Lavin & Gray, points 0, +-1, +-2, inf).  For the output quad (x0 .. x0+3) of a row and every (ky, c):
-//     d_i = in[y+ky-1][x0-1+i][c], i = 0..5
-//     V0 = 4 d0 - 5 d2 + d4            U0 = g0 / 4
-//     V1 = -4 (d1 + d2) + (d3 + d4)    U1 = -(g0 + g1 + g2) / 6
-//     V2 =  4 (d1 - d2) - (d3 - d4)    U2 = -(g0 - g1 + g2) / 6
-//     V3 = -2 (d1 - d3) - (d2 - d4)    U3 = g0 / 24 + g1 / 12 + g2 / 6
-//     V4 =  2 (d1 - d3) - (d2 - d4)    U4 = g0 / 24 - g1 / 12 + g2 / 6
-//     V5 = 4 d1 - 5 d3 + d5            U5 = g2
+// Algebra: Cook-Toom / Winograd F(4,3) with the interpolation points 0, +-a, +-b, inf, a = 5/8, b = 3/2 (the textbook
+// choice 0, +-1, +-2 amplifies the accumulators' fp32 round-off by up to 8 in the output transform; this symmetric
+// set keeps the cheap butterfly structure and has 30 % less error -- restated and compared in numpy in
+// tests/test_split_arith_cpu.py).  For the output quad (x0 .. x0+3) of a row and every (ky, c), with
+// d_i = in[y+ky-1][x0-1+i][c], i = 0..5 and taps g0, g1, g2:
+//     V0 = a^2 b^2 d0 - (a^2 + b^2) d2 + d4                      U0 = g0 / (a^2 b^2)
+//     V1,2 = (d4 - b^2 d2) +- a (d3 - b^2 d1)                    U1,2 = (g0 +- a g1 + a^2 g2) / (2 a^2 (a^2 - b^2))
+//     V3,4 = (d4 - a^2 d2) +- b (d3 - a^2 d1)                    U3,4 = (g0 +- b g1 + b^2 g2) / (2 b^2 (b^2 - a^2))
+//     V5 = a^2 b^2 d1 - (a^2 + b^2) d3 + d5                      U5 = g2
 //     M_xi[quad][o] = sum_{ky,c} V_xi U_xi
-//     out[x0]   = M0 + M1 + M2 + M3 + M4          out[x0+1] = (M1 - M2) + 2 (M3 - M4)
-//     out[x0+2] = (M1 + M2) + 4 (M3 + M4)         out[x0+3] = (M1 - M2) + 8 (M3 - M4) + M5
-// U is transformed in float64 on the host and rounded once.  fp32 error against an fp64 convolution: about 3x that
-// of F(2,3) / of a direct fp32 fma chain (tests/test_split_arith_cpu.py restates it in numpy), well inside the
-// bound tests/test_conv_gpu.py holds every split kernel to (1e-6 of |x| conv |w| elementwise, 1.5e-7 rms).
+//     out[x0]   = M0 + (M1 + M2) + (M3 + M4)                     out[x0+1] = a (M1 - M2) + b (M3 - M4)
+//     out[x0+2] = a^2 (M1 + M2) + b^2 (M3 + M4)                  out[x0+3] = a^3 (M1 - M2) + b^3 (M3 - M4) + M5
+// U is transformed in float64 on the host and rounded once.  fp32 error against an fp64 convolution: about 1.7x that
+// of F(2,3) / of a direct fp32 fma chain, inside the bound tests/test_conv_gpu.py states for this kernel.
 //
 // Block = 256 threads = 4 waves, persistent (one per CU).  Tile = 64 quads (256 pixels: two M-tiles of 32 quads) x
 // 128 couts; wave wn owns both M-tiles x couts [32 wn, 32 wn + 32) x 6 points = 192 accumulator VGPRs.  K-step = one
@@ -56,11 +56,22 @@ struct W4Params {
   float* pool_out;
   int pool_cs, pool_co, write_full, tiles_per_row;
   int total_tiles;
+  int n_mpairs;   // pixel tiles (pairs of M-tiles)
+  int dil;        // dilation d (DIL kernels: taps d apart; a quad = 4 outputs d apart in one residue class mod d)
+  int qpr;        // quads per image row = W / 4
+  int m_fastest;  // tile order: 1 = consecutive tiles share the cout block (weights stay in the XCD's L2)
   unsigned* amax_out;
   unsigned* amax_pool;
 };
 
 namespace {
+
+// interpolation points 0, +-a, +-b, inf (all constants exact in fp32)
+constexpr double W4_PA = 0.625, W4_PB = 1.5;
+constexpr float W4_A = (float)W4_PA, W4_B = (float)W4_PB;
+constexpr float W4_A2 = (float)(W4_PA * W4_PA), W4_B2 = (float)(W4_PB * W4_PB);
+constexpr float W4_A3 = (float)(W4_PA * W4_PA * W4_PA), W4_B3 = (float)(W4_PB * W4_PB * W4_PB);
+constexpr float W4_A2B2 = (float)(W4_PA * W4_PA * W4_PB * W4_PB), W4_A2PB2 = (float)(W4_PA * W4_PA + W4_PB * W4_PB);
 
 constexpr int KH_STRIDE = 256;               // ushorts: 32 rows x 8 channels
 constexpr int PLANE = 2 * 2 * KH_STRIDE;     // one (xi, piece) plane: 2 M-tiles x 2 k halves
@@ -83,6 +94,17 @@ __device__ __forceinline__ long w4_mtile_pm0(const W4Params& p, int mt, int& y0,
   }
 }
 
+// tile index -> (pixel tile, cout block)
+__device__ __forceinline__ void w4_decode(const W4Params& p, int tile, int nblk_n, int& mp, int& nt) {
+  if (p.m_fastest) {
+    nt = tile / p.n_mpairs;
+    mp = tile - nt * p.n_mpairs;
+  } else {
+    mp = tile / nblk_n;
+    nt = tile - mp * nblk_n;
+  }
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t w4_rsrc(const float* base, unsigned bytes) {
   const unsigned long long bb = (unsigned long long)base;
   const unsigned long long bbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)) << 32) |
@@ -92,7 +114,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t w4_rsrc(const float* base, uns
 
 }  // namespace
 
-template <int POOL>
+// DBG (developer timing experiments, wrong results; only instantiated with -DKOCR_DEV_SWITCHES): 1 = no input
+// transform / split VALU work, 2 = no weight stream, 4 = no MFMAs, 8 = no LDS operand fetches
+// DIL = 1: dilated 3x3 convolution (taps p.dil pixels apart in x and y, POOL = 0 only) -- the same F(4,3) algebra on
+// the comb of pixels x = r + d t: quad q of a row covers x0 + d j, j = 0..3, with x0 = (q / d) 4 d + q % d.
+template <int POOL, int DBG = 0, int DIL = 0>
 __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short As[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -109,66 +135,98 @@ __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
   // ------------------------------------------------------------------------------------------------
   const int qi = tid >> 2, q4 = tid & 3;
   const int ldst = ((qi >> 5) * 2 + (q4 >> 1)) * KH_STRIDE + ((((qi & 31) * 8) ^ ((q4 >> 1) * 32)) + (q4 & 1) * 4);
-  int L_ld = blockIdx.x, ld_ky = 0, ld_cg = 0;  // position of the NEXT K-step to load
-  unsigned goff[6];
-  int gy = 0;
-  bool gok = false;
-  __amdgpu_buffer_rsrc_t rsrc_in;
-  auto tile_geometry = [&]() __attribute__((always_inline)) {
-    const int tile = kocr_xcd_remap(L_ld < total ? L_ld : 0, total);
-    const int mtb = (tile / nblk_n) * 2;  // first of the tile's two M-tiles
+  // Gather geometry of a tile: raw-buffer byte offsets of the item's six pixels (an offset of 0x80000000 is out of
+  // range and the load returns 0: row / column zero padding and everything past the end), relative to a base one image
+  // row + one pixel before the tile's first pixel.  Two sets are alive: the tile being consumed and the next one --
+  // the loads run two K-steps ahead and cross the tile boundary first; the choice is a branch-free select so that the
+  // K loop stays one basic block chain without vector-memory waits at joins.
+  struct Geo {
+    unsigned goff[6];
+    int gy;
+    bool gok;
+    const float* base;
+  };
+  auto make_geo = [&](int L, Geo& g) __attribute__((always_inline)) {
+    int mp, nt_unused;
+    w4_decode(p, kocr_xcd_remap(L < total ? L : 0, total), nblk_n, mp, nt_unused);
+    const int mtb = mp * 2;  // first of the tile's two M-tiles
     int y0a, x0a, y0b, x0b;
     const long pm_a = w4_mtile_pm0<POOL>(p, mtb, y0a, x0a);
-    // resource based one image row + one pixel before the tile's first pixel: every valid offset is >= 0
-    rsrc_in = w4_rsrc(p.in + (pm_a * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs, 0x80000000u);
+    const int mt1 = mtb + 1 < p.total_mtiles ? mtb + 1 : mtb;
+    const long pm_b = w4_mtile_pm0<POOL>(p, mt1, y0b, x0b);
+    g.base = p.in + (pm_a * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
     const int m = qi >> 5, i = qi & 31;
-    const int mt = mtb + m;
-    const long pm = m ? w4_mtile_pm0<POOL>(p, mt < p.total_mtiles ? mt : mtb, y0b, x0b) : pm_a;
     int rel, x0;
     if constexpr (POOL) {
       const int row = i >> 4, qc = i & 15;
-      rel = (int)(pm - pm_a) + row * p.W + 4 * qc;
+      rel = (m ? (int)(pm_b - pm_a) : 0) + row * p.W + 4 * qc;
       x0 = (m ? x0b : x0a) + 4 * qc;
-      gy = (m ? y0b : y0a) + row;
-      gok = L_ld < total && mt < p.total_mtiles;
+      g.gy = (m ? y0b : y0a) + row;
+      g.gok = L < total && mtb + m < p.total_mtiles;
+    } else if constexpr (DIL) {
+      // quad index over all rows of the batch -> (row, quad of the row) -> comb position
+      const long q0 = (long)mtb * 32;                   // first quad of the tile
+      const long row_a = q0 / p.qpr;                    // the base row: offsets are relative to its first pixel
+      const long qg = q0 + qi;
+      const long row = qg / p.qpr;
+      const int qr = (int)(qg - row * p.qpr);
+      x0 = (qr / p.dil) * 4 * p.dil + qr % p.dil;
+      rel = (int)((row - row_a) * p.W) + x0;
+      g.gok = L < total && qg * 4 < p.Mtotal;
+      g.gy = (int)(row % p.H);
+      g.base = p.in + ((row_a * p.W) * p.in_cs + p.in_co) - (long)(p.dil * p.W + p.dil) * p.in_cs;
     } else {
       rel = 4 * qi;
-      const long g = pm_a + rel;
-      gok = L_ld < total && g < p.Mtotal;
-      x0 = (int)(g % p.W);
-      gy = (int)((g / p.W) % p.H);
+      const long gp = pm_a + rel;
+      g.gok = L < total && gp < p.Mtotal;
+      x0 = (int)(gp % p.W);
+      g.gy = (int)((gp / p.W) % p.H);
     }
+    const int dd = DIL ? p.dil : 1;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const bool pad = (k == 0 && x0 == 0) || (k == 5 && x0 + 4 >= p.W);  // column zero padding
-      goff[k] = pad ? OOB : (unsigned)(((rel + k) * p.in_cs + q4 * 4) * 4);
+      const bool pad = (k == 0 && x0 < dd) || (k == 5 && x0 + 4 * dd >= p.W);  // column zero padding
+      g.goff[k] = pad ? OOB : (unsigned)(((rel + k * dd) * p.in_cs + q4 * 4) * 4);
     }
   };
+  Geo gc, gn;
+  int ld_ky = 0, ld_cg = 0;  // position of the NEXT K-step to load inside its tile
+  bool ld_next = false;      // ... and whether that tile is already the next one
+  const int ncg = p.Cin >> 4;
   auto load_raw = [&](v4f (&raw)[6]) __attribute__((always_inline)) {
-    const int soff = (ld_ky * p.W * p.in_cs + ld_cg * 16) * 4;
-    const bool ok = gok && (unsigned)(gy + ld_ky - 1) < (unsigned)p.H;
+    const int dd = DIL ? p.dil : 1;
+    const int soff = (ld_ky * dd * p.W * p.in_cs + ld_cg * 16) * 4;
+    const int gy = ld_next ? gn.gy : gc.gy;
+    const bool ok = (ld_next ? gn.gok : gc.gok) & ((unsigned)(gy + dd * (ld_ky - 1)) < (unsigned)p.H);
+    const unsigned kill = ok ? 0u : OOB;  // valid offsets are < 2^31: OR-ing the top bit pushes the load out of range
+    const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
 #pragma unroll
     for (int k = 0; k < 6; ++k)
-      raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, ok ? goff[k] : OOB, soff, 0));
-    if (++ld_ky == 3) {
-      ld_ky = 0;
-      if (++ld_cg == (p.Cin >> 4)) {  // next tile
-        ld_cg = 0;
-        L_ld += G;
-        tile_geometry();
-      }
-    }
+      raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (ld_next ? gn.goff[k] : gc.goff[k]) | kill, soff, 0));
+    const bool wrap_ky = ld_ky == 2;
+    ld_ky = wrap_ky ? 0 : ld_ky + 1;
+    const bool wrap_cg = wrap_ky && ld_cg == ncg - 1;
+    ld_cg = wrap_cg ? 0 : (wrap_ky ? ld_cg + 1 : ld_cg);
+    ld_next = ld_next || wrap_cg;
   };
   // input transform of point xi (fp32, fixed operation order), split, 3 x 8 bytes into LDS
   auto produce_point = [&](const v4f (&d)[6], unsigned short* bufp, int xi) __attribute__((always_inline)) {
+    if constexpr (DBG & 1) {
+      unsigned short* dst0 = bufp + xi * 3 * PLANE + ldst;
+      const u2v r = __builtin_bit_cast(u2v, __builtin_shufflevector(d[xi], d[xi], 0, 1));
+      *reinterpret_cast<u2v*>(dst0) = r;
+      *reinterpret_cast<u2v*>(dst0 + PLANE) = r;
+      *reinterpret_cast<u2v*>(dst0 + 2 * PLANE) = r;
+      return;
+    }
     v4f V;
     switch (xi) {
-      case 0: V = (4.f * d[0] - 5.f * d[2]) + d[4]; break;
-      case 1: V = (d[3] + d[4]) - 4.f * (d[1] + d[2]); break;
-      case 2: V = 4.f * (d[1] - d[2]) - (d[3] - d[4]); break;
-      case 3: V = -2.f * (d[1] - d[3]) - (d[2] - d[4]); break;
-      case 4: V = 2.f * (d[1] - d[3]) - (d[2] - d[4]); break;
-      default: V = (4.f * d[1] - 5.f * d[3]) + d[5]; break;
+      case 0: V = (W4_A2B2 * d[0] - W4_A2PB2 * d[2]) + d[4]; break;
+      case 1: V = (d[4] - W4_B2 * d[2]) + W4_A * (d[3] - W4_B2 * d[1]); break;
+      case 2: V = (d[4] - W4_B2 * d[2]) - W4_A * (d[3] - W4_B2 * d[1]); break;
+      case 3: V = (d[4] - W4_A2 * d[2]) + W4_B * (d[3] - W4_A2 * d[1]); break;
+      case 4: V = (d[4] - W4_A2 * d[2]) - W4_B * (d[3] - W4_A2 * d[1]); break;
+      default: V = (W4_A2B2 * d[1] - W4_A2PB2 * d[3]) + d[5]; break;
     }
     u2v h, m, l;
     kocr_split4(V, h, m, l);
@@ -188,6 +246,7 @@ __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
   f16v acc[6][2];
   const int a_lane = l5 * KH_STRIDE + ((l31 * 8) ^ (l5 * 32));
   auto load_a = [&](bf8 (&a)[2][3], const unsigned short* bufp, int xi) __attribute__((always_inline)) {
+    if constexpr (DBG & 8) return;
     const unsigned short* base = bufp + xi * 3 * PLANE + a_lane;
 #pragma unroll
     for (int s = 2; s >= 0; --s)
@@ -195,6 +254,13 @@ __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
       for (int m = 0; m < 2; ++m) a[m][s] = *reinterpret_cast<const bf8*>(base + s * PLANE + m * 2 * KH_STRIDE);
   };
   auto mfma12 = [&](const bf8 (&a)[2][3], int xi) __attribute__((always_inline)) {
+    if constexpr (DBG & 4) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) acc[xi][m][s] += __builtin_bit_cast(v4f, a[m][s])[0] + __builtin_bit_cast(v4f, bw[xi][s])[0];
+      return;
+    }
     const bf8 b0 = bw[xi][0], b1 = bw[xi][1], b2 = bw[xi][2];
     // smallest terms first; the two M-tiles alternate so consecutive MFMAs are independent
 #pragma unroll
@@ -210,24 +276,54 @@ __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b0, acc[xi][m], 0, 0, 0);
   };
-  // One K-step: consume `bufc` (6 points x 12 MFMAs) while producing the NEXT step from `raw` into `bufn`; the
-  // weights of a point are re-fetched (next K-step) as soon as its MFMAs are issued.  a0 holds point 0 on entry.
+  // One K-step: consume `bufc` (6 points x 12 MFMAs) while producing the NEXT step from `raw` into `bufn`.  Per point:
+  // fetch the next point's A operands from LDS, transform + split + store one point of the next step (VALU work that
+  // issues in the shadow of this point's MFMAs -- the group barriers interleave 1 MFMA : 3 VALU), 12 MFMAs, then
+  // re-fetch this point's weights for the next K-step (a full step ahead; the fences pin that order).  The block
+  // barrier that publishes the next step sits BEFORE the last point's MFMAs: by then this wave has stored all six
+  // points and all its reads of `bufc` have landed, so the next step's first operands are fetched behind 12 MFMAs
+  // instead of exposing the LDS latency after the barrier.  a0 holds point 0 on entry and on exit (of the next step).
   bf8 a0[2][3], a1[2][3];
   auto step = [&](const unsigned short* bufc, unsigned short* bufn, const v4f (&raw)[6],
                   const unsigned short* w_next) __attribute__((always_inline)) {
     auto load_b = [&](int xi) __attribute__((always_inline)) {
+      if constexpr (DBG & 2) return;
 #pragma unroll
       for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w_next + (size_t)(xi * 3 + s) * 64 * 8);
     };
+    auto interleave = [&]() __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);  // the 6 LDS fetches of the next point first
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // 3 VALU
+      }
+      __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);  // the point's 3 LDS stores
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    };
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
+      __builtin_amdgcn_sched_barrier(0);
       load_a(a1, bufc, 2 * q + 1);
       produce_point(raw, bufn, 2 * q);
       mfma12(a0, 2 * q);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
       load_b(2 * q);
-      if (q < 2) load_a(a0, bufc, 2 * q + 2);
-      produce_point(raw, bufn, 2 * q + 1);
-      mfma12(a1, 2 * q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q < 2) {
+        load_a(a0, bufc, 2 * q + 2);
+        produce_point(raw, bufn, 2 * q + 1);
+        mfma12(a1, 2 * q + 1);
+        interleave();
+      } else {
+        produce_point(raw, bufn, 5);
+        __syncthreads();  // next step complete in bufn, bufc free (waits for this wave's LDS traffic too)
+        load_a(a0, bufn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(a1, 5);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       load_b(2 * q + 1);
     }
   };
@@ -235,15 +331,15 @@ __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
   // ------------------------------------------------------------------------------------------------
   // pipeline prologue
   // ------------------------------------------------------------------------------------------------
-  const int my_tiles = (total - (int)blockIdx.x + G - 1) / G;
-  (void)my_tiles;
-  tile_geometry();
+  make_geo(blockIdx.x, gc);
+  make_geo(blockIdx.x + G, gn);
   v4f rawA[6], rawB[6];
   load_raw(rawA);  // global step 0
   load_raw(rawB);  // global step 1
   {
-    const int t0 = kocr_xcd_remap(blockIdx.x, total);
-    const unsigned short* w0 = w_tile(t0 % nblk_n);
+    int mp0, nt0;
+    w4_decode(p, kocr_xcd_remap(blockIdx.x, total), nblk_n, mp0, nt0);
+    const unsigned short* w0 = w_tile(nt0);
 #pragma unroll
     for (int xi = 0; xi < 6; ++xi)
 #pragma unroll
@@ -253,12 +349,15 @@ __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
   for (int xi = 0; xi < 6; ++xi) produce_point(rawA, As, xi);
   load_raw(rawA);  // global step 2
   __syncthreads();
+  load_a(a0, As, 0);
 
   for (int L = blockIdx.x; L < total; L += G) {
-    const int tile = kocr_xcd_remap(L, total);
-    const int mtb = (tile / nblk_n) * 2, nt = tile % nblk_n;
+    int mp, nt, mp_n, nt_n;
+    w4_decode(p, kocr_xcd_remap(L, total), nblk_n, mp, nt);
+    w4_decode(p, kocr_xcd_remap(L + G < total ? L + G : L, total), nblk_n, mp_n, nt_n);
+    const int mtb = mp * 2;
     const unsigned short* w_ptr = w_tile(nt);
-    const unsigned short* w_after = (L + G < total) ? w_tile(kocr_xcd_remap(L + G, total) % nblk_n) : w_ptr;
+    const unsigned short* w_after = w_tile(nt_n);
 #pragma unroll
     for (int x = 0; x < 6; ++x)
 #pragma unroll
@@ -267,19 +366,18 @@ __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
         for (int r = 0; r < 16; ++r) acc[x][m][r] = 0.f;
     // drain the previous tile's stores once here (their unknown count must not merge into the K loop's waits)
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    load_a(a0, As, 0);
     for (int s = 0; s < ns; s += 2) {
       // even global step: consume buffer 0, produce the odd step (rawB) into buffer 1, then refill rawB (step + 3)
       step(As, As + BUF, rawB, w_ptr + (size_t)(s + 1) * w_step);
       load_raw(rawB);
-      __syncthreads();
-      load_a(a0, As + BUF, 0);
       // odd global step: consume buffer 1, produce the next even step (rawA; possibly the next tile's first) into 0
       step(As + BUF, As, rawA, s + 2 < ns ? w_ptr + (size_t)(s + 2) * w_step : w_after);
       load_raw(rawA);
-      __syncthreads();
-      if (s + 2 < ns) load_a(a0, As, 0);
     }
+    // the loads are now inside the next tile: it becomes the current one
+    gc = gn;
+    make_geo(L + 2 * G, gn);
+    ld_next = false;
 
     // ---- epilogue: 32x32 C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----------------
     {
@@ -304,9 +402,9 @@ __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
                       m5 = acc[5][m][r];
           const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
           acc[0][m][r] = act((m0 + s12) + s34);
-          acc[1][m][r] = act(d12 + 2.f * d34);
-          acc[2][m][r] = act(s12 + 4.f * s34);
-          acc[3][m][r] = act((d12 + 8.f * d34) + m5);
+          acc[1][m][r] = act(W4_A * d12 + W4_B * d34);
+          acc[2][m][r] = act(W4_A2 * s12 + W4_B2 * s34);
+          acc[3][m][r] = act((W4_A3 * d12 + W4_B3 * d34) + m5);
         }
       const int ocs4 = p.out_cs * 4;
       if (p.amax_out || p.amax_pool) {
@@ -355,6 +453,25 @@ __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * p.pool_cs * 4, 0);
           }
         }
+      } else if constexpr (DIL) {
+        // per-register pixel offsets: quad (m, r, l5) of the tile -> (row, comb position), relative to the first
+        // pixel of the tile's base row; the quad's four outputs are p.dil pixels apart
+        const long q0 = (long)mtb * 32;
+        const long row_a = q0 / p.qpr;
+        const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + ((row_a * p.W) * p.out_cs + p.out_co), 0x7FFFFFFFu);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const long qg = q0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * l5;
+            const long row = qg / p.qpr;
+            const int qr = (int)(qg - row * p.qpr);
+            const int x0 = (qr / p.dil) * 4 * p.dil + qr % p.dil;
+            const unsigned vo = (live && qg * 4 < p.Mtotal) ? (unsigned)((((int)((row - row_a) * p.W) + x0) * p.out_cs + n) * 4) : OOB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vo, j * p.dil * ocs4, 0);
+          }
       } else {
         int yy, xx;
         const long pm0 = w4_mtile_pm0<POOL>(p, mtb, yy, xx);
@@ -381,7 +498,7 @@ __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
 // host side
 // ---------------------------------------------------------------------------------------
 int prepare_w43(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
-  if (L.KH != 3 || L.KW != 3 || L.dil != 1 || L.Cin % 32 != 0 || L.Cout <= 64) return KOCR_OK;
+  if (L.KH != 3 || L.KW != 3 || L.Cin % 32 != 0 || L.Cout <= 64) return KOCR_OK;  // any dilation: the taps' algebra is the same
   const int Cin = L.Cin, Cout = L.Cout;
   const int cp = (Cout + 127) / 128 * 128;
   const int nt32 = cp / 32;
@@ -393,11 +510,13 @@ int prepare_w43(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
         for (int kx = 0; kx < 3; ++kx)
           g[kx] = w_is_oihw ? w[(((size_t)o * Cin + c) * 3 + ky) * 3 + kx] : w[(((size_t)ky * 3 + kx) * Cin + c) * Cout + o];
         // G g in float64, rounded once to fp32
-        const float U[6] = {(float)(g[0] / 4.0),
-                            (float)(-(g[0] + g[1] + g[2]) / 6.0),
-                            (float)(-(g[0] - g[1] + g[2]) / 6.0),
-                            (float)(g[0] / 24.0 + g[1] / 12.0 + g[2] / 6.0),
-                            (float)(g[0] / 24.0 - g[1] / 12.0 + g[2] / 6.0),
+        const double pa = W4_PA, pb = W4_PB, a2 = pa * pa, b2 = pb * pb;
+        const double na = 2.0 * a2 * (a2 - b2), nb = 2.0 * b2 * (b2 - a2);
+        const float U[6] = {(float)(g[0] / (a2 * b2)),
+                            (float)((g[0] + pa * g[1] + a2 * g[2]) / na),
+                            (float)((g[0] - pa * g[1] + a2 * g[2]) / na),
+                            (float)((g[0] + pb * g[1] + b2 * g[2]) / nb),
+                            (float)((g[0] - pb * g[1] + b2 * g[2]) / nb),
                             (float)g[2]};
         // MFMA 32x32x16 B operand: lane = (k >> 3) * 32 + (o & 31) holds k = 8 (lane >> 5) + j, j = 0..7
         const int k = c % 16, lane = (k >> 3) * 32 + (o & 31), j = k & 7;
@@ -418,16 +537,16 @@ int prepare_w43(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
 
 bool w43_applicable(const kocr_ctx* ctx, const ConvLayer& L, const Tensor& in) {
   static const bool off = getenv("KOCR_W43") && atoi(getenv("KOCR_W43")) == 0;
-  return !off && ctx->split_mode == KOCR_SPLIT_BF16X3 && L.d_w4 && in.W % 4 == 0 && in.cs % 4 == 0 && in.co % 4 == 0 &&
-         ((uintptr_t)in.p & 15) == 0 && L.Cin % 32 == 0;
+  return !off && ctx->split_mode == KOCR_SPLIT_BF16X3 && L.d_w4 && in.W % (4 * L.dil) == 0 && in.cs % 4 == 0 &&
+         in.co % 4 == 0 && ((uintptr_t)in.p & 15) == 0 && L.Cin % 32 == 0 && (size_t)in.pixels() < ((size_t)1 << 29);
 }
 
-template <int POOL>
+template <int POOL, int DBG = 0, int DIL = 0>
 static int w4_launch(kocr_ctx* ctx, W4Params& p) {
   static bool attr_done[64] = {};  // per device: one process may hold contexts on several GPUs
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
-    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43_kernel<POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43_kernel<POOL, DBG, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done[dev] = true;
   }
   static int n_cus[64] = {};
@@ -437,13 +556,13 @@ static int w4_launch(kocr_ctx* ctx, W4Params& p) {
     n_cus[dev] = prop.multiProcessorCount;
   }
   const int grid = p.total_tiles < n_cus[dev] ? p.total_tiles : n_cus[dev];  // persistent: one block per CU
-  hipLaunchKernelGGL((conv_w43_kernel<POOL>), dim3(grid), dim3(256), LDS_BYTES, ctx->stream, p);
+  hipLaunchKernelGGL((conv_w43_kernel<POOL, DBG, DIL>), dim3(grid), dim3(256), LDS_BYTES, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }
 
 int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool, bool need_full) {
-  const bool fuse = pool && in.H % 2 == 0 && in.W % 64 == 0;
+  const bool fuse = pool && L.dil == 1 && in.H % 2 == 0 && in.W % 64 == 0;
   const size_t M = in.pixels();
   W4Params p;
   p.in = in.p;
@@ -466,6 +585,8 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   p.nsteps = 3 * (L.Cin / 16);
   p.Mtotal = (int)M;
   p.total_mtiles = (int)((M + 127) / 128);  // fuse: M % 128 == 0 (two rows x 64 columns)
+  p.dil = L.dil;
+  p.qpr = in.W / 4;
   p.pool_out = nullptr;
   p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
   p.amax_out = out.amax;
@@ -477,18 +598,49 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
     p.write_full = need_full ? 1 : 0;
     p.tiles_per_row = in.W / 64;
   }
-  p.total_tiles = ((p.total_mtiles + 1) / 2) * (p.Cout_pad / 128);
+  p.n_mpairs = (p.total_mtiles + 1) / 2;
+  p.total_tiles = p.n_mpairs * (p.Cout_pad / 128);
+  // Tile order.  The split weights of one cout block are Cin * 3 * 128 * 36 B; with every cout block of a deep layer in
+  // flight on an XCD they overflow its 4 MB L2 and are re-streamed from the Infinity Cache by every round of tiles.
+  // Pixel-tile-fastest order keeps ONE cout block per XCD at a time (measured +4 % on 512 -> 512, neutral below).
+  static const int mfast = getenv("KOCR_W43_MFAST") ? atoi(getenv("KOCR_W43_MFAST")) : -1;
+  p.m_fastest = mfast >= 0 ? mfast : ((size_t)L.Cin * L.w4_cout_pad * 3 * 36 > ((size_t)6 << 20) ? 1 : 0);
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_w4s_256x128%s:%s", fuse ? "p" : "", L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_w4s_256x128%s:%s", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_w4s_256x128%s", fuse ? "_pool" : "");
+    snprintf(nm, sizeof nm, "conv_w4s_256x128%s", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   {
     ProfScope ps(ctx, nm, flops, bytes);
-    if (fuse)
+#ifdef KOCR_DEV_SWITCHES
+    static const int dbg = getenv("KOCR_W43_DBG") ? atoi(getenv("KOCR_W43_DBG")) : 0;
+    if (dbg && !fuse) {
+      switch (dbg) {
+        case 1: return w4_launch<0, 1>(ctx, p);
+        case 2: return w4_launch<0, 2>(ctx, p);
+        case 3: return w4_launch<0, 3>(ctx, p);
+        case 4: return w4_launch<0, 4>(ctx, p);
+        case 5: return w4_launch<0, 5>(ctx, p);
+        case 6: return w4_launch<0, 6>(ctx, p);
+        case 7: return w4_launch<0, 7>(ctx, p);
+        case 8: return w4_launch<0, 8>(ctx, p);
+        case 9: return w4_launch<0, 9>(ctx, p);
+        case 10: return w4_launch<0, 10>(ctx, p);
+        case 11: return w4_launch<0, 11>(ctx, p);
+        case 12: return w4_launch<0, 12>(ctx, p);
+        case 13: return w4_launch<0, 13>(ctx, p);
+        case 14: return w4_launch<0, 14>(ctx, p);
+        case 15: return w4_launch<0, 15>(ctx, p);
+        default: break;
+      }
+    }
+#endif
+    if (L.dil != 1)
+      KOCR_TRY((w4_launch<0, 0, 1>(ctx, p)));
+    else if (fuse)
       KOCR_TRY(w4_launch<1>(ctx, p));
     else
       KOCR_TRY(w4_launch<0>(ctx, p));

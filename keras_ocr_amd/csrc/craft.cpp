@@ -9,6 +9,7 @@
 // concat kernel exists:  cat1 = [s5 | s4], cat2 = [up(y1) | s3], cat3 = [up(y2) | s2],
 // cat4 = [up(y3) | s1]  (detection.py:380-389).
 #include "common.h"
+#include <algorithm>
 #include <cmath>
 
 struct CraftNet {
@@ -149,65 +150,101 @@ struct Dims {
   }
 };
 size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
-}  // namespace
 
-size_t craft_workspace_bytes(int N, int H, int W) {
-  Dims d(H, W);
-  const size_t n = (size_t)N, f = sizeof(float);
-  size_t t = 0;
-  const size_t P1 = n * d.H * d.W, P2 = n * d.H2 * d.W2, P4 = n * d.H4 * d.W4, P8 = n * d.H8 * d.W8,
-               P16 = n * d.H16 * d.W16;
-  t += al(P1 * 64 * f) * 2;                     // slice1.0, slice1.3
-  t += al(P2 * 64 * f) + al(P2 * 128 * f);      // pool, slice1.7
-  t += al(P2 * 192 * f);                        // cat4
-  t += al(P4 * 128 * f) + al(P4 * 256 * f);     // pool, slice2.14
-  t += al(P4 * 384 * f);                        // cat3
-  t += al(P4 * 256 * f) + al(P8 * 256 * f);     // slice3.20, pool
-  t += al(P8 * 512 * f);                        // slice3.24
-  t += al(P8 * 768 * f);                        // cat2
-  t += al(P8 * 512 * f) + al(P16 * 512 * f);    // slice4.30, pool
-  t += al(P16 * 512 * f);                       // slice4.34
-  t += al(P16 * 1536 * f);                      // cat1
-  t += al(P16 * 512 * f) + al(P16 * 1024 * f);  // slice5.0, slice5.1
-  t += al(P16 * 512 * f) + al(P16 * 256 * f);   // upconv1
-  t += al(P8 * 256 * f) + al(P8 * 128 * f);     // upconv2
-  t += al(P4 * 128 * f) + al(P4 * 64 * f);      // upconv3
-  t += al(P2 * 64 * f) + al(P2 * 32 * f);       // upconv4
-  t += al(P2 * 32 * f) * 2 + al(P2 * 16 * f) * 2;  // conv_cls
-  return t + 4096;
-}
+// Activation memory by LIFETIME: every tensor is returned to the pool as soon as its last consumer has been
+// launched (one stream: launch order = execution order), so the peak live set -- the two full-resolution tensors
+// around slice1.3 plus the pooled one -- sizes the workspace, not the sum of all layers: 1.36 GB per 1536x1536 image
+// instead of 2.6 GB, which lets BASELINE's 32-image batches (and 2048x2048 inputs) run as ONE micro-batch.
+struct LivePool {
+  struct Blk {
+    size_t off, size;
+  };
+  std::vector<Blk> free_;  // sorted by offset, coalesced
+  size_t top = 0, peak = 0;
+  size_t alloc(size_t bytes) {
+    bytes = al(bytes);
+    for (size_t i = 0; i < free_.size(); ++i)
+      if (free_[i].size >= bytes) {  // first fit
+        const size_t off = free_[i].off;
+        free_[i].off += bytes;
+        free_[i].size -= bytes;
+        if (free_[i].size == 0) free_.erase(free_.begin() + i);
+        return off;
+      }
+    const size_t off = top;
+    top += bytes;
+    peak = std::max(peak, top);
+    return off;
+  }
+  void release(size_t off, size_t bytes) {
+    bytes = al(bytes);
+    size_t i = 0;
+    while (i < free_.size() && free_[i].off < off) ++i;
+    free_.insert(free_.begin() + i, Blk{off, bytes});
+    if (i + 1 < free_.size() && free_[i].off + free_[i].size == free_[i + 1].off) {
+      free_[i].size += free_[i + 1].size;
+      free_.erase(free_.begin() + i + 1);
+    }
+    if (i > 0 && free_[i - 1].off + free_[i - 1].size == free_[i].off) {
+      free_[i - 1].size += free_[i].size;
+      free_.erase(free_.begin() + i);
+    }
+    if (!free_.empty() && free_.back().off + free_.back().size == top) {
+      top = free_.back().off;
+      free_.pop_back();
+    }
+  }
+};
 
-int craft_forward(kocr_ctx* ctx, const void* d_img, int dtype, int N, int H, int W, float* d_heat) {
-  CraftNet* net = ctx->craft;
-  if (!net || !net->loaded) KOCR_FAIL(ctx, KOCR_ENOWEIGHTS, "kocr_craft_forward: call kocr_load_craft first");
-  if (N <= 0) return KOCR_OK;
-  if (H < 16 || W < 16) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_craft_forward: image smaller than 16x16");
+// The CRAFT graph, once: with DRY = true nothing is launched and only the pool's peak is computed (this IS
+// craft_workspace_bytes), with DRY = false the same allocation sequence runs against the ctx workspace.
+template <bool DRY>
+int craft_run(kocr_ctx* ctx, CraftNet* net, const void* d_img, int dtype, int N, int H, int W, float* d_heat, size_t* peak_out) {
   Dims d(H, W);
-  KOCR_TRY(ctx->amax_begin());
+  LivePool pool;
+  char* base = nullptr;
+  size_t room = 0;
+  if constexpr (!DRY) {
+    const size_t o = (ctx->ws.off + 255) & ~(size_t)255;
+    base = ctx->ws.base + o;
+    room = ctx->ws.cap > o ? ctx->ws.cap - o : 0;
+    KOCR_TRY(ctx->amax_begin());
+  }
   // every tensor produced by a convolution / pooling / up-sampling kernel carries a max-|x| slot
   // (Tensor::amax) so that an fp16-split consumer can pick its exact power-of-two input scale
+  std::map<const float*, std::pair<size_t, size_t>> live;  // tensor base -> (offset, bytes)
   auto mk = [&](int h, int w, int c, Tensor* t) -> int {
-    t->amax = ctx->amax_slot();
+    const size_t bytes = (size_t)N * h * w * c * sizeof(float);
+    const size_t off = pool.alloc(bytes);
     t->N = N;
     t->H = h;
     t->W = w;
     t->C = c;
     t->cs = c;
     t->co = 0;
-    t->p = (float*)ctx->ws_alloc((size_t)N * h * w * c * sizeof(float));
-    if (!t->p) KOCR_FAIL(ctx, KOCR_ENOMEM, "kocr_craft_forward: workspace exhausted");
+    if constexpr (DRY) {
+      t->amax = nullptr;
+      t->p = reinterpret_cast<float*>(off + 256);  // a distinct non-null key; never dereferenced
+    } else {
+      t->amax = ctx->amax_slot();
+      if (off + al(bytes) > room) KOCR_FAIL(ctx, KOCR_ENOMEM, "kocr_craft_forward: workspace exhausted");
+      t->p = reinterpret_cast<float*>(base + off);
+    }
+    live[t->p] = {off, bytes};
     return KOCR_OK;
   };
-  auto conv = [&](const char* name, const Tensor& in, const Tensor& out) -> int {
-    return launch_conv(ctx, net->L[name], in, nullptr, nullptr, out);
+  auto done = [&](const Tensor& t) {  // last consumer launched: the memory may be reused by later layers
+    auto it = live.find(t.p);
+    if (it != live.end()) {
+      pool.release(it->second.first, it->second.second);
+      live.erase(it);
+    }
   };
-
-  // conv + 2x2 max-pool: fused epilogue when the shape tiles (even H, W % 64 == 0), else two kernels.
-  // need_full: the pre-pool tensor is consumed elsewhere (skip connection).
-  auto conv_pool = [&](const char* name, const Tensor& in, const Tensor& full, const Tensor& pooled,
-                       bool need_full) -> int {
-    return launch_conv_pool(ctx, net->L[name], in, nullptr, nullptr, full, &pooled, need_full);
-  };
+#define RUN(expr)               \
+  do {                          \
+    if constexpr (!DRY) KOCR_TRY(expr); \
+  } while (0)
+  auto L = [&](const char* name) -> const ConvLayer& { return net->L.at(name); };
 
   Tensor x0;
   x0.N = N;
@@ -218,76 +255,127 @@ int craft_forward(kocr_ctx* ctx, const void* d_img, int dtype, int N, int H, int
   x0.co = 0;
   x0.p = (dtype == KOCR_F32) ? (float*)d_img : nullptr;
   const uint8_t* u8 = (dtype == KOCR_U8) ? (const uint8_t*)d_img : nullptr;
-
-  Tensor a1, a2, p1, b1, cat4, p2, c1, cat3, c3, p3, e1, cat2, f1, p4, g1, cat1, h0, h1;
-  KOCR_TRY(mk(d.H, d.W, 64, &a1));
-  KOCR_TRY(mk(d.H, d.W, 64, &a2));
-  KOCR_TRY(mk(d.H2, d.W2, 64, &p1));
-  KOCR_TRY(mk(d.H2, d.W2, 128, &b1));
-  KOCR_TRY(mk(d.H2, d.W2, 192, &cat4));
-  KOCR_TRY(mk(d.H4, d.W4, 128, &p2));
-  KOCR_TRY(mk(d.H4, d.W4, 256, &c1));
-  KOCR_TRY(mk(d.H4, d.W4, 384, &cat3));
-  KOCR_TRY(mk(d.H4, d.W4, 256, &c3));
-  KOCR_TRY(mk(d.H8, d.W8, 256, &p3));
-  KOCR_TRY(mk(d.H8, d.W8, 512, &e1));
-  KOCR_TRY(mk(d.H8, d.W8, 768, &cat2));
-  KOCR_TRY(mk(d.H8, d.W8, 512, &f1));
-  KOCR_TRY(mk(d.H16, d.W16, 512, &p4));
-  KOCR_TRY(mk(d.H16, d.W16, 512, &g1));
-  KOCR_TRY(mk(d.H16, d.W16, 1536, &cat1));
-  KOCR_TRY(mk(d.H16, d.W16, 512, &h0));
-  KOCR_TRY(mk(d.H16, d.W16, 1024, &h1));
+  const float* lut = DRY ? nullptr : net->d_lut;
 
   // ---- backbone (detection.py:312-335) ------------------------------------------------
-  KOCR_TRY(launch_conv(ctx, net->L["basenet.slice1.0"], x0, u8, net->d_lut, a1));
-  KOCR_TRY(conv_pool("basenet.slice1.3", a1, a2, p1, /*need_full=*/false));
-  KOCR_TRY(conv("basenet.slice1.7", p1, b1));
+  // conv + 2x2 max-pool: fused epilogue when the shape tiles, else two kernels; need_full: the pre-pool tensor is
+  // consumed elsewhere (skip connection).  The full-resolution buffer of an un-needed tensor is returned at once.
+  Tensor a1, a2, p1, b1, cat4, p2, c1, cat3, c3, p3, e1, cat2, f1, p4, g1, cat1, h0, h1;
+  KOCR_TRY(mk(d.H, d.W, 64, &a1));
+  RUN(launch_conv(ctx, L("basenet.slice1.0"), x0, u8, lut, a1));
+  KOCR_TRY(mk(d.H, d.W, 64, &a2));
+  KOCR_TRY(mk(d.H2, d.W2, 64, &p1));
+  RUN(launch_conv_pool(ctx, L("basenet.slice1.3"), a1, nullptr, nullptr, a2, &p1, /*need_full=*/false));
+  done(a1);
+  done(a2);
+  KOCR_TRY(mk(d.H2, d.W2, 128, &b1));
+  RUN(launch_conv(ctx, L("basenet.slice1.7"), p1, nullptr, nullptr, b1));
+  done(p1);
+  KOCR_TRY(mk(d.H2, d.W2, 192, &cat4));
+  KOCR_TRY(mk(d.H4, d.W4, 128, &p2));
   const Tensor s1 = cat4.slice(64, 128);
-  KOCR_TRY(conv_pool("basenet.slice1.10", b1, s1, p2, /*need_full=*/true));  // s1 is a skip tensor
-  KOCR_TRY(conv("basenet.slice2.14", p2, c1));
+  RUN(launch_conv_pool(ctx, L("basenet.slice1.10"), b1, nullptr, nullptr, s1, &p2, /*need_full=*/true));  // s1: skip tensor
+  done(b1);
+  KOCR_TRY(mk(d.H4, d.W4, 256, &c1));
+  RUN(launch_conv(ctx, L("basenet.slice2.14"), p2, nullptr, nullptr, c1));
+  done(p2);
+  KOCR_TRY(mk(d.H4, d.W4, 384, &cat3));
   const Tensor s2 = cat3.slice(128, 256);
-  KOCR_TRY(conv("basenet.slice2.17", c1, s2));
-  KOCR_TRY(conv_pool("basenet.slice3.20", s2, c3, p3, false));
-  KOCR_TRY(conv("basenet.slice3.24", p3, e1));
+  RUN(launch_conv(ctx, L("basenet.slice2.17"), c1, nullptr, nullptr, s2));
+  done(c1);
+  KOCR_TRY(mk(d.H4, d.W4, 256, &c3));
+  KOCR_TRY(mk(d.H8, d.W8, 256, &p3));
+  RUN(launch_conv_pool(ctx, L("basenet.slice3.20"), s2, nullptr, nullptr, c3, &p3, false));
+  done(c3);
+  KOCR_TRY(mk(d.H8, d.W8, 512, &e1));
+  RUN(launch_conv(ctx, L("basenet.slice3.24"), p3, nullptr, nullptr, e1));
+  done(p3);
+  KOCR_TRY(mk(d.H8, d.W8, 768, &cat2));
   const Tensor s3 = cat2.slice(256, 512);
-  KOCR_TRY(conv("basenet.slice3.27", e1, s3));
-  KOCR_TRY(conv_pool("basenet.slice4.30", s3, f1, p4, false));
-  KOCR_TRY(conv("basenet.slice4.34", p4, g1));
+  RUN(launch_conv(ctx, L("basenet.slice3.27"), e1, nullptr, nullptr, s3));
+  done(e1);
+  KOCR_TRY(mk(d.H8, d.W8, 512, &f1));
+  KOCR_TRY(mk(d.H16, d.W16, 512, &p4));
+  RUN(launch_conv_pool(ctx, L("basenet.slice4.30"), s3, nullptr, nullptr, f1, &p4, false));
+  done(f1);
+  KOCR_TRY(mk(d.H16, d.W16, 512, &g1));
+  RUN(launch_conv(ctx, L("basenet.slice4.34"), p4, nullptr, nullptr, g1));
+  done(p4);
+  KOCR_TRY(mk(d.H16, d.W16, 1536, &cat1));
   const Tensor s4 = cat1.slice(1024, 512);
-  KOCR_TRY(conv("basenet.slice4.37", g1, s4));
+  RUN(launch_conv(ctx, L("basenet.slice4.37"), g1, nullptr, nullptr, s4));
+  done(g1);
   // ---- slice5 (detection.py:365-378) ----------------------------------------------------
-  KOCR_TRY(launch_maxpool3x3s1(ctx, s4, h0));
-  KOCR_TRY(conv("basenet.slice5.1", h0, h1));
-  KOCR_TRY(conv("basenet.slice5.2", h1, cat1.slice(0, 1024)));
+  KOCR_TRY(mk(d.H16, d.W16, 512, &h0));
+  RUN(launch_maxpool3x3s1(ctx, s4, h0));
+  KOCR_TRY(mk(d.H16, d.W16, 1024, &h1));
+  RUN(launch_conv(ctx, L("basenet.slice5.1"), h0, nullptr, nullptr, h1));
+  done(h0);
+  RUN(launch_conv(ctx, L("basenet.slice5.2"), h1, nullptr, nullptr, cat1.slice(0, 1024)));
+  done(h1);
   // ---- U-Net decoder (detection.py:380-390) ---------------------------------------------
   Tensor u1a, u1b, u2a, u2b, u3a, u3b, u4a, feat, k0, k1, k2;
   KOCR_TRY(mk(d.H16, d.W16, 512, &u1a));
+  RUN(launch_conv(ctx, L("upconv1.conv.0"), cat1, nullptr, nullptr, u1a));
+  done(cat1);
   KOCR_TRY(mk(d.H16, d.W16, 256, &u1b));
-  KOCR_TRY(conv("upconv1.conv.0", cat1, u1a));
-  KOCR_TRY(conv("upconv1.conv.3", u1a, u1b));
-  KOCR_TRY(launch_resize_bilinear(ctx, u1b, cat2.slice(0, 256)));
+  RUN(launch_conv(ctx, L("upconv1.conv.3"), u1a, nullptr, nullptr, u1b));
+  done(u1a);
+  RUN(launch_resize_bilinear(ctx, u1b, cat2.slice(0, 256)));
+  done(u1b);
   KOCR_TRY(mk(d.H8, d.W8, 256, &u2a));
+  RUN(launch_conv(ctx, L("upconv2.conv.0"), cat2, nullptr, nullptr, u2a));
+  done(cat2);
   KOCR_TRY(mk(d.H8, d.W8, 128, &u2b));
-  KOCR_TRY(conv("upconv2.conv.0", cat2, u2a));
-  KOCR_TRY(conv("upconv2.conv.3", u2a, u2b));
-  KOCR_TRY(launch_resize_bilinear(ctx, u2b, cat3.slice(0, 128)));
+  RUN(launch_conv(ctx, L("upconv2.conv.3"), u2a, nullptr, nullptr, u2b));
+  done(u2a);
+  RUN(launch_resize_bilinear(ctx, u2b, cat3.slice(0, 128)));
+  done(u2b);
   KOCR_TRY(mk(d.H4, d.W4, 128, &u3a));
+  RUN(launch_conv(ctx, L("upconv3.conv.0"), cat3, nullptr, nullptr, u3a));
+  done(cat3);
   KOCR_TRY(mk(d.H4, d.W4, 64, &u3b));
-  KOCR_TRY(conv("upconv3.conv.0", cat3, u3a));
-  KOCR_TRY(conv("upconv3.conv.3", u3a, u3b));
-  KOCR_TRY(launch_resize_bilinear(ctx, u3b, cat4.slice(0, 64)));
+  RUN(launch_conv(ctx, L("upconv3.conv.3"), u3a, nullptr, nullptr, u3b));
+  done(u3a);
+  RUN(launch_resize_bilinear(ctx, u3b, cat4.slice(0, 64)));
+  done(u3b);
   KOCR_TRY(mk(d.H2, d.W2, 64, &u4a));
+  RUN(launch_conv(ctx, L("upconv4.conv.0"), cat4, nullptr, nullptr, u4a));
+  done(cat4);
   KOCR_TRY(mk(d.H2, d.W2, 32, &feat));
-  KOCR_TRY(conv("upconv4.conv.0", cat4, u4a));
-  KOCR_TRY(conv("upconv4.conv.3", u4a, feat));
+  RUN(launch_conv(ctx, L("upconv4.conv.3"), u4a, nullptr, nullptr, feat));
+  done(u4a);
   // ---- head (detection.py:392-410), linear output ---------------------------------------
   KOCR_TRY(mk(d.H2, d.W2, 32, &k0));
+  RUN(launch_conv(ctx, L("conv_cls.0"), feat, nullptr, nullptr, k0));
+  done(feat);
   KOCR_TRY(mk(d.H2, d.W2, 32, &k1));
+  RUN(launch_conv(ctx, L("conv_cls.2"), k0, nullptr, nullptr, k1));
+  done(k0);
   KOCR_TRY(mk(d.H2, d.W2, 16, &k2));
-  KOCR_TRY(conv("conv_cls.0", feat, k0));
-  KOCR_TRY(conv("conv_cls.2", k0, k1));
-  KOCR_TRY(conv("conv_cls.4", k1, k2));
+  RUN(launch_conv(ctx, L("conv_cls.4"), k1, nullptr, nullptr, k2));
+  done(k1);
   // conv_cls.6 + conv_cls.8 (1x1 16 -> 16 ReLU, 1x1 16 -> 2): one fused pass, no 16-channel round trip
-  return launch_head_tail(ctx, net->L.at("conv_cls.6"), net->L.at("conv_cls.8"), k2, d_heat);
+  RUN(launch_head_tail(ctx, L("conv_cls.6"), L("conv_cls.8"), k2, d_heat));
+  done(k2);
+#undef RUN
+  if (peak_out) *peak_out = pool.peak;
+  return KOCR_OK;
+}
+
+}  // namespace
+
+size_t craft_workspace_bytes(int N, int H, int W) {
+  size_t peak = 0;
+  static CraftNet empty;  // layer look-ups are never evaluated in the dry run
+  craft_run<true>(nullptr, &empty, nullptr, KOCR_U8, N, H, W, nullptr, &peak);
+  return peak + 4096;
+}
+
+int craft_forward(kocr_ctx* ctx, const void* d_img, int dtype, int N, int H, int W, float* d_heat) {
+  CraftNet* net = ctx->craft;
+  if (!net || !net->loaded) KOCR_FAIL(ctx, KOCR_ENOWEIGHTS, "kocr_craft_forward: call kocr_load_craft first");
+  if (N <= 0) return KOCR_OK;
+  if (H < 16 || W < 16) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_craft_forward: image smaller than 16x16");
+  return craft_run<false>(ctx, net, d_img, dtype, N, H, W, d_heat, nullptr);
 }

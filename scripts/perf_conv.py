@@ -13,6 +13,8 @@ SHAPES = [  # N, H, W, Cin, Cout, k  — CRAFT layer classes at 8 x 768x768
     (8, 48, 48, 1536, 512, 1),
     (8, 384, 384, 32, 32, 3),
     (8, 384, 384, 32, 16, 3),
+    (8, 192, 192, 512, 512, 3),  # slice3.27 at 8 x 1536x1536
+    (8, 384, 384, 256, 256, 3),  # slice2.17 at 8 x 1536x1536
 ]
 if len(sys.argv) > 1:
     SHAPES = [SHAPES[int(a)] for a in sys.argv[1:]]

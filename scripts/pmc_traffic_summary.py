@@ -45,6 +45,19 @@ for k in sorted(fetch, key=lambda k: -fetch[k]["FETCH_SIZE"]):
         row["clock_ghz"] = cyc / mfma[k]["_ns_GRBM_GUI_ACTIVE"]
         row["waves_per_simd"] = mfma[k]["SQ_WAVE_CYCLES"] * 4 / (cyc * 1024)
     res["kernels"][k] = row
+# libkocr's profiler row names (what bench.py's roofline object is keyed on) -> rocprof kernel names
+PROF = {
+    "conv_w4s_256x128": "void conv_w43_kernel<0", "conv_w4s_256x128_pool": "void conv_w43_kernel<1",
+    "conv_ws_128x128": "void conv_ws_kernel<0, 1, 4, 0", "conv_ws_128x128_pool": "void conv_ws_kernel<1, 1, 4, 0",
+    "conv_ws_256x64": "void conv_ws_kernel<0, 2, 2, 0", "conv_ws_256x64_pool": "void conv_ws_kernel<1, 2, 2, 0",
+    "conv_ds_256x128": "void conv_ds_kernel<1, 4, 0", "conv_ds_512x64": "void conv_ds_kernel<2, 2, 0",
+}
+res["by_prof_name"] = {}
+for pn, prefix in PROF.items():
+    for k, row in res["kernels"].items():
+        if k.startswith(prefix):
+            res["by_prof_name"][pn] = dict(row, kernel=k)
+            break
 json.dump(res, open(out_json, "w"), indent=1)
 for k, row in list(res["kernels"].items())[:8]:
     print(k[:70], {a: (round(b, 3) if isinstance(b, float) and b < 100 else b) for a, b in row.items()})

@@ -101,6 +101,11 @@ SPLIT_CASES = [
     (2, 64, 128, 64, 64),     # 256x64 tiles
     (1, 40, 64, 48, 96),      # 9 K-steps (odd)
     (1, 30, 50, 512, 130),    # ragged couts, tiles crossing image rows
+    # conv_w43.hip (Winograd F(4,3): Cin % 32 == 0, Cout > 64, W % 4 == 0) -- the first case above takes it too
+    (1, 30, 52, 512, 130),    # ragged couts, 256-pixel tiles crossing image rows, last tile partly outside
+    (2, 17, 36, 64, 128),     # 12 K-steps, two images, odd height
+    (1, 64, 128, 128, 256),   # two cout tiles per pixel tile
+    (3, 8, 4, 32, 96),        # a single quad per row: both column paddings in one quad
 ]
 
 
@@ -116,8 +121,10 @@ def test_split_kernel_is_fp32_class_against_fp64(ctx, case):
     want = F.conv2d(xt, wtt, None, padding=1).permute(0, 2, 3, 1).numpy()
     bound = F.conv2d(xt.abs(), wtt.abs(), None, padding=1).permute(0, 2, 3, 1).numpy()
     ratio = np.abs(got - want) / np.maximum(bound, 1e-30)
+    rms = float(np.sqrt((ratio ** 2).mean()))
+    print(f"split conv {case}: max err / (|x| conv |w|) = {ratio.max():.3e}, rms = {rms:.3e}")
     assert float(ratio.max()) <= 1e-6, f"max err / (|x| conv |w|) = {ratio.max():.3e}"
-    assert float(np.sqrt((ratio ** 2).mean())) <= 1.5e-7, f"rms = {np.sqrt((ratio ** 2).mean()):.3e}"
+    assert rms <= 1.5e-7, f"rms = {rms:.3e}"
 
 
 # conv_dsplit.hip: the same bf16x3 arithmetic for 1x1 / dilated / larger kernels (>= 4096 pixels)
@@ -129,6 +136,10 @@ DSPLIT_CASES = [
     (1, 70, 61, 48, 100, 1, 1),     # ragged pixels / couts, 3 K-steps
     (1, 65, 67, 32, 40, 5, 1),      # 5x5, tiles crossing rows, odd sizes
     (2, 50, 90, 64, 70, 3, 2),      # dilation 2, two images
+    # dilated layers with W % (4 dil) == 0, Cin % 32 == 0, Cout > 64 take conv_w43.hip (Winograd F(4,3) on the comb
+    # of pixels dil apart) -- the first case above does too
+    (2, 48, 48, 64, 128, 3, 6),     # slice5.1 geometry at 768x768 input
+    (1, 33, 40, 32, 96, 3, 2),      # dilation 2, odd height, ragged couts, tile ends inside a row
 ]
 
 

@@ -1,4 +1,5 @@
-mkdir -p gpurun_out/c13
-( time python -m pytest tests/test_craft_gpu.py tests/test_pipeline_gpu.py tests/test_baseline_sizes_gpu.py tests/test_split_modes_gpu.py -m gpu -q -x ) > gpurun_out/c13/gpu.log 2>&1
-( time python bench.py --no-cpu-baseline ) > gpurun_out/c13/bench.json 2> gpurun_out/c13/bench.err
-tail -4 gpurun_out/c13/gpu.log; cut -c1-300 gpurun_out/c13/bench.json; tail -3 gpurun_out/c13/bench.err
+mkdir -p gpurun_out/c14
+( timeout 600 python -m pytest tests/test_conv_gpu.py tests/test_craft_gpu.py -m gpu -q -s ) > gpurun_out/c14/conv.log 2>&1
+grep -E "passed|failed|Error|error" gpurun_out/c14/conv.log | tail -5
+( KOCR_PROF_LAYERS=1 timeout 300 python scripts/perf_craft.py 8 1536 1536 ) > gpurun_out/c14/craft.log 2>&1
+head -3 gpurun_out/c14/craft.log; grep -E "slice5|upconv1.conv.3" gpurun_out/c14/craft.log

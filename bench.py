@@ -139,6 +139,10 @@ def main():
                     help="arithmetic of the wide convolutions for the headline number (include/kocr.h KOCR_SPLIT_*)")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the extra leg in the other split mode")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] / configs[4]-share / host-array legs")
+    ap.add_argument("--profile-all", action="store_true",
+                    help="keep the HIP-event profiler on for the WHOLE process (headline loop included) and report the "
+                         "per-launch averages over every launch: the numbers a rocprofv3 --stats / --pmc run of the "
+                         "same command must agree with (scripts/profile_final.sh)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -165,7 +169,19 @@ def main():
     ctx = k.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_split_mode(args.split)
-    ctx.profile_enable(False)
+    ctx.profile_reset()
+    ctx.profile_enable(bool(args.profile_all))
+    prof_process = {}
+
+    def fold_process_profile():
+        """--profile-all: accumulate the profiler rows seen so far (every launch of the process) and restart it"""
+        if not args.profile_all:
+            return
+        for kk, v in ctx.profile_report().items():
+            row = prof_process.setdefault(kk, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            for f in row:
+                row[f] += v[f]
+        ctx.profile_reset()
 
     pages = make_pages(args.batch, SIDE, seed=4 + rank)
     craft_w = k.weights.synthetic_craft_weights(1234)
@@ -219,11 +235,13 @@ def main():
     dt, out = timed(step, args.steps)
     n_words = sum(len(g) for g in out)
     # ---- the same K steps with the HIP-event profiler on: stage times + roofline of the dominant kernel --
+    fold_process_profile()
     ctx.profile_reset()
     ctx.profile_enable(True)
     dt_prof, _ = timed(step, args.steps)
     prof = {kk: v for kk, v in ctx.profile_report().items() if v["launches"]}
-    ctx.profile_enable(False)
+    fold_process_profile()
+    ctx.profile_enable(bool(args.profile_all))
 
     # ---- other arithmetic mode of the wide convolutions, same workload; reported beside the headline ------
     alt = None
@@ -295,6 +313,7 @@ def main():
                                "words": sum(len(g) for g in o5)}
         del p5
 
+    fold_process_profile()
     if rank == 0:
         dom = max((kv for kv in prof.items() if kv[0].startswith("conv_")), key=lambda kv: kv[1]["ms"])
         name, r = dom
@@ -363,6 +382,14 @@ def main():
                           "value": crnn_us_per_crop / 1e3, "unit": "ms/crop",
                           "fp32_mfma_floor_ms": 13.444e9 / (FP32_MFMA_PEAK_TF * 1e12) * 1e3},
         }
+        if args.profile_all and name in prof_process:
+            pr = prof_process[name]
+            res["roofline"]["process"] = {
+                "note": "--profile-all: HIP-event averages over EVERY launch of this kernel in the process (calibration, "
+                        "warm-up, headline and profiled loops, extra legs) -- the set a rocprofv3 run of this command sees",
+                "launches": pr["launches"], "avg_launch_ms": pr["ms"] / pr["launches"],
+                "algorithmic_bytes_per_launch": pr["bytes"] / pr["launches"],
+                "algorithmic_fp32_tflops": pr["flops"] / (pr["ms"] * 1e-3) / 1e12}
         res.update(extra)
         if alt is not None:
             res["alt_split_mode"] = alt

@@ -13,7 +13,10 @@
  *     workspace.  `on_device` != 0 means the pointers are HIP device pointers on the
  *     ctx's device (e.g. torch.Tensor.data_ptr()); 0 means host pointers (numpy).
  *   - one ctx per device; calls on a ctx are serialised on its HIP stream and are not
- *     re-entrant.  Device-pointer calls are asynchronous on that stream unless they
+ *     re-entrant.  A ctx (its stream, workspace arenas and profiler) belongs to ONE host thread
+ *     at a time: the library takes no locks, exactly as the reference documents nothing as
+ *     thread-safe (single caller thread, synchronous).  Use one ctx per thread, or serialise
+ *     the calls yourself; separate contexts (also on one device) are independent.  Device-pointer calls are asynchronous on that stream unless they
  *     return host-side counts (documented per call).
  *   - tensors are dense, row-major, channels-last (NHWC), exactly the layouts the
  *     reference hands to / receives from Keras.

@@ -203,6 +203,9 @@ int kocr_craft_forward(kocr_ctx* ctx, const void* img, int dtype, int N, int H, 
   int mb = micro_batch > 0 ? micro_batch : 32;  // Keras predict default batch_size (detection.py:779)
   // keep the per-micro-batch workspace under ~64 GiB of the 288 GB HBM
   while (mb > 1 && craft_workspace_bytes(mb, H, W) > ((size_t)96 << 30)) mb = (mb + 1) / 2;
+  // fp16x2 split: the exact input scale of a convolution follows the max |x| of the tensor it reads, so one IMAGE
+  // per forward makes every image's result independent of what else is in the batch
+  if (ctx->split_mode == KOCR_SPLIT_F16X2) mb = 1;
   mb = std::min(mb, N);
   const size_t esz = dtype == KOCR_U8 ? 1 : 4;
   const size_t in_img = (size_t)H * W * 3 * esz;

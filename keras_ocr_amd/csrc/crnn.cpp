@@ -182,6 +182,14 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
   if (!net || !net->loaded) KOCR_FAIL(ctx, KOCR_ENOWEIGHTS, "kocr_crnn_forward: call kocr_load_crnn first");
   if (M <= 0) return KOCR_OK;
   KOCR_TRY(ctx->amax_begin());
+  // The recogniser always runs the exact bf16x3 split: its batch is a mix of crops of many images, and the fp16x2
+  // scale (max |x| of the whole tensor) would make a crop's result depend on its neighbours in the batch.
+  struct ModeGuard {
+    kocr_ctx* c;
+    int old;
+    explicit ModeGuard(kocr_ctx* ctx) : c(ctx), old(ctx->split_mode) { c->split_mode = KOCR_SPLIT_BF16X3; }
+    ~ModeGuard() { c->split_mode = old; }
+  } mode_guard(ctx);
   auto mk = [&](int n, int h, int w, int c, Tensor* t) -> int {
     t->amax = nullptr;  // assigned below for the conv stack only (its producers all maintain the slot)
     t->N = n;

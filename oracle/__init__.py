@@ -5,14 +5,17 @@ A restatement, on torch-CPU / numpy / scipy, of the algorithm behind
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
 import this package; the product (``keras_ocr_amd/``) never does.
 
-Pinning status (see DESIGN.md "Oracle"):
-  * ``oracle.craft``  — pinned against the reference's own PyTorch statement of CRAFT
+Pinning status (DESIGN.md section 4 has the full table):
+  * ``oracle.craft``  -- pinned against the reference's own PyTorch statement of CRAFT
     (``keras_ocr/detection.py:472-644``) executed from /root/reference with a stub
     ``torchvision`` (``tests/golden/make_golden.py``), fixtures under ``tests/golden/``.
-  * ``oracle.tools`` geometry helpers — pinned against the reference's ``tools.py``
-    functions that run on numpy/scipy alone (same script).
-  * everything that bottoms out in TensorFlow / OpenCV / shapely (CRNN graph, getBoxes,
-    warpPerspective, resize, cvtColor) — **parity unpinned**: those libraries, and the
-    pretrained weights, are absent here; the restatement follows the reference call sites
-    and the published semantics of those libraries.
+  * ``oracle.tools`` geometry helpers -- pinned against the reference's ``tools.py``
+    functions that run on numpy/scipy alone (same script); ``oracle.crnn.stn_transform`` -- pinned against
+    the reference's own ``recognition._transform`` executed through a numpy stand-in of the TF ops it uses.
+  * everything that bottoms out in TensorFlow / OpenCV / shapely (Conv/BN/LSTM/CTC semantics, getBoxes' cv2
+    calls, warpPerspective, resize, cvtColor, minimum_rotated_rectangle) -- those libraries and the pretrained
+    weights are installed nowhere in this image, so they cannot be executed; each is cross-checked against an
+    INDEPENDENT statement of the same operation (scikit-image / scipy / Qhull / Pillow fixtures generated under the
+    image's second interpreter by ``tests/golden/make_golden_3p.py``; ``torch.nn`` modules;
+    ``tests/test_thirdparty_crosscheck_cpu.py``).
 """

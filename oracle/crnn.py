@@ -2,8 +2,11 @@
 TEST INFRASTRUCTURE ONLY.
 
 Follows ``keras_ocr/recognition.py`` with Keras/TensorFlow layer semantics (SURVEY.md
-Appendix C).  TensorFlow is absent here, so this graph is **parity unpinned** against the
-reference runtime; every step cites the line it restates:
+Appendix C).  TensorFlow cannot be installed here; status: the STN sampler is **pinned** to the reference's own
+``_transform`` (executed through a numpy stand-in of the TF ops it uses, tests/golden/make_golden.py); the LSTM, the
+conv / BatchNorm / pooling stack and the CTC rule are **cross-checked by independent implementations** (torch.nn.LSTM /
+Conv2d / BatchNorm2d modules with Keras-ordered weights, itertools.groupby: tests/test_thirdparty_crosscheck_cpu.py).
+Every step cites the line it restates:
 
   Permute((2,1,3)) + flip axis 2                         :215-216
   conv_1..conv_7 3x3 same ReLU; BN *after* ReLU (Keras default eps=1e-3) at 3/5/7;

@@ -2,8 +2,14 @@
 
 Restates ``keras_ocr.detection.getBoxes`` (reference ``keras_ocr/detection.py:207-287``).
 Every ``cv2.*`` call there is a third-party [3P] behaviour that cannot be executed in this
-environment (no OpenCV): **parity unpinned** for those; the restatement follows the
-documented semantics:
+environment (OpenCV is installed in neither interpreter of the image).  Status: **cross-checked by independent
+implementation** -- label order / areas / bounding boxes against skimage.measure.label + regionprops, the k x k
+rectangle dilation (odd AND even k) against scipy.ndimage.maximum_filter and skimage.morphology, the fragment choice
+against skimage 8-connectivity labels, hull vertices against Qhull, the min-area rectangle against a float64
+brute-force search (tests/golden/make_golden_3p.py -> tests/test_thirdparty_crosscheck_cpu.py).  The one rule that
+rests on reading OpenCV's sources rather than on an executable cross-check is WHICH contour ``findContours`` lists
+first when a component was split into several fragments (siblings are inserted at the head of the list, so it is
+the fragment found last by the raster scan).  The restatement follows the documented semantics:
 
   cv2.threshold(THRESH_BINARY)            dst = maxval if src > thresh else 0   (strict >)
   connectedComponentsWithStats(conn=4)    labels in raster order of first pixel

@@ -7,8 +7,12 @@ get_rotated_box :533-581, get_rotated_width_height :41-57, adjust_boxes :232-260
 
 In-repo logic (scale rule, padding, point ordering, width/height, scale, paste) follows the
 reference line by line and is pinned by ``tests/golden`` fixtures generated from the
-reference's own functions.  The OpenCV/shapely calls underneath are [3P] and **parity
-unpinned** (libraries absent); they are restated from their published algorithms:
+reference's own functions.  The OpenCV/shapely calls underneath are [3P]; the
+libraries are installed in neither interpreter of the image, so each restatement is **cross-checked by an independent
+implementation** instead (skimage ProjectiveTransform for the homography, numpy.linalg.inv + scipy map_coordinates on
+1/32-px coordinates for the warp -- bit for bit --, skimage float bilinear resize within 1 LSB, Pillow's ITU-R 601
+gray within 1 LSB, a brute-force float64 rectangle search for shapely: tests/test_thirdparty_crosscheck_cpu.py).
+They are restated from their published algorithms:
 
   cv2.resize(INTER_LINEAR, u8)   half-pixel mapping, 11-bit fixed-point coefficients,
                                  horizontal pass in int32, vertical pass

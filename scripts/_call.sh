@@ -1,5 +1,5 @@
-mkdir -p gpurun_out/c14
-( timeout 600 python -m pytest tests/test_conv_gpu.py tests/test_craft_gpu.py -m gpu -q -s ) > gpurun_out/c14/conv.log 2>&1
-grep -E "passed|failed|Error|error" gpurun_out/c14/conv.log | tail -5
-( KOCR_PROF_LAYERS=1 timeout 300 python scripts/perf_craft.py 8 1536 1536 ) > gpurun_out/c14/craft.log 2>&1
-head -3 gpurun_out/c14/craft.log; grep -E "slice5|upconv1.conv.3" gpurun_out/c14/craft.log
+mkdir -p gpurun_out/c16
+( time KOCR_SPLIT=f16 python -m pytest tests -m gpu -q -x ) > gpurun_out/c16/gpu_f16.log 2>&1
+( time python bench.py --no-cpu-baseline --no-extra ) > gpurun_out/c16/bench.json 2> gpurun_out/c16/bench.err
+tail -4 gpurun_out/c16/gpu_f16.log; python -c "
+import json;d=json.loads(open('gpurun_out/c16/bench.json').readline());print(d['value'],d['alt_split_mode'])"

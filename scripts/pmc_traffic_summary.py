@@ -58,6 +58,17 @@ for pn, prefix in PROF.items():
         if k.startswith(prefix):
             res["by_prof_name"][pn] = dict(row, kernel=k)
             break
+# algorithmic bytes per launch of the SAME process (bench.py --profile-all line of the FETCH_SIZE run)
+bj = os.path.join(root, "bench_under_pmc.json")
+if os.path.isfile(bj) and os.path.getsize(bj):
+    b = json.load(open(bj))
+    pr = b.get("roofline", {}).get("process")
+    nm = b.get("roofline", {}).get("kernel")
+    if pr and nm in res["by_prof_name"]:
+        row = res["by_prof_name"][nm]
+        row["algorithmic_bytes_per_launch_same_process"] = pr["algorithmic_bytes_per_launch"]
+        row["launches_hip_events"] = pr["launches"]
+        row["traffic_over_algorithmic"] = row["hbm_bytes_per_launch"] / pr["algorithmic_bytes_per_launch"]
 json.dump(res, open(out_json, "w"), indent=1)
 for k, row in list(res["kernels"].items())[:8]:
     print(k[:70], {a: (round(b, 3) if isinstance(b, float) and b < 100 else b) for a, b in row.items()})

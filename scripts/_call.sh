@@ -1,5 +1,6 @@
-mkdir -p gpurun_out/c16
-( time KOCR_SPLIT=f16 python -m pytest tests -m gpu -q -x ) > gpurun_out/c16/gpu_f16.log 2>&1
-( time python bench.py --no-cpu-baseline --no-extra ) > gpurun_out/c16/bench.json 2> gpurun_out/c16/bench.err
-tail -4 gpurun_out/c16/gpu_f16.log; python -c "
-import json;d=json.loads(open('gpurun_out/c16/bench.json').readline());print(d['value'],d['alt_split_mode'])"
+mkdir -p gpurun_out/c17
+( KOCR_W43B=1 timeout 600 python -m pytest tests/test_conv_gpu.py tests/test_craft_gpu.py -m gpu -q -x ) > gpurun_out/c17/conv.log 2>&1
+tail -5 gpurun_out/c17/conv.log
+for b in 0 1; do echo "== W43B $b"; KOCR_W43B=$b timeout 120 python scripts/perf_conv.py 8 9 2>&1 | grep conv; done
+( KOCR_W43B=1 KOCR_PROF_LAYERS=1 timeout 300 python scripts/perf_craft.py 8 1536 1536 ) > gpurun_out/c17/craft_b.log 2>&1
+head -14 gpurun_out/c17/craft_b.log

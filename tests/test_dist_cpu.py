@@ -95,3 +95,75 @@ def test_shard_bounds_cover_everything():
             spans = [keras_ocr_amd.dist.shard_bounds(n, w, r) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+# ---------------------------------------------------------------------------------------------------
+# the REAL Pipeline / Detector / Recognizer classes over a context mocked at the C-ABI seam (Context.pipeline)
+# ---------------------------------------------------------------------------------------------------
+class _MockContext:
+    """Stands in for keras_ocr_amd._lib.Context: `pipeline()` is the ctypes wrapper of kocr_pipeline.  It returns what
+    the library would: per image (n_i,4,2) float32 boxes in DETECTOR-INPUT pixels and (sum n_i, 48) label rows -- here
+    derived from the arguments, so that the test can tell which rank processed which image with which padded size."""
+
+    def pipeline(self, images, hs, ws, dhs, dws, hmax, wmax, micro_batch=0, on_device=False, **kw):
+        groups, rows = [], []
+        for im, h, w, dh, dw in zip(images, hs, ws, dhs, dws):
+            n = int(h) % 3
+            boxes = np.zeros((n, 4, 2), np.float32)
+            for j in range(n):
+                boxes[j] = np.array([[0, 0], [dw, 0], [dw, dh], [0, dh]], np.float32) + j
+                row = np.full(48, -1, np.int32)
+                row[:3] = [int(h) % 36, hmax % 36, j]   # decoded with the default alphabet below
+                rows.append(row)
+            groups.append(boxes if n else np.array([]))
+        return groups, (np.array(rows, np.int32) if rows else np.zeros((0, 48), np.int32))
+
+
+def _real_pipeline():
+    import keras_ocr_amd as k
+
+    ctx = _MockContext()
+    det = object.__new__(k.detection.Detector)
+    rec = object.__new__(k.recognition.Recognizer)
+    det._ctx = rec._ctx = ctx  # pylint: disable=protected-access
+    rec.alphabet = k.recognition.DEFAULT_ALPHABET
+    rec.blank_label_idx = len(rec.alphabet)
+    return k.pipeline.Pipeline(detector=det, recognizer=rec, scale=2, max_size=2048)
+
+
+def _worker_real(rank, world, port, n_images, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import keras_ocr_amd
+
+    keras_ocr_amd.dist.init_from_env(backend="gloo")
+    images = [np.zeros((10 + i, 20 + 2 * i, 3), np.uint8) for i in range(n_images)]
+    out = keras_ocr_amd.dist.ShardedPipeline(_real_pipeline()).recognize(images)
+    q.put((rank, [[(t, b.tolist()) for t, b in page] for page in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_real_pipeline_classes_over_mocked_abi_gloo_world2():
+    """ShardedPipeline(real Pipeline).recognize on 2 ranks == the same Pipeline.recognize in one process: scale rule,
+    adjust_boxes, string assembly and the packed all-gather all run for real; only kocr_pipeline is mocked."""
+    n_images = 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_real, args=(r, 2, port, n_images, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    images = [np.zeros((10 + i, 20 + 2 * i, 3), np.uint8) for i in range(n_images)]
+    single = [[(t, b.tolist()) for t, b in page] for page in _real_pipeline().recognize(images)]
+    assert res[0][1] == single and res[1][1] == single
+    # image 1 (height 11 -> 2 boxes): boxes come back in INPUT pixels (detector-input / scale 2), strings decoded
+    assert len(single[1]) == 2 and single[1][0][1][2] == [20 + 2, 11.0]
+    alphabet = "0123456789abcdefghijklmnopqrstuvwxyz"
+    hmax = 2 * (10 + n_images - 1)
+    assert single[1][0][0] == alphabet[11] + alphabet[hmax % 36] + alphabet[0]

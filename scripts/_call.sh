@@ -1,5 +1,3 @@
-mkdir -p gpurun_out/c19
-( KOCR_WS_MIN_COUT=32 KOCR_PROF_LAYERS=1 timeout 300 python scripts/perf_craft.py 8 1536 1536 ) > gpurun_out/c19/craft32.log 2>&1
-head -3 gpurun_out/c19/craft32.log; grep -E "upconv4.conv.3|conv_cls" gpurun_out/c19/craft32.log
-( KOCR_WS_MIN_COUT=16 KOCR_PROF_LAYERS=1 timeout 300 python scripts/perf_craft.py 8 1536 1536 ) > gpurun_out/c19/craft16.log 2>&1
-head -3 gpurun_out/c19/craft16.log; grep -E "upconv4.conv.3|conv_cls" gpurun_out/c19/craft16.log
+for mf in 0 1; do echo "== MFAST $mf shape 8 (512->512, 8x192x192: in 0.604 GB, out 0.604 GB)"; bash scripts/pmc_conv.sh mf${mf}_8 8 KOCR_W43_MFAST=$mf; done
+for mf in 0 1; do echo "== MFAST $mf shape 9 (256->256, 8x384x384: in 1.208 GB, out 1.208 GB)"; bash scripts/pmc_conv.sh mf${mf}_9 9 KOCR_W43_MFAST=$mf; done
+echo "== old kernel shape 8"; bash scripts/pmc_conv.sh old_8 8 KOCR_W43=0

@@ -1,10 +1,24 @@
 #!/bin/bash
+# FETCH_SIZE / WRITE_SIZE of one convolution shape (scripts/perf_conv.py index), separate rocprofv3 runs.
+# usage: pmc_conv.sh <tag> <shape index> [ENV=VAL ...]
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/pmc_conv_$1
+TAG=$1; IDX=$2; shift 2
+OUT=$REPO/gpurun_out/pmcc_$TAG
 mkdir -p $OUT
-CMD="python $REPO/scripts/perf_conv.py 0"
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $OUT/p1 -o p1 -- $CMD > $OUT/p1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD --output-format csv -d $OUT/p2 -o p2 -- $CMD > $OUT/p2.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/p3 -o p3 -- $REPO/scripts/probes/probe_mfma > $OUT/p3.log 2>&1
-tail -2 $OUT/p2.log
+for c in FETCH_SIZE WRITE_SIZE; do
+  env "$@" rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o p -- python $REPO/scripts/perf_conv.py $IDX > $OUT/$c.log 2>&1
+done
+python3 - $OUT <<'PY'
+import csv, glob, os, sys, collections
+root = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(os.path.join(root, c, "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Kernel_Name"].startswith("void conv_"):
+                agg[r["Kernel_Name"][:44]][r["Counter_Name"]] += float(r["Counter_Value"]); n[(r["Kernel_Name"][:44], c)].add(r["Dispatch_Id"])
+for k, v in agg.items():
+    nf = len(n[(k, "FETCH_SIZE")]) or 1
+    print(f"{k:46s} launches={nf} fetch/launch={v['FETCH_SIZE']*1024*2/nf/1e9:.3f} GB write/launch={v['WRITE_SIZE']*1024/nf/1e9:.3f} GB")
+PY

@@ -1,0 +1,59 @@
+"""CPU suite: the host-side pieces of bench.py (no GPU): synthetic pages, the parity object, the work model behind
+the roofline object, and the refusal to report a multi-GPU number from fewer devices."""
+import subprocess
+import sys
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_pages_are_seeded_and_hold_the_requested_words():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    a = bench.make_pages(3, 768, seed=4)
+    b = bench.make_pages(3, 768, seed=4)
+    c = bench.make_pages(3, 768, seed=5)
+    assert a.shape == (3, 768, 768, 3) and a.dtype == np.uint8
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    # white background with dark glyphs in about WORDS_PER_PAGE grid cells
+    dark = (a[0].min(-1) < 128)
+    assert 0.002 < dark.mean() < 0.2
+
+
+def test_parity_object():
+    import bench
+
+    box = np.array([[0, 0], [10, 0], [10, 5], [0, 5]], np.float32)
+    same = bench.parity_of([("ab", box), ("c", box + 1)], [("ab", box), ("c", box + 1)])
+    assert same["ok"] and same["strings_equal"] and same["boxes_max_abs_diff_px"] == 0.0
+    moved = bench.parity_of([("ab", box)], [("ab", box + 0.5)])
+    assert not moved["ok"] and moved["boxes_max_abs_diff_px"] == 0.5
+    text = bench.parity_of([("ab", box)], [("ax", box)])
+    assert not text["ok"] and not text["strings_equal"]
+    count = bench.parity_of([("ab", box)], [])
+    assert not count["ok"] and count["boxes_max_abs_diff_px"] is None
+    assert bench.parity_of([], [])["ok"]
+
+
+def test_issued_work_model():
+    import keras_ocr_amd as k
+
+    f = k.perfmodel.issued_per_algorithmic
+    assert f("conv_w4s_256x128_pool") == {"pipe": "bf16", "factor": 3.0, "why": f("conv_w4s_256x128")["why"]}
+    assert f("conv_ws_128x128")["factor"] == 4.0 and f("conv_wh_128x128")["factor"] == 2.0
+    assert f("conv_ds_256x128")["factor"] == 6.0 and f("conv_wino_128x32")["pipe"] == "fp32"
+    assert abs(f("conv_wino_128x32")["factor"] - 2 / 3) < 1e-12 and f("conv_mfma_128x64_m2")["factor"] == 1.0
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 2` with fewer than 2 visible GPUs must fail loudly, not print n_gpus: 1."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=env, timeout=600, check=False)
+    assert r.returncode != 0
+    assert "GPU(s) visible" in (r.stderr + r.stdout)
+    assert '"metric"' not in r.stdout

@@ -147,6 +147,13 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         respawn_under_torchrun(args)
+    if "WORLD_SIZE" not in os.environ and "MASTER_PORT" not in os.environ:
+        import socket  # single process: rendezvous on a free local port (a fixed one may still be in TIME_WAIT)
+
+        with socket.socket() as sck:
+            sck.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sck.getsockname()[1])
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     # stdout carries exactly ONE JSON line: RCCL / HIP banners written to fd 1 by native code go to stderr
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)

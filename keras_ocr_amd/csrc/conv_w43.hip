@@ -494,13 +494,354 @@ __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
   }
 }
 
+// ===================================================================================================
+// conv_w43n_kernel -- the 64-cout ("narrow") arrangement for layers with 32 < Cout <= 64 (slice1.3, upconv3.conv.3):
+// tile = 128 quads (512 pixels, four M-tiles) x 64 couts; wave (wm, wn) owns M-tiles {2 wm, 2 wm + 1} x couts
+// [32 wn, 32 wn + 32) x 6 points -- the same 192 accumulators and the same K-step of 72 MFMAs as conv_w43_kernel.
+// The transform is amortised over half as many couts, so every thread has TWO gather items per K-step (quads q and
+// q + 64).  Their raw pixels share two register sets without doubling them: item 0 is transformed during the first
+// three points of a K-step (two points per MFMA group) and its registers are refilled at once with the K-step after
+// next; item 1 follows in the last three.  LDS: 2 x 72 KB.  dilation 1 only.
+// ===================================================================================================
+template <int POOL>
+__global__ __launch_bounds__(256) void conv_w43n_kernel(W4Params p) {
+  constexpr int NMT = 4;                       // M-tiles per block tile
+  constexpr int PLANE_N = NMT * 2 * KH_STRIDE;  // one (xi, piece) plane
+  constexpr int BUF_N = 6 * 3 * PLANE_N;        // one K-step: 72 KB
+  extern __shared__ __attribute__((aligned(16))) unsigned short As[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wm = wave >> 1;
+  const int l31 = lane & 31, l5 = lane >> 5;
+  const int nblk_n = p.Cout_pad >> 6;
+  const int total = p.total_tiles;
+  const int ns = p.nsteps;
+  const int G = gridDim.x;
+  constexpr unsigned OOB = 0x80000000u;
+
+  // ---- producer state: items it = 0, 1: quad qi + 64 it of the 128-quad tile, channel quad q4 ------------------
+  const int qi = tid >> 2, q4 = tid & 3;
+  int ldst[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int q = qi + 64 * it;
+    ldst[it] = ((q >> 5) * 2 + (q4 >> 1)) * KH_STRIDE + ((((q & 31) * 8) ^ ((q4 >> 1) * 32)) + (q4 & 1) * 4);
+  }
+  struct Geo {
+    unsigned off0[2];  // byte offset of raw pixel d0 of each item (the six pixels are in_cs * 4 bytes apart)
+    unsigned flags;    // per item it: bit 4 it: valid, bit 4 it + 1: d0 is left padding, bit 4 it + 2: d5 is right padding
+    int gy[2];
+    const float* base;
+  };
+  auto make_geo = [&](int L, Geo& g) __attribute__((always_inline)) {
+    int mp, nt_unused;
+    w4_decode(p, kocr_xcd_remap(L < total ? L : 0, total), nblk_n, mp, nt_unused);
+    const int mtb = mp * NMT;
+    int y0a, x0a;
+    const long pm_a = w4_mtile_pm0<POOL>(p, mtb, y0a, x0a);
+    g.base = p.in + (pm_a * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
+    g.flags = 0;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int q = qi + 64 * it;
+      const int m = q >> 5, i = q & 31;
+      int rel, x0;
+      bool gok;
+      if constexpr (POOL) {
+        const int mt = mtb + m;
+        int y0b, x0b;
+        const long pm_b = w4_mtile_pm0<POOL>(p, mt < p.total_mtiles ? mt : mtb, y0b, x0b);
+        const int row = i >> 4, qc = i & 15;
+        rel = (int)(pm_b - pm_a) + row * p.W + 4 * qc;
+        x0 = x0b + 4 * qc;
+        g.gy[it] = y0b + row;
+        gok = L < total && mt < p.total_mtiles;
+      } else {
+        rel = 4 * q;
+        const long gp = pm_a + rel;
+        gok = L < total && gp < p.Mtotal;
+        x0 = (int)(gp % p.W);
+        g.gy[it] = (int)((gp / p.W) % p.H);
+      }
+      g.off0[it] = (unsigned)((rel * p.in_cs + q4 * 4) * 4);
+      g.flags |= ((gok ? 1u : 0u) | (x0 == 0 ? 2u : 0u) | (x0 + 4 >= p.W ? 4u : 0u)) << (4 * it);
+    }
+  };
+  Geo gc, gn;
+  int ld_ky = 0, ld_cg = 0;  // position of the NEXT K-step to load (shared by both items; advanced after item 1)
+  bool ld_next = false;
+  const int ncg = p.Cin >> 4;
+  v4f raw0[6], raw1[6];
+  auto load_item = [&](v4f (&raw)[6], int it) __attribute__((always_inline)) {
+    const int soff = (ld_ky * p.W * p.in_cs + ld_cg * 16) * 4;
+    const int gy = ld_next ? gn.gy[it] : gc.gy[it];
+    const unsigned fl = (ld_next ? gn.flags : gc.flags) >> (4 * it);
+    const bool ok = (fl & 1u) & ((unsigned)(gy + ld_ky - 1) < (unsigned)p.H);
+    const unsigned kill = ok ? 0u : OOB;
+    const unsigned off0 = (ld_next ? gn.off0[it] : gc.off0[it]) | kill;
+    const unsigned stride = (unsigned)(p.in_cs * 4);
+    const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const unsigned padk = (k == 0 ? ((fl & 2u) ? OOB : 0u) : 0u) | (k == 5 ? ((fl & 4u) ? OOB : 0u) : 0u);
+      raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (off0 + k * stride) | padk, soff, 0));
+    }
+  };
+  auto advance = [&]() __attribute__((always_inline)) {
+    const bool wrap_ky = ld_ky == 2;
+    ld_ky = wrap_ky ? 0 : ld_ky + 1;
+    const bool wrap_cg = wrap_ky && ld_cg == ncg - 1;
+    ld_cg = wrap_cg ? 0 : (wrap_ky ? ld_cg + 1 : ld_cg);
+    ld_next = ld_next || wrap_cg;
+  };
+  auto produce_point = [&](const v4f (&d)[6], unsigned short* bufp, int xi, int it) __attribute__((always_inline)) {
+    v4f V;
+    switch (xi) {
+      case 0: V = (W4_A2B2 * d[0] - W4_A2PB2 * d[2]) + d[4]; break;
+      case 1: V = (d[4] - W4_B2 * d[2]) + W4_A * (d[3] - W4_B2 * d[1]); break;
+      case 2: V = (d[4] - W4_B2 * d[2]) - W4_A * (d[3] - W4_B2 * d[1]); break;
+      case 3: V = (d[4] - W4_A2 * d[2]) + W4_B * (d[3] - W4_A2 * d[1]); break;
+      case 4: V = (d[4] - W4_A2 * d[2]) - W4_B * (d[3] - W4_A2 * d[1]); break;
+      default: V = (W4_A2B2 * d[1] - W4_A2PB2 * d[3]) + d[5]; break;
+    }
+    u2v h, m, l;
+    kocr_split4(V, h, m, l);
+    unsigned short* dst = bufp + xi * 3 * PLANE_N + ldst[it];
+    *reinterpret_cast<u2v*>(dst) = h;
+    *reinterpret_cast<u2v*>(dst + PLANE_N) = m;
+    *reinterpret_cast<u2v*>(dst + 2 * PLANE_N) = l;
+  };
+
+  // ---- consumer state ------------------------------------------------------------------------------------------
+  const int ntiles32 = p.Cout_pad >> 5;
+  const size_t w_step = (size_t)ntiles32 * 18 * 64 * 8;
+  auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * 2 + wn) * 18 * 64 + lane) * 8; };
+  bf8 bw[6][3];
+  f16v acc[6][2];
+  const int a_lane = (wm * 2 * 2 + l5) * KH_STRIDE + ((l31 * 8) ^ (l5 * 32));
+  auto load_a = [&](bf8 (&a)[2][3], const unsigned short* bufp, int xi) __attribute__((always_inline)) {
+    const unsigned short* base = bufp + xi * 3 * PLANE_N + a_lane;
+#pragma unroll
+    for (int s = 2; s >= 0; --s)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m][s] = *reinterpret_cast<const bf8*>(base + s * PLANE_N + m * 2 * KH_STRIDE);
+  };
+  auto mfma12 = [&](const bf8 (&a)[2][3], int xi) __attribute__((always_inline)) {
+    const bf8 b0 = bw[xi][0], b1 = bw[xi][1], b2 = bw[xi][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b0, acc[xi][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b2, acc[xi][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b1, acc[xi][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b0, acc[xi][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b1, acc[xi][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b0, acc[xi][m], 0, 0, 0);
+  };
+  // One K-step: per point, the LDS fetches of the next point, two transform-split-store chunks of the NEXT step
+  // (item 0's six points during points 0-2, item 1's during points 3-5) interleaved 1 MFMA : 5 VALU, 12 MFMAs, the
+  // re-fetch of this point's weights.  a0 holds point 0 on entry and on exit.
+  bf8 a0[2][3], a1[2][3];
+  auto step = [&](const unsigned short* bufc, unsigned short* bufn, const unsigned short* w_next) __attribute__((always_inline)) {
+    auto load_b = [&](int xi) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w_next + (size_t)(xi * 3 + s) * 64 * 8);
+    };
+    auto interleave = [&]() __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+      for (int i = 0; i < 11; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x200, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    };
+#pragma unroll
+    for (int ph = 0; ph < 6; ++ph) {
+      __builtin_amdgcn_sched_barrier(0);
+      bf8(&cur)[2][3] = (ph & 1) ? a1 : a0;
+      bf8(&nxt)[2][3] = (ph & 1) ? a0 : a1;
+      const int it = ph / 3, pt = 2 * (ph % 3);
+      if (ph < 5) {
+        load_a(nxt, bufc, ph + 1);
+        if (it == 0) {
+          produce_point(raw0, bufn, pt, 0);
+          produce_point(raw0, bufn, pt + 1, 0);
+        } else {
+          produce_point(raw1, bufn, pt, 1);
+          produce_point(raw1, bufn, pt + 1, 1);
+        }
+        mfma12(cur, ph);
+        interleave();
+      } else {
+        produce_point(raw1, bufn, 4, 1);
+        produce_point(raw1, bufn, 5, 1);
+        __syncthreads();  // next step complete in bufn, bufc free
+        load_a(nxt, bufn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(cur, 5);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(ph);
+      if (ph == 2) load_item(raw0, 0);  // item 0 is done with its registers: refill them with the step after next
+    }
+    load_item(raw1, 1);
+    advance();
+  };
+
+  // ---- prologue ------------------------------------------------------------------------------------------------
+  make_geo(blockIdx.x, gc);
+  make_geo(blockIdx.x + G, gn);
+  load_item(raw0, 0);
+  load_item(raw1, 1);
+  advance();  // global step 0 loaded
+  {
+    int mp0, nt0;
+    w4_decode(p, kocr_xcd_remap(blockIdx.x, total), nblk_n, mp0, nt0);
+    const unsigned short* w0 = w_tile(nt0);
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w0 + (size_t)(xi * 3 + s) * 64 * 8);
+  }
+#pragma unroll
+  for (int xi = 0; xi < 6; ++xi) {
+    produce_point(raw0, As, xi, 0);
+    produce_point(raw1, As, xi, 1);
+  }
+  load_item(raw0, 0);
+  load_item(raw1, 1);
+  advance();  // global step 1 loaded
+  __syncthreads();
+  load_a(a0, As, 0);
+
+  for (int L = blockIdx.x; L < total; L += G) {
+    int mp, nt, mp_n, nt_n;
+    w4_decode(p, kocr_xcd_remap(L, total), nblk_n, mp, nt);
+    w4_decode(p, kocr_xcd_remap(L + G < total ? L + G : L, total), nblk_n, mp_n, nt_n);
+    const int mtb = mp * NMT;
+    const unsigned short* w_ptr = w_tile(nt);
+    const unsigned short* w_after = w_tile(nt_n);
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][m][r] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int s = 0; s < ns; s += 2) {
+      step(As, As + BUF_N, w_ptr + (size_t)(s + 1) * w_step);
+      step(As + BUF_N, As, s + 2 < ns ? w_ptr + (size_t)(s + 2) * w_step : w_after);
+    }
+    gc = gn;
+    make_geo(L + 2 * G, gn);
+    ld_next = false;
+
+    // ---- epilogue (as conv_w43_kernel, M-tiles 2 wm + m) --------------------------------------------------------
+    {
+      const int n = (nt * 2 + wn) * 32 + l31;
+      const int nc = n < p.Cout ? n : p.Cout - 1;
+      const float pa = p.pre_a[nc], pb = p.pre_b[nc];
+      const bool has_post = p.post_a != nullptr;
+      const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
+      const bool live = n < p.Cout;
+      auto act = [&](float v) {
+        v = v * pa + pb;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (has_post) v = v * qa + qb;
+        return v;
+      };
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float m0 = acc[0][m][r], m1 = acc[1][m][r], m2 = acc[2][m][r], m3 = acc[3][m][r], m4 = acc[4][m][r],
+                      m5 = acc[5][m][r];
+          const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+          acc[0][m][r] = act((m0 + s12) + s34);
+          acc[1][m][r] = act(W4_A * d12 + W4_B * d34);
+          acc[2][m][r] = act(W4_A2 * s12 + W4_B2 * s34);
+          acc[3][m][r] = act((W4_A3 * d12 + W4_B3 * d34) + m5);
+        }
+      const int ocs4 = p.out_cs * 4;
+      if (p.amax_out || p.amax_pool) {
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[j][m][r]));
+        mx = live ? mx : 0.f;
+        if (p.amax_out) kocr_amax_update(p.amax_out, mx);
+        if (p.amax_pool) kocr_amax_update(p.amax_pool, mx);
+      }
+      if constexpr (POOL) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int mt = mtb + wm * 2 + m;
+          int y0, x0;
+          const long pm = w4_mtile_pm0<POOL>(p, mt < p.total_mtiles ? mt : mtb, y0, x0);
+          const bool mlive = live && mt < p.total_mtiles;
+          if (p.write_full) {
+            const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (pm * p.out_cs + p.out_co), 0x7FFFFFFFu);
+            const unsigned vo = mlive ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const int px = 4 * ((r & 3) + 8 * (r >> 2));
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vo, (px + j) * ocs4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r + 8]), ro, vo, (px + j + p.W) * ocs4, 0);
+              }
+            }
+          }
+          const long nimg = pm / ((long)p.H * p.W);
+          const long pp0 = (nimg * (p.H >> 1) + (y0 >> 1)) * (p.W >> 1) + (x0 >> 1);
+          const __amdgpu_buffer_rsrc_t rp = w4_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
+          const unsigned vp = mlive ? (unsigned)((8 * l5 * p.pool_cs + n) * 4) : OOB;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int pq = 2 * ((r & 3) + 8 * (r >> 2));
+            const float v0 = fmaxf(fmaxf(acc[0][m][r], acc[1][m][r]), fmaxf(acc[0][m][r + 8], acc[1][m][r + 8]));
+            const float v1 = fmaxf(fmaxf(acc[2][m][r], acc[3][m][r]), fmaxf(acc[2][m][r + 8], acc[3][m][r + 8]));
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * p.pool_cs * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * p.pool_cs * 4, 0);
+          }
+        }
+      } else {
+        int yy, xx;
+        const long pm0 = w4_mtile_pm0<POOL>(p, mtb, yy, xx);
+        const long rem = ((long)p.Mtotal - pm0) * ocs4;
+        const __amdgpu_buffer_rsrc_t ro =
+            w4_rsrc(p.out + (pm0 * p.out_cs + p.out_co), rem < 0x7FFFFFFFL ? (unsigned)(rem > 0 ? rem : 0) : 0x7FFFFFFFu);
+        const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int px = 4 * ((wm * 2 + m) * 32 + (r & 3) + 8 * (r >> 2));  // + 16 l5 in vo
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vo, (px + j) * ocs4, 0);
+          }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
 int prepare_w43(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
-  if (L.KH != 3 || L.KW != 3 || L.Cin % 32 != 0 || L.Cout <= 64) return KOCR_OK;  // any dilation: the taps' algebra is the same
+  // any dilation: the taps' algebra is the same.  32 < Cout <= 64: the 64-cout arrangement (dilation 1 only)
+  if (L.KH != 3 || L.KW != 3 || L.Cin % 32 != 0 || L.Cout <= 32 || (L.Cout <= 64 && L.dil != 1)) return KOCR_OK;
   const int Cin = L.Cin, Cout = L.Cout;
-  const int cp = (Cout + 127) / 128 * 128;
+  const int cp = Cout <= 64 ? 64 : (Cout + 127) / 128 * 128;
   const int nt32 = cp / 32;
   std::vector<unsigned short> u((size_t)(Cin / 16) * 3 * nt32 * 18 * 64 * 8, 0);
   for (int c = 0; c < Cin; ++c)
@@ -561,6 +902,27 @@ static int w4_launch(kocr_ctx* ctx, W4Params& p) {
   return KOCR_OK;
 }
 
+template <int POOL>
+static int w4n_launch(kocr_ctx* ctx, W4Params& p) {
+  constexpr int LDSN = 2 * LDS_BYTES;  // 2 x 72 KB
+  static bool attr_done[64] = {};
+  const int dev = ctx->device & 63;
+  if (!attr_done[dev]) {
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43n_kernel<POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSN));
+    attr_done[dev] = true;
+  }
+  static int n_cus[64] = {};
+  if (!n_cus[dev]) {
+    hipDeviceProp_t prop;
+    KOCR_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    n_cus[dev] = prop.multiProcessorCount;
+  }
+  const int grid = p.total_tiles < n_cus[dev] ? p.total_tiles : n_cus[dev];
+  hipLaunchKernelGGL((conv_w43n_kernel<POOL>), dim3(grid), dim3(256), LDSN, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
 int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool, bool need_full) {
   const bool fuse = pool && L.dil == 1 && in.H % 2 == 0 && in.W % 64 == 0;
   const size_t M = in.pixels();
@@ -598,8 +960,9 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
     p.write_full = need_full ? 1 : 0;
     p.tiles_per_row = in.W / 64;
   }
-  p.n_mpairs = (p.total_mtiles + 1) / 2;
-  p.total_tiles = p.n_mpairs * (p.Cout_pad / 128);
+  const bool narrow = L.w4_cout_pad == 64;  // 64-cout arrangement: 4 M-tiles x 64 couts per tile
+  p.n_mpairs = narrow ? (p.total_mtiles + 3) / 4 : (p.total_mtiles + 1) / 2;
+  p.total_tiles = p.n_mpairs * (p.Cout_pad / (narrow ? 64 : 128));
   // Tile order.  The split weights of one cout block are Cin * 3 * 128 * 36 B; with every cout block of a deep layer in
   // flight on an XCD they overflow its 4 MB L2 and are re-streamed from the Infinity Cache by every round of tiles.
   // Pixel-tile-fastest order keeps ONE cout block per XCD at a time (measured +4 % on 512 -> 512, neutral below).
@@ -608,9 +971,9 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_w4s_256x128%s:%s", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_w4s_%s%s:%s", narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_w4s_256x128%s", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
+    snprintf(nm, sizeof nm, "conv_w4s_%s%s", narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   {
@@ -638,7 +1001,12 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
       }
     }
 #endif
-    if (L.dil != 1)
+    if (narrow) {
+      if (fuse)
+        KOCR_TRY(w4n_launch<1>(ctx, p));
+      else
+        KOCR_TRY(w4n_launch<0>(ctx, p));
+    } else if (L.dil != 1)
       KOCR_TRY((w4_launch<0, 0, 1>(ctx, p)));
     else if (fuse)
       KOCR_TRY(w4_launch<1>(ctx, p));

@@ -15,6 +15,8 @@ SHAPES = [  # N, H, W, Cin, Cout, k  — CRAFT layer classes at 8 x 768x768
     (8, 384, 384, 32, 16, 3),
     (8, 192, 192, 512, 512, 3),  # slice3.27 at 8 x 1536x1536
     (8, 384, 384, 256, 256, 3),  # slice2.17 at 8 x 1536x1536
+    (1, 768, 768, 64, 64, 3),    # slice1.3 class, input 151 MB (Infinity-Cache resident on repeat)
+    (8, 1536, 1536, 64, 64, 3),  # slice1.3 at 8 x 1536x1536 (4.8 GB input: streams from HBM)
 ]
 if len(sys.argv) > 1:
     SHAPES = [SHAPES[int(a)] for a in sys.argv[1:]]

@@ -106,6 +106,10 @@ SPLIT_CASES = [
     (2, 17, 36, 64, 128),     # 12 K-steps, two images, odd height
     (1, 64, 128, 128, 256),   # two cout tiles per pixel tile
     (3, 8, 4, 32, 96),        # a single quad per row: both column paddings in one quad
+    # 32 < Cout <= 64: the 64-cout arrangement of conv_w43.hip (512-pixel tiles, two gather items per thread);
+    # (2, 64, 128, 64, 64) above takes it too
+    (1, 17, 36, 32, 48),      # ragged couts, odd height, last tile mostly outside
+    (2, 40, 128, 128, 64),    # upconv3.conv.3 class
 ]
 
 

@@ -277,3 +277,35 @@ def test_baseline_cfg3_size_crnn_order_independence(ctx, crnn_weights):
     perm = rng.permutation(512)
     b = ctx.crnn_forward(crops[perm])
     assert np.array_equal(b, a[perm])  # the recogniser runs the exact bf16x3 split in either mode
+
+
+def test_duck_typed_stages_take_the_reference_stagewise_path(pipe):
+    """A detector / recogniser that is not a libkocr-backed object (anything with ``detect`` /
+    ``recognize_from_boxes``, as the reference accepts) makes Pipeline.recognize fall back to the reference's own
+    sequence (pipeline.py:44-75) over the public stage APIs; with wrappers around the real stages the answer must be
+    the fused path's."""
+    import keras_ocr_amd
+
+    class Det:  # no _ctx attribute
+        def __init__(self, inner):
+            self.inner = inner
+
+        def detect(self, images, **kw):
+            return self.inner.detect(images, **kw)
+
+    class Rec:
+        def __init__(self, inner):
+            self.inner, self.alphabet = inner, inner.alphabet
+
+        def recognize_from_boxes(self, images, box_groups, **kw):
+            return self.inner.recognize_from_boxes(images, box_groups, **kw)
+
+    pages = [synth.text_page(96, 128, 5, seed=21), synth.text_page(80, 100, 4, seed=22)]
+    fused = pipe.recognize(pages)
+    p2 = keras_ocr_amd.pipeline.Pipeline(detector=Det(pipe.detector), recognizer=Rec(pipe.recognizer))
+    staged = p2.recognize(pages)
+    assert [[t for t, _ in g] for g in staged] == [[t for t, _ in g] for g in fused]
+    for ga, gb in zip(staged, fused):
+        assert all(np.array_equal(a[1], b[1]) for a, b in zip(ga, gb))
+    with pytest.raises(TypeError):
+        pipe.recognize([pages[0].astype(np.float32)])

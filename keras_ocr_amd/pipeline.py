@@ -111,7 +111,10 @@ class Pipeline:
 
     def assemble(self, box_groups, labels):
         """(box_groups, label rows) -> the reference's return value (pipeline.py:72-75)."""
-        predictions = self.recognizer._decode(labels)  # pylint: disable=protected-access
+        # recognition.py:527-534: label rows -> strings, skipping the blank (= len(alphabet)) and the -1 padding
+        alphabet = self.recognizer.alphabet
+        skip = (len(alphabet), -1)
+        predictions = ["".join(alphabet[idx] for idx in row if idx not in skip) for row in np.asarray(labels)]
         out, start = [], 0
         for boxes in box_groups:
             out.append(list(zip(predictions[start:start + len(boxes)], boxes)))

@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include "../../include/kocr.h"

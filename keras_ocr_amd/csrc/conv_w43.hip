@@ -884,19 +884,20 @@ bool w43_applicable(const kocr_ctx* ctx, const ConvLayer& L, const Tensor& in) {
 
 template <int POOL, int DBG = 0, int DIL = 0>
 static int w4_launch(kocr_ctx* ctx, W4Params& p) {
-  static bool attr_done[64] = {};  // per device: one process may hold contexts on several GPUs
+  static std::atomic<bool> attr_done[64];  // per device (one process may hold contexts on several GPUs); a race only repeats the call
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
     KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43_kernel<POOL, DBG, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done[dev] = true;
   }
-  static int n_cus[64] = {};
+  static std::atomic<int> n_cus[64];
   if (!n_cus[dev]) {
     hipDeviceProp_t prop;
     KOCR_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
     n_cus[dev] = prop.multiProcessorCount;
   }
-  const int grid = p.total_tiles < n_cus[dev] ? p.total_tiles : n_cus[dev];  // persistent: one block per CU
+  const int n_cu = n_cus[dev];
+  const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;  // persistent: one block per CU
   hipLaunchKernelGGL((conv_w43_kernel<POOL, DBG, DIL>), dim3(grid), dim3(256), LDS_BYTES, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
@@ -905,19 +906,20 @@ static int w4_launch(kocr_ctx* ctx, W4Params& p) {
 template <int POOL>
 static int w4n_launch(kocr_ctx* ctx, W4Params& p) {
   constexpr int LDSN = 2 * LDS_BYTES;  // 2 x 72 KB
-  static bool attr_done[64] = {};
+  static std::atomic<bool> attr_done[64];
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
     KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43n_kernel<POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSN));
     attr_done[dev] = true;
   }
-  static int n_cus[64] = {};
+  static std::atomic<int> n_cus[64];
   if (!n_cus[dev]) {
     hipDeviceProp_t prop;
     KOCR_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
     n_cus[dev] = prop.multiProcessorCount;
   }
-  const int grid = p.total_tiles < n_cus[dev] ? p.total_tiles : n_cus[dev];
+  const int n_cu = n_cus[dev];
+  const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
   hipLaunchKernelGGL((conv_w43n_kernel<POOL>), dim3(grid), dim3(256), LDSN, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;

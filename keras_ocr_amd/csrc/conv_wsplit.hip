@@ -593,14 +593,14 @@ bool wsplit_applicable(const ConvLayer& L, const Tensor& in) {
 template <int POOL, int WM, int WN, int HALF, int KB>
 static int ws_launch(kocr_ctx* ctx, WsParams& p, size_t M) {
   constexpr int LDS_BYTES = 2 * 4 * (HALF ? 2 : 3) * KB * (2 * WM) * 2 * 256 * 2;  // 48 / 96 KB (bf16x3), 32 / 64 KB * KB (fp16x2)
-  static bool attr_done[64] = {};  // per device: one process may hold contexts on several GPUs
+  static std::atomic<bool> attr_done[64];  // per device (one process may hold contexts on several GPUs); a race only repeats the call
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
     KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_ws_kernel<POOL, WM, WN, HALF, KB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       LDS_BYTES));
     attr_done[dev] = true;
   }
-  static int n_cus[64] = {};
+  static std::atomic<int> n_cus[64];
   if (!n_cus[dev]) {
     hipDeviceProp_t prop;
     KOCR_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));

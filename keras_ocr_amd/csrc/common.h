@@ -216,7 +216,8 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
 // conv_dsplit.hip
 int prepare_dsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
 bool dsplit_applicable(const ConvLayer& L, const Tensor& in);
-int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out);
+bool dsplit_usable(const ConvLayer& L, const Tensor& in);
+int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* up = nullptr);
 // elementwise.hip
 // row_off: input row that starts output row 0 (0 = keras 'valid' pooling; 1 = the same pooling seen
 // through a vertical flip of an odd-height tensor, as in the CRNN's natural-orientation conv stack)

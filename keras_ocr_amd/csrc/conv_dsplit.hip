@@ -36,9 +36,13 @@ struct DsParams {
   const unsigned* amax_in;  // HALF kernels: tracked max |input| (Tensor::amax), never null there
   int w_exp;                // HALF kernels: the weights are stored multiplied by 2^w_exp
   unsigned* amax_out;  // Tensor::amax of the output or nullptr
+  // UP kernels: out = epilogue(acc + bilinear_resize(up)[pixel][cout]) -- see launch_conv_dsplit
+  const float* up;     // [N][up_H][up_W][Cout] contiguous
+  int up_H, up_W;
+  float up_sy, up_sx;  // up_H / H, up_W / W
 };
 
-template <int WM, int WN, int HALF>
+template <int WM, int WN, int HALF, int UP>
 __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
   constexpr int NP = HALF ? 2 : 3;            // operand pieces
   constexpr int NMT = 8 * WM;                 // 32-pixel M-tiles per block tile
@@ -267,6 +271,76 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
       const float pa = p.pre_a[nc] * unscale, pb = p.pre_b[nc];
       const bool has_post = p.post_a != nullptr;
       const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
+      if constexpr (UP) {
+        // acc += the low-resolution tensor `up` resized bilinearly to this layer's H x W (the resize_bilinear_kernel
+        // formula, elementwise.hip).  The four tap offsets and two weights of a pixel are the same for every output
+        // channel: each wave works them out once for its 256 pixels (4 per lane) into a private LDS table -- no
+        // block barrier, a wave's DS operations execute in order -- and then reads one 32-byte entry per pixel.
+        unsigned* tab = reinterpret_cast<unsigned*>(As + 2 * BUF) + wave * (256 * 8);
+        const long wbase = pm0 + (long)wm * 256;
+        const unsigned ucs4 = (unsigned)p.Cout * 4u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int q = lane + 64 * i;
+          long gl = wbase + q;
+          if (gl > (long)p.Mtotal - 1) gl = (long)p.Mtotal - 1;
+          const int gi = (int)gl;
+          const int ox = gi % p.W, t2 = gi / p.W;
+          const int oy = t2 % p.H, ni = t2 / p.H;
+          const float fy = ((float)oy + 0.5f) * p.up_sy - 0.5f;
+          const float fx = ((float)ox + 0.5f) * p.up_sx - 0.5f;
+          const float fly = floorf(fy), flx = floorf(fx);
+          const int y0 = max((int)fly, 0), y1 = min((int)ceilf(fy), p.up_H - 1);
+          const int x0 = max((int)flx, 0), x1 = min((int)ceilf(fx), p.up_W - 1);
+          const unsigned r0 = (unsigned)((ni * p.up_H + y0) * p.up_W), r1 = (unsigned)((ni * p.up_H + y1) * p.up_W);
+          uint4 o4;
+          o4.x = (r0 + x0) * ucs4;
+          o4.y = (r0 + x1) * ucs4;
+          o4.z = (r1 + x0) * ucs4;
+          o4.w = (r1 + x1) * ucs4;
+          *reinterpret_cast<uint4*>(tab + q * 8) = o4;
+          float2 wl;
+          wl.x = fx - flx;
+          wl.y = fy - fly;
+          *reinterpret_cast<float2*>(tab + q * 8 + 4) = wl;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long ub = (unsigned long long)p.up;
+        const unsigned long long ubu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)ub);
+        const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)ubu, 0, 0x7FFFFFFF, 0x00020000);
+        const unsigned ch = (unsigned)nc * 4u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const unsigned* e = tab + ((g * 2 + m) * 32 + 8 * rr + 4 * l5) * 8;
+              uint4 o4[4];
+              float2 wl[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                o4[j] = *reinterpret_cast<const uint4*>(e + j * 8);
+                wl[j] = *reinterpret_cast<const float2*>(e + j * 8 + 4);
+              }
+              float v[4][4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                v[j][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o4[j].x + ch, 0, 0));
+                v[j][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o4[j].y + ch, 0, 0));
+                v[j][2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o4[j].z + ch, 0, 0));
+                v[j][3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, o4[j].w + ch, 0, 0));
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float top = v[j][0] + (v[j][1] - v[j][0]) * wl[j].x;
+                const float bot = v[j][2] + (v[j][3] - v[j][2]) * wl[j].x;
+                acc[g][m][rr * 4 + j] += top + (bot - top) * wl[j].y;
+              }
+            }
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -368,20 +442,25 @@ int prepare_dsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) 
   return KOCR_OK;
 }
 
-bool dsplit_applicable(const ConvLayer& L, const Tensor& in) {
+// the kernel can run this layer on this input (any size)
+bool dsplit_usable(const ConvLayer& L, const Tensor& in) {
   static const bool off = getenv("KOCR_DSPLIT") && atoi(getenv("KOCR_DSPLIT")) == 0;
-  // small GEMMs (the CRNN's dense layers) stay on the fp32 kernel: nothing to gain below a few tiles
-  return !off && L.d_ds && in.cs % 4 == 0 && in.co % 4 == 0 && ((uintptr_t)in.p & 15) == 0 && in.pixels() >= 4096 &&
+  return !off && L.d_ds && in.cs % 4 == 0 && in.co % 4 == 0 && ((uintptr_t)in.p & 15) == 0 &&
          (size_t)in.pixels() * in.cs < ((size_t)1 << 40);
 }
 
-template <int WM, int WN, int HALF>
+// ... and launch_conv's dispatch prefers it: small GEMMs (the CRNN's dense layers) stay on the fp32 kernel, nothing to
+// gain below a few tiles
+bool dsplit_applicable(const ConvLayer& L, const Tensor& in) { return dsplit_usable(L, in) && in.pixels() >= 4096; }
+
+template <int WM, int WN, int HALF, int UP = 0>
 static int ds_launch(kocr_ctx* ctx, DsParams& p, size_t M) {
-  constexpr int LDS_BYTES = 2 * (HALF ? 2 : 3) * (8 * WM) * 2 * 256 * 2;  // 48 / 96 KB (bf16x3), 32 / 64 KB (fp16x2)
+  // 48 / 96 KB (bf16x3), 32 / 64 KB (fp16x2); UP: + one 8 KB tap table per consumer wave
+  constexpr int LDS_BYTES = 2 * (HALF ? 2 : 3) * (8 * WM) * 2 * 256 * 2 + (UP ? 4 * 256 * 32 : 0);
   static std::atomic<bool> attr_done[64];  // per device (one process may hold contexts on several GPUs); a race only repeats the call
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
-    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_ds_kernel<WM, WN, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_ds_kernel<WM, WN, HALF, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done[dev] = true;
   }
   static std::atomic<int> n_cus[64];
@@ -394,12 +473,17 @@ static int ds_launch(kocr_ctx* ctx, DsParams& p, size_t M) {
   const size_t mtiles = (M + 256 * WM - 1) / (256 * WM);
   p.total_tiles = (int)(mtiles * (p.Cout_pad / (32 * WN)));
   const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
-  hipLaunchKernelGGL((conv_ds_kernel<WM, WN, HALF>), dim3(grid), dim3(512), LDS_BYTES, ctx->stream, p);
+  hipLaunchKernelGGL((conv_ds_kernel<WM, WN, HALF, UP>), dim3(grid), dim3(512), LDS_BYTES, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }
 
-int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out) {
+// `up` (optional, bf16x3 mode only): a [N][h][w][Cout] tensor that is resized bilinearly to the output's H x W and added
+// to the accumulators before the epilogue.  craft.cpp uses it to evaluate the decoder's
+// conv1x1(concat(resize(y), skip)) (detection.py:106-115, 380-389) as resize(conv1x1_y(y)) + conv1x1_skip(skip): a
+// 1x1 convolution commutes with the (linear, per-channel) resize, so the y half of the products runs at a quarter of
+// the pixels and the up-sampled tensor is never written.
+int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* up) {
   const size_t M = in.pixels();
   DsParams p;
   p.in = in.p;
@@ -427,6 +511,19 @@ int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   p.total_tiles = 0;
   p.amax_out = out.amax;
   const bool half = ctx->split_mode == KOCR_SPLIT_F16X2 && L.d_ds16;
+  p.up = nullptr;
+  p.up_H = p.up_W = 0;
+  p.up_sy = p.up_sx = 0.f;
+  if (up) {
+    if (half || up->C != L.Cout || up->cs != L.Cout || up->co != 0 || up->N != in.N || L.KH != 1 || L.KW != 1 ||
+        up->pixels() * (size_t)L.Cout * 4 >= ((size_t)1 << 31))
+      KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": unsupported up-sampled addend");
+    p.up = up->p;
+    p.up_H = up->H;
+    p.up_W = up->W;
+    p.up_sy = (float)up->H / (float)in.H;
+    p.up_sx = (float)up->W / (float)in.W;
+  }
   p.amax_in = nullptr;
   p.w_exp = 0;
   if (half) {
@@ -445,12 +542,13 @@ int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_d%s_%dx%d:%s", half ? "h" : "s", wcls == 128 ? 256 : 512, wcls, L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_d%s_%dx%d%s:%s", half ? "h" : "s", wcls == 128 ? 256 : 512, wcls, up ? "_up" : "", L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_d%s_%dx%d", half ? "h" : "s", wcls == 128 ? 256 : 512, wcls);
+    snprintf(nm, sizeof nm, "conv_d%s_%dx%d%s", half ? "h" : "s", wcls == 128 ? 256 : 512, wcls, up ? "_up" : "");
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
-  const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
+  const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout + (up ? (double)up->pixels() * L.Cout : 0.0));
   ProfScope ps(ctx, nm, flops, bytes);
+  if (up) return wcls == 128 ? ds_launch<1, 4, 0, 1>(ctx, p, M) : ds_launch<2, 2, 0, 1>(ctx, p, M);
   if (half) return wcls == 128 ? ds_launch<1, 4, 1>(ctx, p, M) : ds_launch<2, 2, 1>(ctx, p, M);
   return wcls == 128 ? ds_launch<1, 4, 0>(ctx, p, M) : ds_launch<2, 2, 0>(ctx, p, M);
 }

@@ -11,6 +11,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cmath>
+#include <thread>
 
 struct CraftNet {
   std::map<std::string, ConvLayer> L;
@@ -56,6 +57,31 @@ const Spec kSpecs[] = {
     {"conv_cls.6", nullptr, 16, 16, 1, 1, 1},
     {"conv_cls.8", nullptr, 16, 2, 1, 1, 0},
 };
+
+// channels of the up-sampled decoder tensor y at the head of the concat a 1x1 layer reads (detection.py:380-389)
+int fold_channels(const char* conv) {
+  const std::string n = conv;
+  return n == "upconv2.conv.0" ? 256 : n == "upconv3.conv.0" ? 128 : n == "upconv4.conv.0" ? 64 : 0;
+}
+
+// C[m][n] = A[m][k] * B[k][n] in float64 (row-major), rows of C spread over a few host threads; load-time only
+void matmul_f64(const double* A, const double* B, double* C, int m, int k, int n) {
+  const int nt = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([=]() {
+      for (int i = t; i < m; i += nt) {
+        double* c = C + (size_t)i * n;
+        std::fill(c, c + n, 0.0);
+        for (int kk = 0; kk < k; ++kk) {
+          const double a = A[(size_t)i * k + kk];
+          const double* b = B + (size_t)kk * n;
+          for (int j = 0; j < n; ++j) c[j] += a * b[j];
+        }
+      }
+    });
+  for (auto& x : th) x.join();
+}
 
 struct Blob {
   const float* p;
@@ -113,6 +139,74 @@ int craft_load(kocr_ctx* ctx, int n, const char* const* names, const float* cons
     L.name = s.conv;
     KOCR_TRY(prepare_conv(ctx, L, w->p, /*oihw=*/true, s.cin, s.cout, s.k, s.k, s.dil, pa.data(),
                           pb.data(), s.relu, nullptr, nullptr));
+    // The decoder's 1x1 convolutions over concat(resize(y), skip), split by input-channel range (see up_conv below):
+    // "<name>#y" = the y columns, no bias / BN / ReLU; "<name>#skip" = the skip columns with the layer's epilogue.
+    const int c_y = fold_channels(s.conv);
+    if (c_y) {
+      std::vector<float> wy((size_t)s.cout * c_y), wsk((size_t)s.cout * (s.cin - c_y));
+      for (int o = 0; o < s.cout; ++o)
+        for (int c = 0; c < s.cin; ++c)
+          (c < c_y ? wy[(size_t)o * c_y + c] : wsk[(size_t)o * (s.cin - c_y) + (c - c_y)]) = w->p[(size_t)o * s.cin + c];
+      ConvLayer& Ly = net->L[std::string(s.conv) + "#y"];
+      Ly.name = std::string(s.conv) + "#y";
+      KOCR_TRY(prepare_conv(ctx, Ly, wy.data(), true, c_y, s.cout, 1, 1, 1, nullptr, nullptr, 0, nullptr, nullptr));
+      ConvLayer& Ls = net->L[std::string(s.conv) + "#skip"];
+      Ls.name = std::string(s.conv) + "#skip";
+      KOCR_TRY(prepare_conv(ctx, Ls, wsk.data(), true, s.cin - c_y, s.cout, 1, 1, 1, pa.data(), pb.data(), s.relu, nullptr, nullptr));
+    }
+  }
+  // slice5.1 (3x3, dilation 6) -> slice5.2 (1x1) -> [concat with s4] -> upconv1.conv.0 (1x1) has NO non-linearity between
+  // its three convolutions (detection.py:349-353: Conv2D, Conv2D without activation; :106-108 the upconv's first Conv2D
+  // precedes its BatchNorm/ReLU), so the chain is one linear map of (pool(s4), s4):
+  //     Wu_a (W2 (W1 * h0 + b1) + b2) + Wu_b s4 + bu  =  (Wu_a W2 W1) * h0  +  Wu_b s4  +  Wu_a (W2 b1 + b2) + bu
+  // The composite 3x3 dilated 512 -> 512 kernel is formed once, in float64, here; the forward then runs it plus a
+  // 512 -> 512 1x1 over s4 instead of 512 -> 1024 (3x3), 1024 -> 1024 and 1536 -> 512: 40 % of the products, and the two
+  // 1024-channel tensors are never written.  Same sum up to fp32 round-off (the intermediates are no longer rounded to
+  // fp32); craft_run uses it in bf16x3 mode unless KOCR_LINFOLD=0.
+  {
+    const Blob *w1, *b1, *w2, *b2, *wu, *bu;
+    KOCR_TRY(need("basenet.slice5.1.weight", (size_t)1024 * 512 * 9, &w1));
+    KOCR_TRY(need("basenet.slice5.1.bias", 1024, &b1));
+    KOCR_TRY(need("basenet.slice5.2.weight", (size_t)1024 * 1024, &w2));
+    KOCR_TRY(need("basenet.slice5.2.bias", 1024, &b2));
+    KOCR_TRY(need("upconv1.conv.0.weight", (size_t)512 * 1536, &wu));
+    KOCR_TRY(need("upconv1.conv.0.bias", 512, &bu));
+    std::vector<double> A((size_t)512 * 1024), B(w2->p, w2->p + (size_t)1024 * 1024), P((size_t)512 * 1024);
+    std::vector<float> wskip((size_t)512 * 512);
+    for (int o = 0; o < 512; ++o)
+      for (int c = 0; c < 1536; ++c) {
+        if (c < 1024)
+          A[(size_t)o * 1024 + c] = wu->p[(size_t)o * 1536 + c];
+        else
+          wskip[(size_t)o * 512 + (c - 1024)] = wu->p[(size_t)o * 1536 + c];
+      }
+    matmul_f64(A.data(), B.data(), P.data(), 512, 1024, 1024);  // Wu_a W2
+    std::vector<double> W1(w1->p, w1->p + (size_t)1024 * 4608), Wc((size_t)512 * 4608);
+    matmul_f64(P.data(), W1.data(), Wc.data(), 512, 1024, 4608);  // (Wu_a W2) W1: [512][512][3][3]
+    std::vector<float> wc(Wc.begin(), Wc.end());
+    std::vector<double> c0(512);
+    for (int o = 0; o < 512; ++o) {
+      double acc = 0;
+      for (int c = 0; c < 1024; ++c) acc += P[(size_t)o * 1024 + c] * (double)b1->p[c] + A[(size_t)o * 1024 + c] * (double)b2->p[c];
+      c0[o] = acc;
+    }
+    const Blob *g, *be, *mu, *var;
+    KOCR_TRY(need("upconv1.conv.1.weight", 512, &g));
+    KOCR_TRY(need("upconv1.conv.1.bias", 512, &be));
+    KOCR_TRY(need("upconv1.conv.1.running_mean", 512, &mu));
+    KOCR_TRY(need("upconv1.conv.1.running_var", 512, &var));
+    std::vector<float> pa(512), pb(512);
+    for (int o = 0; o < 512; ++o) {
+      const float sc = g->p[o] / std::sqrt(var->p[o] + 1e-5f);
+      pa[o] = sc;
+      pb[o] = (float)(((double)bu->p[o] + c0[o] - (double)mu->p[o]) * (double)sc + (double)be->p[o]);
+    }
+    ConvLayer& Lf = net->L["basenet.slice5#fold"];
+    Lf.name = "basenet.slice5#fold";
+    KOCR_TRY(prepare_conv(ctx, Lf, wc.data(), true, 512, 512, 3, 3, 6, nullptr, nullptr, 0, nullptr, nullptr));
+    ConvLayer& Ls = net->L["upconv1.conv.0#skip"];
+    Ls.name = "upconv1.conv.0#skip";
+    KOCR_TRY(prepare_conv(ctx, Ls, wskip.data(), true, 512, 512, 1, 1, 1, pa.data(), pb.data(), 1, nullptr, nullptr));
   }
   // compute_input (detection.py:34-42): float32 image; image -= mean*255 (float64 math, stored
   // back as float32); image /= variance*255 (same).
@@ -309,39 +403,74 @@ int craft_run(kocr_ctx* ctx, CraftNet* net, const void* d_img, int dtype, int N,
   KOCR_TRY(mk(d.H16, d.W16, 512, &h0));
   RUN(launch_maxpool3x3s1(ctx, s4, h0));
   KOCR_TRY(mk(d.H16, d.W16, 1024, &h1));
-  RUN(launch_conv(ctx, L("basenet.slice5.1"), h0, nullptr, nullptr, h1));
-  done(h0);
-  RUN(launch_conv(ctx, L("basenet.slice5.2"), h1, nullptr, nullptr, cat1.slice(0, 1024)));
-  done(h1);
-  // ---- U-Net decoder (detection.py:380-390) ---------------------------------------------
-  Tensor u1a, u1b, u2a, u2b, u3a, u3b, u4a, feat, k0, k1, k2;
+  Tensor u1a;
   KOCR_TRY(mk(d.H16, d.W16, 512, &u1a));
-  RUN(launch_conv(ctx, L("upconv1.conv.0"), cat1, nullptr, nullptr, u1a));
+  bool lin_fold = false;
+  if constexpr (!DRY) {
+    const char* off = getenv("KOCR_LINFOLD");
+    lin_fold = !(off && atoi(off) == 0) && ctx->split_mode == KOCR_SPLIT_BF16X3 && dsplit_usable(L("upconv1.conv.0#skip"), s4) &&
+               h0.pixels() * (size_t)512 * 4 < ((size_t)1 << 31);
+    if (lin_fold) {  // see craft_load: slice5.1 -> slice5.2 -> upconv1.conv.0 as one dilated 3x3 plus a 1x1 over s4
+      Tensor t = h1;  // the first half of h1's buffer, as a contiguous 512-channel tensor
+      t.C = t.cs = 512;
+      KOCR_TRY(launch_conv(ctx, L("basenet.slice5#fold"), h0, nullptr, nullptr, t));
+      KOCR_TRY(launch_conv_dsplit(ctx, L("upconv1.conv.0#skip"), s4, u1a, &t));
+    } else {
+      KOCR_TRY(launch_conv(ctx, L("basenet.slice5.1"), h0, nullptr, nullptr, h1));
+      KOCR_TRY(launch_conv(ctx, L("basenet.slice5.2"), h1, nullptr, nullptr, cat1.slice(0, 1024)));
+      KOCR_TRY(launch_conv(ctx, L("upconv1.conv.0"), cat1, nullptr, nullptr, u1a));
+    }
+  }
+  done(h0);
+  done(h1);
   done(cat1);
+  // ---- U-Net decoder (detection.py:380-390) ---------------------------------------------
+  // conv1x1(concat(resize(y), skip)) -> BN -> ReLU.  A 1x1 convolution commutes with the bilinear resize (both are linear
+  // and the resize acts per channel), so the y columns of the weight matrix are applied at y's own resolution -- a
+  // quarter of the pixels -- and conv_dsplit's epilogue adds the resized product to the skip columns' sum: the
+  // up-sampled tensor is never written, and a quarter of the layer's products disappear (same sum, different rounding
+  // order: fp32 round-off, like the Winograd layers).  bf16x3 mode only; KOCR_UPFOLD=0, the fp16 mode and shapes the
+  // split kernel does not take run resize + convolution over the concat buffer as before.  `t` is allocated either
+  // way so that the dry run sizes the workspace for both.
+  auto up_conv = [&](const char* name, Tensor& y, Tensor& cat, Tensor& out) -> int {
+    const int c_y = y.C;
+    Tensor t;
+    KOCR_TRY(mk(y.H, y.W, out.C, &t));
+    if constexpr (!DRY) {
+      const ConvLayer& Ls = L((std::string(name) + "#skip").c_str());
+      const Tensor skip = cat.slice(c_y, cat.C - c_y);
+      const char* off = getenv("KOCR_UPFOLD");
+      const bool fold = !(off && atoi(off) == 0) && ctx->split_mode == KOCR_SPLIT_BF16X3 && dsplit_usable(Ls, skip) &&
+                        t.pixels() * (size_t)t.C * 4 < ((size_t)1 << 31);
+      if (fold) {
+        KOCR_TRY(launch_conv(ctx, L((std::string(name) + "#y").c_str()), y, nullptr, nullptr, t));
+        KOCR_TRY(launch_conv_dsplit(ctx, Ls, skip, out, &t));
+      } else {
+        KOCR_TRY(launch_resize_bilinear(ctx, y, cat.slice(0, c_y)));
+        KOCR_TRY(launch_conv(ctx, L(name), cat, nullptr, nullptr, out));
+      }
+    }
+    done(t);
+    done(y);
+    done(cat);
+    return KOCR_OK;
+  };
+  Tensor u1b, u2a, u2b, u3a, u3b, u4a, feat, k0, k1, k2;
   KOCR_TRY(mk(d.H16, d.W16, 256, &u1b));
   RUN(launch_conv(ctx, L("upconv1.conv.3"), u1a, nullptr, nullptr, u1b));
   done(u1a);
-  RUN(launch_resize_bilinear(ctx, u1b, cat2.slice(0, 256)));
-  done(u1b);
   KOCR_TRY(mk(d.H8, d.W8, 256, &u2a));
-  RUN(launch_conv(ctx, L("upconv2.conv.0"), cat2, nullptr, nullptr, u2a));
-  done(cat2);
+  KOCR_TRY(up_conv("upconv2.conv.0", u1b, cat2, u2a));
   KOCR_TRY(mk(d.H8, d.W8, 128, &u2b));
   RUN(launch_conv(ctx, L("upconv2.conv.3"), u2a, nullptr, nullptr, u2b));
   done(u2a);
-  RUN(launch_resize_bilinear(ctx, u2b, cat3.slice(0, 128)));
-  done(u2b);
   KOCR_TRY(mk(d.H4, d.W4, 128, &u3a));
-  RUN(launch_conv(ctx, L("upconv3.conv.0"), cat3, nullptr, nullptr, u3a));
-  done(cat3);
+  KOCR_TRY(up_conv("upconv3.conv.0", u2b, cat3, u3a));
   KOCR_TRY(mk(d.H4, d.W4, 64, &u3b));
   RUN(launch_conv(ctx, L("upconv3.conv.3"), u3a, nullptr, nullptr, u3b));
   done(u3a);
-  RUN(launch_resize_bilinear(ctx, u3b, cat4.slice(0, 64)));
-  done(u3b);
   KOCR_TRY(mk(d.H2, d.W2, 64, &u4a));
-  RUN(launch_conv(ctx, L("upconv4.conv.0"), cat4, nullptr, nullptr, u4a));
-  done(cat4);
+  KOCR_TRY(up_conv("upconv4.conv.0", u3b, cat4, u4a));
   KOCR_TRY(mk(d.H2, d.W2, 32, &feat));
   RUN(launch_conv(ctx, L("upconv4.conv.3"), u4a, nullptr, nullptr, feat));
   done(u4a);

@@ -77,3 +77,37 @@ def test_heatmap_at_baseline_cfg2_size(craft_ctx, craft_weights):
     want = ocraft.detector_predict(craft_weights, img)
     err = float(np.abs(got - want).max())
     assert err <= HEAT_TOL, f"max abs heat-map error {err}"
+
+
+@pytest.mark.parametrize("shape", [(1, 520, 392), (2, 96, 80), (1, 1024, 1024)])
+def test_folded_linear_layers_equal_the_plain_schedule(craft_ctx, craft_weights, monkeypatch, shape):
+    """Two load-time / schedule-level rewrites of consecutive LINEAR layers (craft.cpp, bf16x3 mode) against the plain
+    layer-by-layer schedule and against the oracle:
+      KOCR_UPFOLD  -- conv1x1(concat(resize(y), skip)) as resize(conv1x1_y(y)) + conv1x1_skip(skip);
+      KOCR_LINFOLD -- slice5.1 (3x3 dil 6) -> slice5.2 (1x1) -> upconv1.conv.0 (1x1 over the concat with s4), which have
+                      no non-linearity between them, as ONE dilated 3x3 512 -> 512 (float64-composed weights) + a 1x1 on s4.
+    520x392 has levels that are not exact halves (65 -> 32: resize ratio 0.492)."""
+    from oracle import craft as ocraft
+    from tests import synth
+
+    n, h, w = shape
+    if min(h, w) >= 200:
+        img = np.stack([synth.text_page(h, w, 12, seed=5 + i) for i in range(n)])
+    else:
+        img = np.random.default_rng(5).integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    want = ocraft.detector_predict(craft_weights, img)
+    got = {}
+    for name, env in (("folded", {}), ("no_upfold", {"KOCR_UPFOLD": "0"}), ("no_linfold", {"KOCR_LINFOLD": "0"}),
+                      ("plain", {"KOCR_UPFOLD": "0", "KOCR_LINFOLD": "0"})):
+        for k in ("KOCR_UPFOLD", "KOCR_LINFOLD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got[name] = craft_ctx.craft_forward(img)
+    for k in ("KOCR_UPFOLD", "KOCR_LINFOLD"):
+        monkeypatch.delenv(k, raising=False)
+    errs = {k: float(np.abs(v - want).max()) for k, v in got.items()}
+    d = {k: float(np.abs(v - got["plain"]).max()) for k, v in got.items()}
+    print(f"{shape}: heat-map error vs oracle {errs}; vs plain schedule {d}")
+    assert max(errs.values()) <= HEAT_TOL
+    assert max(d.values()) <= 5e-5

@@ -1,0 +1,251 @@
+// conv_hsplit.hip — 3x3 / stride 1 / dilation 1 'same' convolution with FEW output channels (<= 32) on the gfx950 BF16
+// matrix cores, fp32 operands split exactly into three bf16 pieces (six of the nine piece products kept, fp32
+// accumulation): the arithmetic of conv_dsplit.hip, arranged for the CRAFT head (detection.py:392-406: conv_cls.0 / .2
+// 32 -> 32, conv_cls.4 32 -> 16) and the decoder's last 3x3 (detection.py:109-113: upconv4.conv.3, 64 -> 32).
+//
+// With 32 output channels a (pixel, channel) operand is used by only 32 x 9 products, so the cost that decides the layout
+// is the operand preparation, not the matrix pipe: conv_dsplit.hip gathers and splits the input once per TAP (9 x), the
+// Winograd kernels transform it once per kernel row (3 x) and amortise that over >= 64 channels.  Here the haloed input
+// tile is split ONCE into LDS and every tap reads it back at a shifted address:
+//
+//   block = 256 threads (4 waves), tile = 8 rows x 32 columns of one image; per 16-channel chunk the 10 x 34 halo tile is
+//   loaded with raw buffer loads (out-of-image offsets return the zero padding), split, and stored as three bf16 planes
+//   [pixel][16 ch] with a 48-byte pixel stride (odd multiple of 16 B: the 16-byte A-operand reads of 32 neighbouring
+//   pixels are conflict-free);  wave w owns rows 2w, 2w+1 = two 32-pixel M-tiles x 32 couts (32 accumulators);  per
+//   (chunk, tap): 6 ds_read_b128 + 3 weight loads (16 B per lane, L1/L2 resident: 27 KB per chunk) + 12 MFMA 32x32x16.
+//   The next chunk's raw pixels are in flight while the current one is multiplied;  one buffer, two barriers per chunk --
+//   48 KB of LDS and ~100 registers let three blocks share a CU, which is what hides the barriers.
+#include "split_common.h"
+#include <algorithm>
+#include <atomic>
+
+struct HsParams {
+  const float* in;
+  const unsigned short* wgt;  // [Cin/16][9 taps][3 pieces][64 lanes][8]
+  float* out;
+  const float* pre_a;
+  const float* pre_b;
+  const float* post_a;
+  const float* post_b;
+  int H, W, Cin, in_cs, in_co;
+  int Cout, out_cs, out_co;
+  int relu;
+  int tiles_x, tiles_y;
+  unsigned* amax_out;
+};
+
+namespace {
+constexpr int HS_TH = 8, HS_TW = 32;
+constexpr int HS_HH = HS_TH + 2, HS_HW = HS_TW + 2;
+constexpr int HS_NPX = HS_HH * HS_HW;        // 340 halo pixels
+constexpr int HS_PS = 24;                    // ushorts per pixel of a plane: 16 channels + 8 padding (48 bytes)
+constexpr int HS_PLANE = HS_NPX * HS_PS;     // 8160 ushorts
+constexpr int HS_IPT = (HS_NPX * 4 + 255) / 256;  // gather items (pixel, channel quad) per thread: 6
+}  // namespace
+
+__global__ __launch_bounds__(256, 3) void conv_hs_kernel(HsParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[3 * HS_PLANE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, l5 = lane >> 5;
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x;
+  t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int n = t / p.tiles_y;
+  const int y0 = ty * HS_TH, x0 = tx * HS_TW;
+  constexpr unsigned OOB = 0x80000000u;
+
+  // one buffer resource per image: offsets stay below 2^31
+  const float* img = p.in + (size_t)n * p.H * p.W * p.in_cs + p.in_co;
+  const unsigned long long ib = (unsigned long long)img;
+  const unsigned long long ibu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ib >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)ib);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ibu, 0, 0x80000000, 0x00020000);
+
+  unsigned goff[HS_IPT];
+  int ldst[HS_IPT];
+#pragma unroll
+  for (int it = 0; it < HS_IPT; ++it) {
+    const int item = tid + it * 256;
+    const int px = item >> 2, c4 = item & 3;
+    const int hy = px / HS_HW, hx = px - hy * HS_HW;
+    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+    const bool ok = px < HS_NPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    goff[it] = ok ? (unsigned)(((gy * p.W + gx) * p.in_cs + c4 * 4) * 4) : OOB;
+    ldst[it] = px < HS_NPX ? px * HS_PS + c4 * 4 : -1;
+  }
+  auto load_raw = [&](v4f (&raw)[HS_IPT], int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < HS_IPT; ++it)
+      raw[it] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[it], chunk * 64, 0));
+  };
+  auto produce = [&](const v4f (&raw)[HS_IPT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < HS_IPT; ++it) {
+      u2v h, m, l;
+      kocr_split4(raw[it], h, m, l);
+      if (it + 1 < HS_IPT || ldst[it] >= 0) {
+        unsigned short* dst = As + ldst[it];
+        *reinterpret_cast<u2v*>(dst) = h;
+        *reinterpret_cast<u2v*>(dst + HS_PLANE) = m;
+        *reinterpret_cast<u2v*>(dst + 2 * HS_PLANE) = l;
+      }
+    }
+  };
+
+  f16v acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  // A operand of M-tile m (tile row 2*wave + m), tap (ky, kx): pixel ((2*wave + m + ky) * 34 + l31 + kx), k half l5
+  const int a_lane = ((2 * wave) * HS_HW + l31) * HS_PS + l5 * 8;
+  const unsigned short* w_lane = p.wgt + lane * 8;
+  const int nchunks = p.Cin >> 4;
+
+  v4f raw[HS_IPT];
+  load_raw(raw, 0);
+  produce(raw);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) load_raw(raw, c + 1);
+    const unsigned short* wc = w_lane + (size_t)c * 9 * 3 * 512;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      bf8 b[3], a[2][3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) b[s] = *reinterpret_cast<const bf8*>(wc + (tap * 3 + s) * 512);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          a[m][s] = *reinterpret_cast<const bf8*>(As + s * HS_PLANE + a_lane + ((m + ky) * HS_HW + kx) * HS_PS);
+      // smallest products first (the order of conv_dsplit.hip)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b[0], acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[2], acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b[1], acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b[0], acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[1], acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[0], acc[m], 0, 0, 0);
+    }
+    if (c + 1 < nchunks) {
+      __syncthreads();  // every wave has read this chunk
+      produce(raw);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: 32x32 C/D map: col (cout) = lane & 31, row (tile column) = (r&3) + 8*(r>>2) + 4*(lane>>5) ----------
+  const int nc = l31 < p.Cout ? l31 : p.Cout - 1;
+  const float pa = p.pre_a[nc], pb = p.pre_b[nc];
+  const bool has_post = p.post_a != nullptr;
+  const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
+  float mx = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float o = acc[m][r] * pa + pb;
+      if (p.relu) o = fmaxf(o, 0.f);
+      if (has_post) o = o * qa + qb;
+      acc[m][r] = o;
+      mx = fmaxf(mx, fabsf(o));
+    }
+  float* oimg = p.out + (size_t)n * p.H * p.W * p.out_cs + p.out_co;
+  const unsigned long long ob = (unsigned long long)oimg;
+  const unsigned long long obu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ob >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)ob);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)obu, 0, 0x80000000, 0x00020000);
+  float mxv = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int y = y0 + 2 * wave + m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * l5;
+      const bool ok = y < p.H && x < p.W && l31 < p.Cout;
+      const unsigned vo = ok ? (unsigned)(((y * p.W + x) * p.out_cs + l31) * 4) : OOB;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][r]), ro, vo, 0, 0);
+      if (ok) mxv = fmaxf(mxv, fabsf(acc[m][r]));
+    }
+  }
+  (void)mx;
+  if (p.amax_out) kocr_amax_update(p.amax_out, mxv);
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+int prepare_hsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
+  if (L.KH != 3 || L.KW != 3 || L.dil != 1 || L.Cout > 32 || L.Cin % 16 != 0) return KOCR_OK;
+  const int Cin = L.Cin, Cout = L.Cout;
+  std::vector<unsigned short> u((size_t)(Cin / 16) * 9 * 3 * 512, 0);
+  for (int c = 0; c < Cin; ++c)
+    for (int tap = 0; tap < 9; ++tap)
+      for (int o = 0; o < Cout; ++o) {
+        const float g = w_is_oihw ? w[((size_t)o * Cin + c) * 9 + tap] : w[((size_t)tap * Cin + c) * Cout + o];
+        // MFMA 32x32x16 B operand: lane = (k >> 3) * 32 + o holds k = 8 * (lane >> 5) + j
+        const int k = c % 16, lane = (k >> 3) * 32 + o, j = k & 7;
+        unsigned short pc[3];
+        kocr_split3_host(g, pc);
+        for (int s = 0; s < 3; ++s) u[((((size_t)(c / 16) * 9 + tap) * 3 + s) * 64 + lane) * 8 + j] = pc[s];
+      }
+  void* d = nullptr;
+  KOCR_TRY(ctx->dev_alloc(&d, u.size() * sizeof(unsigned short)));
+  KOCR_HIP(ctx, hipMemcpy(d, u.data(), u.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  L.d_hs = (unsigned short*)d;
+  return KOCR_OK;
+}
+
+bool hsplit_applicable(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in) {
+  static const bool off = getenv("KOCR_HSPLIT") && atoi(getenv("KOCR_HSPLIT")) == 0;
+  return !off && ctx->split_mode == KOCR_SPLIT_BF16X3 && L.d_hs && in.cs % 4 == 0 && in.co % 4 == 0 &&
+         ((uintptr_t)in.p & 15) == 0 && in.pixels() >= 4096 && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31) &&
+         (size_t)in.H * in.W * 32 * 4 < ((size_t)1 << 31);
+}
+
+int launch_conv_hsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out) {
+  if ((size_t)out.H * out.W * out.cs * 4 >= ((size_t)1 << 31)) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": image too large");
+  HsParams p;
+  p.in = in.p;
+  p.wgt = L.d_hs;
+  p.out = out.p;
+  p.pre_a = L.d_pre_a;
+  p.pre_b = L.d_pre_b;
+  p.post_a = L.d_post_a;
+  p.post_b = L.d_post_b;
+  p.H = in.H;
+  p.W = in.W;
+  p.Cin = L.Cin;
+  p.in_cs = in.cs;
+  p.in_co = in.co;
+  p.Cout = L.Cout;
+  p.out_cs = out.cs;
+  p.out_co = out.co;
+  p.relu = L.relu;
+  p.tiles_x = (in.W + HS_TW - 1) / HS_TW;
+  p.tiles_y = (in.H + HS_TH - 1) / HS_TH;
+  p.amax_out = out.amax;
+  const size_t M = in.pixels();
+  static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
+  char nm[64];
+  if (per_layer)
+    snprintf(nm, sizeof nm, "conv_hs_256x32:%s", L.name.c_str());
+  else
+    snprintf(nm, sizeof nm, "conv_hs_256x32");
+  const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
+  const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
+  ProfScope ps(ctx, nm, flops, bytes);
+  const size_t grid = (size_t)in.N * p.tiles_y * p.tiles_x;
+  hipLaunchKernelGGL(conv_hs_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}

@@ -494,6 +494,7 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
   KOCR_TRY(prepare_wsplit(ctx, L, w, w_is_oihw));
   KOCR_TRY(prepare_w43(ctx, L, w, w_is_oihw));
   KOCR_TRY(prepare_dsplit(ctx, L, w, w_is_oihw));
+  KOCR_TRY(prepare_hsplit(ctx, L, w, w_is_oihw));
   if (Cin == 3 && KH == 3 && KW == 3 && dil == 1) {  // uint8 first layer: K order [tap][R,G,B,0], 48 rows
     std::vector<float> w4((size_t)48 * L.Cout_pad, 0.f);
     for (int tap = 0; tap < 9; ++tap)
@@ -641,6 +642,10 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
     return launch_conv_wsplit(ctx, L, in, out, pool, need_full);
   if (!in_u8 && variant == 0 && conv_variant() == 0 && dsplit_applicable(L, in)) {
     KOCR_TRY(launch_conv_dsplit(ctx, L, in, out));
+    return pool ? launch_maxpool2x2(ctx, out, *pool) : KOCR_OK;
+  }
+  if (!in_u8 && variant == 0 && conv_variant() == 0 && hsplit_applicable(ctx, L, in)) {  // few couts: split once into LDS
+    KOCR_TRY(launch_conv_hsplit(ctx, L, in, out));
     return pool ? launch_maxpool2x2(ctx, out, *pool) : KOCR_OK;
   }
   const bool wino = !in_u8 && variant == 0 && conv_variant() == 0 && wino_applicable(L, in);

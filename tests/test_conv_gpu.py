@@ -110,6 +110,11 @@ SPLIT_CASES = [
     # (2, 64, 128, 64, 64) above takes it too
     (1, 17, 36, 32, 48),      # ragged couts, odd height, last tile mostly outside
     (2, 40, 128, 128, 64),    # upconv3.conv.3 class
+    # Cout <= 32 (conv_hsplit.hip: haloed 8x32 tile split once into LDS; needs >= 4096 pixels)
+    (1, 64, 64, 32, 32),      # conv_cls.0 / .2 class, tiles exact
+    (2, 70, 45, 64, 32),      # upconv4.conv.3 class: 4 chunks, ragged tiles in both directions, two images
+    (1, 67, 100, 32, 16),     # conv_cls.4 class: 16 of 32 columns used
+    (1, 130, 33, 16, 7),      # one chunk, a single used column in the second tile column
 ]
 
 

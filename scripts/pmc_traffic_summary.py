@@ -52,7 +52,9 @@ PROF = {
     "conv_w4s_512x64_pool": "void conv_w43n_kernel<1",
     "conv_ws_128x128": "void conv_ws_kernel<0, 1, 4, 0", "conv_ws_128x128_pool": "void conv_ws_kernel<1, 1, 4, 0",
     "conv_ws_256x64": "void conv_ws_kernel<0, 2, 2, 0", "conv_ws_256x64_pool": "void conv_ws_kernel<1, 2, 2, 0",
-    "conv_ds_256x128": "void conv_ds_kernel<1, 4, 0", "conv_ds_512x64": "void conv_ds_kernel<2, 2, 0",
+    "conv_ds_256x128": "void conv_ds_kernel<1, 4, 0, 0", "conv_ds_512x64": "void conv_ds_kernel<2, 2, 0, 0",
+    "conv_ds_256x128_up": "void conv_ds_kernel<1, 4, 0, 1", "conv_ds_512x64_up": "void conv_ds_kernel<2, 2, 0, 1",
+    "conv_hs_256x32": "conv_hs_kernel",
 }
 res["by_prof_name"] = {}
 for pn, prefix in PROF.items():

@@ -40,7 +40,12 @@ int kocr_ctx::amax_begin() {
   return KOCR_OK;
 }
 
-unsigned* kocr_ctx::amax_slot() { return (d_amax && amax_used < AMAX_SLOTS) ? d_amax + amax_used++ : nullptr; }
+// Only the fp16x2 kernels read a tensor's tracked max |x| (their exact power-of-two input scale); in bf16x3 mode no slot is
+// handed out, so the producers' epilogues skip the reduction and the atomic altogether.
+unsigned* kocr_ctx::amax_slot() {
+  if (split_mode != KOCR_SPLIT_F16X2) return nullptr;
+  return (d_amax && amax_used < AMAX_SLOTS) ? d_amax + amax_used++ : nullptr;
+}
 
 int kocr_ctx::dev_alloc(void** out, size_t bytes) {
   void* p = nullptr;

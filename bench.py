@@ -139,6 +139,9 @@ def main():
                     help="arithmetic of the wide convolutions for the headline number (include/kocr.h KOCR_SPLIT_*)")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the extra leg in the other split mode")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] / configs[4]-share / host-array legs")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with two rocprofv3 --pmc passes of a short child run; read the "
+                         "committed profiles/*_pmc_traffic.json instead")
     ap.add_argument("--profile-all", action="store_true",
                     help="keep the HIP-event profiler on for the WHOLE process (headline loop included) and report the "
                          "per-launch averages over every launch: the numbers a rocprofv3 --stats / --pmc run of the "
@@ -335,14 +338,25 @@ def main():
         stage_ms = {kk: round(v["ms"] / args.steps, 3) for kk, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         # HBM traffic of the dominant kernel: PMC passes cannot run inside this process; the number
         # is read from the committed summary of scripts/pmc_bench.sh over this same command
-        traffic, traffic_src = None, "no profiles/*_pmc_traffic.json entry for this kernel"
+        traffic, traffic_src, traffic_live = None, "no profiles/*_pmc_traffic.json entry for this kernel", None
         import glob
-        for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        if world == 1 and not args.no_live_traffic:
+            # live: FETCH_SIZE and WRITE_SIZE passes (one counter per run, kernel-trace only) over a short child run of
+            # this same command; average over every launch of the kernel in that child process
+            try:
+                traffic_live = k.pmc.measure_traffic(os.path.abspath(__file__), name)
+                traffic = traffic_live["hbm_bytes_per_launch"]
+                traffic_src = (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                               f"`bench.py --steps 1 --warmup 1 --profile-all`, average over {traffic_live['launches']} launches")
+            except Exception as e:  # noqa: BLE001 -- fall back to the committed summary, say why
+                traffic_src = f"live PMC passes failed ({type(e).__name__}: {str(e)[:120]}); "
+        for cand in ([] if traffic is not None else sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True)):
             pm = json.load(open(cand))
             row = pm.get("by_prof_name", {}).get(name)
             if row and "hbm_bytes_per_launch" in row:
                 traffic = row["hbm_bytes_per_launch"]
-                traffic_src = "profiles/" + os.path.basename(cand) + f", average over {row['launches']} launches of the bench process"
+                traffic_src = (traffic_src if traffic_src.startswith("live PMC") else "") + "profiles/" + os.path.basename(cand) + \
+                    f", average over {row['launches']} launches of the bench process"
                 break
         res = {
             "metric": "images/sec end-to-end Pipeline.recognize() @768x768",
@@ -381,6 +395,7 @@ def main():
                          "algorithmic_vs_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TF,
                          "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE*2 + WRITE_SIZE, " + traffic_src + ")",
+                         "traffic_live": traffic_live,
                          "algorithmic_bytes_per_launch": r["bytes"] / r["launches"],
                          "avg_launch_ms": r["ms"] / r["launches"], "launches": r["launches"],
                          "all_conv_tflops": conv_fl / (conv_ms * 1e-3) / 1e12},

@@ -5,5 +5,5 @@ it, kept for the layout the build contract names).  Same surface as the referenc
 ``keras_ocr`` for the inference path: ``pipeline.Pipeline``, ``detection.Detector``,
 ``recognition.Recognizer``, ``tools``.
 """
-from . import _lib, weights, tools, detection, recognition, pipeline, dist, evaluation, perfmodel  # noqa: F401
+from . import _lib, weights, tools, detection, recognition, pipeline, dist, evaluation, perfmodel, pmc  # noqa: F401
 from ._lib import Context, KocrError, load_library, default_context  # noqa: F401

@@ -46,16 +46,8 @@ for k in sorted(fetch, key=lambda k: -fetch[k]["FETCH_SIZE"]):
         row["waves_per_simd"] = mfma[k]["SQ_WAVE_CYCLES"] * 4 / (cyc * 1024)
     res["kernels"][k] = row
 # libkocr's profiler row names (what bench.py's roofline object is keyed on) -> rocprof kernel names
-PROF = {
-    "conv_w4s_256x128": "void conv_w43_kernel<0, 0, 0", "conv_w4s_256x128_pool": "void conv_w43_kernel<1",
-    "conv_w4s_256x128_dil": "void conv_w43_kernel<0, 0, 1", "conv_w4s_512x64": "void conv_w43n_kernel<0",
-    "conv_w4s_512x64_pool": "void conv_w43n_kernel<1",
-    "conv_ws_128x128": "void conv_ws_kernel<0, 1, 4, 0", "conv_ws_128x128_pool": "void conv_ws_kernel<1, 1, 4, 0",
-    "conv_ws_256x64": "void conv_ws_kernel<0, 2, 2, 0", "conv_ws_256x64_pool": "void conv_ws_kernel<1, 2, 2, 0",
-    "conv_ds_256x128": "void conv_ds_kernel<1, 4, 0, 0", "conv_ds_512x64": "void conv_ds_kernel<2, 2, 0, 0",
-    "conv_ds_256x128_up": "void conv_ds_kernel<1, 4, 0, 1", "conv_ds_512x64_up": "void conv_ds_kernel<2, 2, 0, 1",
-    "conv_hs_256x32": "conv_hs_kernel",
-}
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "keras_ocr_amd"))
+from pmc import PROF_TO_KERNEL as PROF  # noqa: E402  (stdlib-only module; the package itself is not imported)
 res["by_prof_name"] = {}
 for pn, prefix in PROF.items():
     for k, row in res["kernels"].items():

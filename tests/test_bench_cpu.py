@@ -57,3 +57,26 @@ def test_bench_refuses_more_ranks_than_gpus():
     assert r.returncode != 0
     assert "GPU(s) visible" in (r.stderr + r.stdout)
     assert '"metric"' not in r.stdout
+
+
+def test_pmc_counter_parsing_and_corrections(tmp_path):
+    """keras_ocr_amd.pmc: per-kernel sums over a rocprofv3 counter_collection.csv, the gfx950 FETCH_SIZE correction (KiB,
+    doubled) and the profiler-row -> kernel-name mapping bench.py's live traffic measurement relies on."""
+    import keras_ocr_amd as k
+
+    d = tmp_path / "fetch"
+    d.mkdir()
+    rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"]
+    for i, (name, v) in enumerate([("void conv_w43_kernel<0, 0, 0>(W4Params)", 1000.0), ("void conv_w43_kernel<0, 0, 0>(W4Params)", 3000.0),
+                                   ("void conv_w43_kernel<1, 0, 0>(W4Params)", 7.0), ("maxpool2x2_kernel(EwParams)", 512.0)]):
+        rows.append(f'{i},"{name}",FETCH_SIZE,{v},{100 * i},{100 * i + 40}')
+    (d / "p_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    agg, n = k.pmc.load_counters(str(tmp_path))
+    kern = k.pmc.find_kernel(agg.keys(), "conv_w4s_256x128")
+    assert kern.startswith("void conv_w43_kernel<0, 0, 0") and n[kern] == 2
+    assert agg[kern]["FETCH_SIZE"] == 4000.0 and agg[kern]["_ns_FETCH_SIZE"] == 80
+    assert k.pmc.fetch_bytes(agg[kern]["FETCH_SIZE"]) / n[kern] == 2000 * 1024 * 2
+    assert k.pmc.write_bytes(10.0) == 10240
+    assert k.pmc.find_kernel(agg.keys(), "conv_w4s_256x128_pool").startswith("void conv_w43_kernel<1")
+    assert k.pmc.find_kernel(agg.keys(), "conv_hs_256x32") is None and k.pmc.find_kernel(agg.keys(), "no_such_row") is None
+    assert k.perfmodel.issued_per_algorithmic("conv_hs_256x32")["factor"] == 6.0

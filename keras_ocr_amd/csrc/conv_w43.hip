@@ -834,6 +834,306 @@ __global__ __launch_bounds__(256) void conv_w43n_kernel(W4Params p) {
   }
 }
 
+// ===================================================================================================
+// conv_w43r_kernel -- 32 < Cout <= 64 on images that tile as 2 rows x 128 columns (H even, W % 128 == 0: slice1.3,
+// upconv3.conv.3): the "row reuse" arrangement.  conv_w43n_kernel above transforms and splits every input row once per
+// vertical tap (its K-step is (channel group, ky)) and, with only 64 couts to amortise that over, is issue-bound (9 VALU
+// instructions per MFMA, matrix pipe 34 % busy).  Here a tile is 2 output rows x 128 columns and the K loop runs over
+// channel groups only: the FOUR input rows y0-1 .. y0+2 of a 16-channel group are transformed and split ONCE into LDS
+// (4 rows x 32 quads x 6 points x 3 pieces = 72 KB, double buffered) and the three vertical taps read them back at a
+// row offset -- 4 row transforms per 2 output rows instead of 6, spread over 3 x 36 MFMAs per wave.
+//   M-tile = 2 rows x 64 columns (the geometry of the fused-pool tiles), wave (wm, wn) owns M-tile wm x couts
+//   [32 wn, 32 wn + 32) x 6 points = 96 accumulators; a group = two points x 6 products = 12 MFMAs alternating between
+//   the two points' accumulators; 9 groups per channel group, 12 transform-split-store chunks (2 items x 6 points)
+//   spread 2,1,1 over them; the weights (conv_w43n's layout and order, one (channel group, ky) step ahead in registers)
+//   are re-fetched point by point; one block barrier per channel group.
+// POOL = 1: fused 2x2 max-pool (full-resolution store optional); POOL = 0: full-resolution store only.
+// ===================================================================================================
+template <int POOL>
+__global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
+  constexpr int ROW_STRIDE = 2 * KH_STRIDE;     // ushorts per input row of a plane: 2 k halves x 32 quads x 8 channels
+  constexpr int PLANE_R = 4 * ROW_STRIDE;       // one (xi, piece) plane: 4 input rows
+  constexpr int BUF_R = 6 * 3 * PLANE_R;        // one channel group: 72 KB
+  extern __shared__ __attribute__((aligned(16))) unsigned short As[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, wm = wave >> 1;
+  const int l31 = lane & 31, l5 = lane >> 5;
+  const int total = p.total_tiles;  // pairs of M-tiles; one cout block
+  const int ncg = p.Cin >> 4;
+  const int G = gridDim.x;
+  constexpr unsigned OOB = 0x80000000u;
+
+  // ---- producer state: items it = 0, 1: input row (tid >> 7) + 2 it of the 4-row window, quad qd, channel quad q4 ----
+  const int q4 = tid & 3, qd = (tid >> 2) & 31, rh = tid >> 7;
+  int ldst[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+    ldst[it] = (rh + 2 * it) * ROW_STRIDE + (q4 >> 1) * KH_STRIDE + (((qd * 8) ^ ((q4 >> 1) * 32)) + (q4 & 1) * 4);
+  struct Geo {
+    unsigned off0[2];  // byte offset of raw pixel d0 of each item
+    unsigned ok;       // bit it: the item's input row lies inside the image (and the tile exists)
+    const float* base;
+  };
+  const bool lpad = qd == 0;  // d0 / d5 are column zero padding only at the image edges: W % 128 == 0, tiles_per_row even
+  auto make_geo = [&](int L, Geo& g, bool& left, bool& right) __attribute__((always_inline)) {
+    const int mp = kocr_xcd_remap(L < total ? L : 0, total);
+    int y0, x0;
+    const long pm = w4_mtile_pm0<1>(p, 2 * mp, y0, x0);
+    g.base = p.in + (pm * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
+    g.ok = 0;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = rh + 2 * it;  // input row y0 - 1 + row
+      g.off0[it] = (unsigned)(((row * p.W + 4 * qd) * p.in_cs + q4 * 4) * 4);
+      g.ok |= ((L < total && (unsigned)(y0 - 1 + row) < (unsigned)p.H) ? 1u : 0u) << it;
+    }
+    left = lpad && x0 == 0;
+    right = qd == 31 && x0 + 128 >= p.W;
+  };
+  Geo gc, gn;
+  bool lc, rc, ln, rn;
+  int ld_cg = 0;  // channel group of the NEXT load inside its tile
+  bool ld_next = false;
+  auto load_item = [&](v4f (&raw)[6], int it) __attribute__((always_inline)) {
+    const int soff = ld_cg * 64;
+    const bool ok = ((ld_next ? gn.ok : gc.ok) >> it) & 1u;
+    const unsigned off0 = (ld_next ? gn.off0[it] : gc.off0[it]) | (ok ? 0u : OOB);
+    const bool left = ld_next ? ln : lc, right = ld_next ? rn : rc;
+    const unsigned stride = (unsigned)(p.in_cs * 4);
+    const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const unsigned padk = (k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u);
+      raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (off0 + k * stride) | padk, soff, 0));
+    }
+  };
+  auto advance = [&]() __attribute__((always_inline)) {
+    const bool wrap = ld_cg == ncg - 1;
+    ld_cg = wrap ? 0 : ld_cg + 1;
+    ld_next = ld_next || wrap;
+  };
+  auto produce_point = [&](const v4f (&d)[6], unsigned short* bufp, int xi, int it) __attribute__((always_inline)) {
+    v4f V;
+    switch (xi) {
+      case 0: V = (W4_A2B2 * d[0] - W4_A2PB2 * d[2]) + d[4]; break;
+      case 1: V = (d[4] - W4_B2 * d[2]) + W4_A * (d[3] - W4_B2 * d[1]); break;
+      case 2: V = (d[4] - W4_B2 * d[2]) - W4_A * (d[3] - W4_B2 * d[1]); break;
+      case 3: V = (d[4] - W4_A2 * d[2]) + W4_B * (d[3] - W4_A2 * d[1]); break;
+      case 4: V = (d[4] - W4_A2 * d[2]) - W4_B * (d[3] - W4_A2 * d[1]); break;
+      default: V = (W4_A2B2 * d[1] - W4_A2PB2 * d[3]) + d[5]; break;
+    }
+    u2v h, m, l;
+    kocr_split4(V, h, m, l);
+    unsigned short* dst = bufp + xi * 3 * PLANE_R + ldst[it];
+    *reinterpret_cast<u2v*>(dst) = h;
+    *reinterpret_cast<u2v*>(dst + PLANE_R) = m;
+    *reinterpret_cast<u2v*>(dst + 2 * PLANE_R) = l;
+  };
+
+  // ---- consumer state ------------------------------------------------------------------------------------------
+  const size_t w_step = (size_t)2 * 18 * 64 * 8;  // ushorts per (channel group, ky) step: two 32-cout tiles
+  const unsigned short* w_ptr = p.wgt + ((size_t)wn * 18 * 64 + lane) * 8;
+  const int ns = 3 * ncg;
+  bf8 bw[6][3];
+  f16v acc[6];
+  // M row l31 of M-tile wm: image row (l31 >> 4) [+ ky], quad 16 wm + (l31 & 15), k half l5
+  const int a_lane = (l31 >> 4) * ROW_STRIDE + l5 * KH_STRIDE + (((16 * wm + (l31 & 15)) * 8) ^ (l5 * 32));
+  auto load_a = [&](bf8 (&a)[2][3], const unsigned short* bufp, int ky, int pp) __attribute__((always_inline)) {
+    const unsigned short* base = bufp + a_lane + ky * ROW_STRIDE + 2 * pp * 3 * PLANE_R;
+#pragma unroll
+    for (int s = 2; s >= 0; --s)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) a[e][s] = *reinterpret_cast<const bf8*>(base + (e * 3 + s) * PLANE_R);
+  };
+  auto mfma12 = [&](const bf8 (&a)[2][3], int pp) __attribute__((always_inline)) {
+    // smallest terms first; the two points alternate so consecutive MFMAs are independent
+#pragma unroll
+    for (int e = 0; e < 2; ++e) acc[2 * pp + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[e][2], bw[2 * pp + e][0], acc[2 * pp + e], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) acc[2 * pp + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[e][0], bw[2 * pp + e][2], acc[2 * pp + e], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) acc[2 * pp + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[e][1], bw[2 * pp + e][1], acc[2 * pp + e], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) acc[2 * pp + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[e][1], bw[2 * pp + e][0], acc[2 * pp + e], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) acc[2 * pp + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[e][0], bw[2 * pp + e][1], acc[2 * pp + e], 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) acc[2 * pp + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[e][0], bw[2 * pp + e][0], acc[2 * pp + e], 0, 0, 0);
+  };
+  // One channel group: consume `bufc` in 9 groups (ky, point pair) while transforming the NEXT channel group from
+  // raw0 / raw1 into `bufn` (chunks 2,1,1 per three groups; item 0 is finished after group 3 and its registers are refilled
+  // at once with the channel group after next, item 1 after group 8).  s0 = index of this channel group's first weight
+  // step; the weights of step s0 + ky + 1 replace those of (s0 + ky) point pair by point pair.  a0 (flip = 0) /
+  // a1 (flip = 1) holds group 0 on entry, the other one the next channel group's group 0 on exit.
+  v4f raw0[6], raw1[6];
+  bf8 a0[2][3], a1[2][3];
+  auto phase = [&](const unsigned short* bufc, unsigned short* bufn, int s0, int flip) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int ky = g / 3, pp = g - ky * 3;
+      // nine groups: the roles of a0 / a1 swap from one channel group to the next (flip), back after two
+      bf8(&cur)[2][3] = ((g & 1) ^ flip) ? a1 : a0;
+      bf8(&nxt)[2][3] = ((g & 1) ^ flip) ? a0 : a1;
+      const int nchunks = (g % 3 == 0) ? 2 : 1;
+      const int c0 = (g / 3) * 4 + (g % 3 == 0 ? 0 : g % 3 + 1);  // first chunk of this group: 0,2,3 | 4,6,7 | 8,10,11
+      if (g < 8) load_a(nxt, bufc, (g + 1) / 3, (g + 1) % 3);
+#pragma unroll
+      for (int c = c0; c < c0 + nchunks; ++c) {
+        if (c < 6)
+          produce_point(raw0, bufn, c, 0);
+        else
+          produce_point(raw1, bufn, c - 6, 1);
+      }
+      if (g < 8) {
+        mfma12(cur, pp);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);  // the LDS fetches of the next group first
+        if (g % 3 == 0) {  // two chunks: 1 MFMA : 5 VALU
+#pragma unroll
+          for (int i = 0; i < 11; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x200, 6, 0);
+        } else {  // one chunk: 1 MFMA : 3 VALU
+#pragma unroll
+          for (int i = 0; i < 11; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      } else {
+        __syncthreads();  // the next channel group is complete in bufn, bufc is free
+        load_a(nxt, bufn, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(cur, pp);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {  // this point pair's weights of the next step
+        int sn = s0 + ky + 1;
+        sn = sn >= ns ? sn - ns : sn;
+        const unsigned short* wq = w_ptr + (size_t)sn * w_step;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int s = 0; s < 3; ++s) bw[2 * pp + e][s] = *reinterpret_cast<const bf8*>(wq + (size_t)((2 * pp + e) * 3 + s) * 64 * 8);
+      }
+      if (g == 3) load_item(raw0, 0);
+    }
+    load_item(raw1, 1);
+    advance();
+  };
+
+  // ---- prologue ------------------------------------------------------------------------------------------------
+  make_geo(blockIdx.x, gc, lc, rc);
+  make_geo(blockIdx.x + G, gn, ln, rn);
+  load_item(raw0, 0);
+  load_item(raw1, 1);
+  advance();  // channel group 0 loaded
+#pragma unroll
+  for (int xi = 0; xi < 6; ++xi)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w_ptr + (size_t)(xi * 3 + s) * 64 * 8);
+#pragma unroll
+  for (int xi = 0; xi < 6; ++xi) {
+    produce_point(raw0, As, xi, 0);
+    produce_point(raw1, As, xi, 1);
+  }
+  load_item(raw0, 0);
+  load_item(raw1, 1);
+  advance();  // channel group 1 loaded
+  __syncthreads();
+  load_a(a0, As, 0, 0);
+
+  for (int L = blockIdx.x; L < total; L += G) {
+    const int mp = kocr_xcd_remap(L, total);
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int cg = 0; cg < ncg; cg += 2) {
+      phase(As, As + BUF_R, 3 * cg, 0);
+      phase(As + BUF_R, As, 3 * cg + 3, 1);
+    }
+    gc = gn;
+    lc = ln;
+    rc = rn;
+    make_geo(L + 2 * G, gn, ln, rn);
+    ld_next = false;
+
+    // ---- epilogue (as conv_w43_kernel's fused-pool tiles; this wave's M-tile is 2 mp + wm) -------------------------
+    {
+      const int n = wn * 32 + l31;
+      const int nc = n < p.Cout ? n : p.Cout - 1;
+      const float pa = p.pre_a[nc], pb = p.pre_b[nc];
+      const bool has_post = p.post_a != nullptr;
+      const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
+      const bool live = n < p.Cout;
+      auto act = [&](float v) {
+        v = v * pa + pb;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (has_post) v = v * qa + qb;
+        return v;
+      };
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+        acc[0][r] = act((m0 + s12) + s34);
+        acc[1][r] = act(W4_A * d12 + W4_B * d34);
+        acc[2][r] = act(W4_A2 * s12 + W4_B2 * s34);
+        acc[3][r] = act((W4_A3 * d12 + W4_B3 * d34) + m5);
+      }
+      const int ocs4 = p.out_cs * 4;
+      if (p.amax_out || p.amax_pool) {
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[j][r]));
+        mx = live ? mx : 0.f;
+        if (p.amax_out) kocr_amax_update(p.amax_out, mx);
+        if (p.amax_pool) kocr_amax_update(p.amax_pool, mx);
+      }
+      const int mt = 2 * mp + wm;
+      int y0, x0;
+      const long pm = w4_mtile_pm0<1>(p, mt, y0, x0);
+      if (!POOL || p.write_full) {
+        const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (pm * p.out_cs + p.out_co), 0x7FFFFFFFu);
+        const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int px = 4 * ((r & 3) + 8 * (r >> 2));  // quad column (r&3) + 8 (r>>2) [+ 4 l5] of row y0
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][r]), ro, vo, (px + j) * ocs4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][r + 8]), ro, vo, (px + j + p.W) * ocs4, 0);
+          }
+        }
+      }
+      if constexpr (POOL) {
+        // 2x2 max: rows y0 (r) and y0 + 1 (r + 8), columns (0,1) and (2,3) of the quad
+        const long nimg = pm / ((long)p.H * p.W);
+        const long pp0 = (nimg * (p.H >> 1) + (y0 >> 1)) * (p.W >> 1) + (x0 >> 1);
+        const __amdgpu_buffer_rsrc_t rp = w4_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
+        const unsigned vp = live ? (unsigned)((8 * l5 * p.pool_cs + n) * 4) : OOB;  // 4 quads = 8 pooled px per l5
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int pq = 2 * ((r & 3) + 8 * (r >> 2));
+          const float v0 = fmaxf(fmaxf(acc[0][r], acc[1][r]), fmaxf(acc[0][r + 8], acc[1][r + 8]));
+          const float v1 = fmaxf(fmaxf(acc[2][r], acc[3][r]), fmaxf(acc[2][r + 8], acc[3][r + 8]));
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * p.pool_cs * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * p.pool_cs * 4, 0);
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -925,6 +1225,28 @@ static int w4n_launch(kocr_ctx* ctx, W4Params& p) {
   return KOCR_OK;
 }
 
+template <int POOL>
+static int w4r_launch(kocr_ctx* ctx, W4Params& p) {
+  constexpr int LDSR = 2 * LDS_BYTES;  // 2 x 72 KB
+  static std::atomic<bool> attr_done[64];
+  const int dev = ctx->device & 63;
+  if (!attr_done[dev]) {
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43r_kernel<POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSR));
+    attr_done[dev] = true;
+  }
+  static std::atomic<int> n_cus[64];
+  if (!n_cus[dev]) {
+    hipDeviceProp_t prop;
+    KOCR_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    n_cus[dev] = prop.multiProcessorCount;
+  }
+  const int n_cu = n_cus[dev];
+  const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
+  hipLaunchKernelGGL((conv_w43r_kernel<POOL>), dim3(grid), dim3(256), LDSR, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
 int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool, bool need_full) {
   const bool fuse = pool && L.dil == 1 && in.H % 2 == 0 && in.W % 64 == 0;
   const size_t M = in.pixels();
@@ -963,7 +1285,12 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
     p.tiles_per_row = in.W / 64;
   }
   const bool narrow = L.w4_cout_pad == 64;  // 64-cout arrangement: 4 M-tiles x 64 couts per tile
-  p.n_mpairs = narrow ? (p.total_mtiles + 3) / 4 : (p.total_mtiles + 1) / 2;
+  // ... or, when the image tiles as 2 rows x 128 columns, the row-reuse arrangement (2 M-tiles of 2 rows x 64 columns)
+  static const bool no_rr = getenv("KOCR_W43R") && atoi(getenv("KOCR_W43R")) == 0;
+  const bool rowreuse = narrow && !no_rr && L.dil == 1 && in.H % 2 == 0 && in.W % 128 == 0 && (!pool || fuse) &&
+                        (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31);
+  if (rowreuse && !fuse) p.tiles_per_row = in.W / 64;  // the 2-row x 64-column M-tile geometry without the pooling
+  p.n_mpairs = rowreuse ? p.total_mtiles / 2 : narrow ? (p.total_mtiles + 3) / 4 : (p.total_mtiles + 1) / 2;
   p.total_tiles = p.n_mpairs * (p.Cout_pad / (narrow ? 64 : 128));
   // Tile order.  The split weights of one cout block are Cin * 3 * 128 * 36 B; with every cout block of a deep layer in
   // flight on an XCD they overflow its 4 MB L2 and are re-streamed from the Infinity Cache by every round of tiles.
@@ -973,9 +1300,9 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_w4s_%s%s:%s", narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_w4s_%s%s:%s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_w4s_%s%s", narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
+    snprintf(nm, sizeof nm, "conv_w4s_%s%s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   {
@@ -1003,7 +1330,12 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
       }
     }
 #endif
-    if (narrow) {
+    if (rowreuse) {
+      if (fuse)
+        KOCR_TRY(w4r_launch<1>(ctx, p));
+      else
+        KOCR_TRY(w4r_launch<0>(ctx, p));
+    } else if (narrow) {
       if (fuse)
         KOCR_TRY(w4n_launch<1>(ctx, p));
       else

@@ -110,6 +110,10 @@ SPLIT_CASES = [
     # (2, 64, 128, 64, 64) above takes it too
     (1, 17, 36, 32, 48),      # ragged couts, odd height, last tile mostly outside
     (2, 40, 128, 128, 64),    # upconv3.conv.3 class
+    # 32 < Cout <= 64 on images that tile as 2 rows x 128 columns: the row-reuse arrangement (conv_w43r_kernel)
+    (1, 6, 128, 32, 48),      # two channel groups, one tile per row pair, ragged couts
+    (2, 8, 256, 64, 64),      # slice1.3 class: four channel groups, two tiles per row pair, two images
+    (1, 4, 384, 96, 40),      # six channel groups, three tiles per row pair
     # Cout <= 32 (conv_hsplit.hip: haloed 8x32 tile split once into LDS; needs >= 4096 pixels)
     (1, 64, 64, 32, 32),      # conv_cls.0 / .2 class, tiles exact
     (2, 70, 45, 64, 32),      # upconv4.conv.3 class: 4 chunks, ragged tiles in both directions, two images

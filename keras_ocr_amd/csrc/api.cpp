@@ -79,6 +79,9 @@ hipEvent_t kocr_ctx::get_event() {
 }
 
 void kocr_ctx::prof_begin(const char* name, double flops, double bytes) {
+  // bounded: a caller that leaves profiling on without ever asking for the report pays one synchronisation per 4096
+  // launches instead of an event pool that grows without limit
+  if (pending.size() >= 4096) prof_flush();
   Pending pd;
   pd.name = name;
   pd.a = get_event();

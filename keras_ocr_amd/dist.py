@@ -68,6 +68,13 @@ def ranks_seen(group=None):
     return int(one.item())
 
 
+def packed_payload_bytes(per_rank_images, cap):
+    """Bytes ONE rank contributes to the three all-gathers of `gather_packed` (counts, boxes, label rows)."""
+    cap = max(int(cap), 1)
+    return {"counts": 4 * (per_rank_images + 1), "boxes": cap * 8 * 4, "labels": cap * LABEL_WIDTH * 4,
+            "total": 4 * (per_rank_images + 1) + cap * 8 * 4 + cap * LABEL_WIDTH * 4}
+
+
 def gather_packed(box_groups, labels, per_rank_images, group=None):
     """all-gather of the per-image box counts, then of fixed-capacity packed results.
 

@@ -167,3 +167,12 @@ def test_sharded_real_pipeline_classes_over_mocked_abi_gloo_world2():
     alphabet = "0123456789abcdefghijklmnopqrstuvwxyz"
     hmax = 2 * (10 + n_images - 1)
     assert single[1][0][0] == alphabet[11] + alphabet[hmax % 36] + alphabet[0]
+
+
+def test_packed_payload_bytes():
+    """Payload of the three result all-gathers: counts + cap x 8 f32 + cap x 48 i32 per rank."""
+    from keras_ocr_amd import dist as kd
+
+    p = kd.packed_payload_bytes(32, 1128)
+    assert p == {"counts": 132, "boxes": 1128 * 32, "labels": 1128 * 192, "total": 132 + 1128 * 224}
+    assert kd.packed_payload_bytes(4, 0)["total"] == 20 + 224

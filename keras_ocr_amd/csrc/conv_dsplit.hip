@@ -279,6 +279,11 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
         unsigned* tab = reinterpret_cast<unsigned*>(As + 2 * BUF) + wave * (256 * 8);
         const long wbase = pm0 + (long)wm * 256;
         const unsigned ucs4 = (unsigned)p.Cout * 4u;
+        // byte offsets are relative to the image of the wave's first pixel (its 256 pixels reach into the next image at
+        // most): the 32-bit offsets then only have to span two images, whatever the batch size
+        const int hw = p.H * p.W;
+        const long wb = wbase < (long)p.Mtotal - 1 ? wbase : (long)p.Mtotal - 1;
+        const int n0 = __builtin_amdgcn_readfirstlane((int)(wb / hw));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int q = lane + 64 * i;
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
           const float fly = floorf(fy), flx = floorf(fx);
           const int y0 = max((int)fly, 0), y1 = min((int)ceilf(fy), p.up_H - 1);
           const int x0 = max((int)flx, 0), x1 = min((int)ceilf(fx), p.up_W - 1);
-          const unsigned r0 = (unsigned)((ni * p.up_H + y0) * p.up_W), r1 = (unsigned)((ni * p.up_H + y1) * p.up_W);
+          const unsigned r0 = (unsigned)(((ni - n0) * p.up_H + y0) * p.up_W), r1 = (unsigned)(((ni - n0) * p.up_H + y1) * p.up_W);
           uint4 o4;
           o4.x = (r0 + x0) * ucs4;
           o4.y = (r0 + x1) * ucs4;
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const unsigned long long ub = (unsigned long long)p.up;
+        const unsigned long long ub = (unsigned long long)(p.up + (size_t)n0 * p.up_H * p.up_W * p.Cout);
         const unsigned long long ubu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ub >> 32)) << 32) |
                                        (unsigned)__builtin_amdgcn_readfirstlane((int)ub);
         const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)ubu, 0, 0x7FFFFFFF, 0x00020000);
@@ -516,7 +521,7 @@ int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   p.up_sy = p.up_sx = 0.f;
   if (up) {
     if (half || up->C != L.Cout || up->cs != L.Cout || up->co != 0 || up->N != in.N || L.KH != 1 || L.KW != 1 ||
-        up->pixels() * (size_t)L.Cout * 4 >= ((size_t)1 << 31))
+        2 * (size_t)up->H * up->W * L.Cout * 4 >= ((size_t)1 << 31))
       KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": unsupported up-sampled addend");
     p.up = up->p;
     p.up_H = up->H;

@@ -409,7 +409,7 @@ int craft_run(kocr_ctx* ctx, CraftNet* net, const void* d_img, int dtype, int N,
   if constexpr (!DRY) {
     const char* off = getenv("KOCR_LINFOLD");
     lin_fold = !(off && atoi(off) == 0) && ctx->split_mode == KOCR_SPLIT_BF16X3 && dsplit_usable(L("upconv1.conv.0#skip"), s4) &&
-               h0.pixels() * (size_t)512 * 4 < ((size_t)1 << 31);
+               2 * (size_t)h0.H * h0.W * 512 * 4 < ((size_t)1 << 31);
     if (lin_fold) {  // see craft_load: slice5.1 -> slice5.2 -> upconv1.conv.0 as one dilated 3x3 plus a 1x1 over s4
       Tensor t = h1;  // the first half of h1's buffer, as a contiguous 512-channel tensor
       t.C = t.cs = 512;
@@ -441,7 +441,7 @@ int craft_run(kocr_ctx* ctx, CraftNet* net, const void* d_img, int dtype, int N,
       const Tensor skip = cat.slice(c_y, cat.C - c_y);
       const char* off = getenv("KOCR_UPFOLD");
       const bool fold = !(off && atoi(off) == 0) && ctx->split_mode == KOCR_SPLIT_BF16X3 && dsplit_usable(Ls, skip) &&
-                        t.pixels() * (size_t)t.C * 4 < ((size_t)1 << 31);
+                        2 * (size_t)t.H * t.W * t.C * 4 < ((size_t)1 << 31);  // two images of t within 32-bit offsets
       if (fold) {
         KOCR_TRY(launch_conv(ctx, L((std::string(name) + "#y").c_str()), y, nullptr, nullptr, t));
         KOCR_TRY(launch_conv_dsplit(ctx, Ls, skip, out, &t));

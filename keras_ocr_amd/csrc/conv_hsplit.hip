@@ -148,7 +148,6 @@ __global__ __launch_bounds__(256, 3) void conv_hs_kernel(HsParams p) {
   const float pa = p.pre_a[nc], pb = p.pre_b[nc];
   const bool has_post = p.post_a != nullptr;
   const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
-  float mx = 0.f;
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -157,7 +156,6 @@ __global__ __launch_bounds__(256, 3) void conv_hs_kernel(HsParams p) {
       if (p.relu) o = fmaxf(o, 0.f);
       if (has_post) o = o * qa + qb;
       acc[m][r] = o;
-      mx = fmaxf(mx, fabsf(o));
     }
   float* oimg = p.out + (size_t)n * p.H * p.W * p.out_cs + p.out_co;
   const unsigned long long ob = (unsigned long long)oimg;
@@ -177,7 +175,6 @@ __global__ __launch_bounds__(256, 3) void conv_hs_kernel(HsParams p) {
       if (ok) mxv = fmaxf(mxv, fabsf(acc[m][r]));
     }
   }
-  (void)mx;
   if (p.amax_out) kocr_amax_update(p.amax_out, mxv);
 }
 

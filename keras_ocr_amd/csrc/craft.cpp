@@ -8,6 +8,11 @@
 // producer straight into the channel slice of the concat buffer that consumes them, so no
 // concat kernel exists:  cat1 = [s5 | s4], cat2 = [up(y1) | s3], cat3 = [up(y2) | s2],
 // cat4 = [up(y3) | s1]  (detection.py:380-389).
+// In bf16x3 mode two chains of convolutions WITHOUT a non-linearity between them are evaluated in their algebraically
+// identical shorter form (same sums, fp32 round-off apart): slice5.1 -> slice5.2 -> upconv1.conv.0 as one composed
+// dilated 3x3 plus a 1x1 over s4 (craft_load / craft_run, KOCR_LINFOLD), and conv1x1(concat(resize(y), skip)) as
+// resize(conv1x1_y(y)) + conv1x1_skip(skip) (up_conv, KOCR_UPFOLD); the up-sampled halves of cat2..4 and s5 are then
+// never written.
 #include "common.h"
 #include <algorithm>
 #include <cmath>

@@ -14,7 +14,7 @@
 //   pixels are conflict-free);  wave w owns rows 2w, 2w+1 = two 32-pixel M-tiles x 32 couts (32 accumulators);  per
 //   (chunk, tap): 6 ds_read_b128 + 3 weight loads (16 B per lane, L1/L2 resident: 27 KB per chunk) + 12 MFMA 32x32x16.
 //   The next chunk's raw pixels are in flight while the current one is multiplied;  one buffer, two barriers per chunk --
-//   48 KB of LDS and ~100 registers let three blocks share a CU, which is what hides the barriers.
+//   48 KB of LDS and 164 registers let three blocks share a CU, which is what hides the barriers.
 #include "split_common.h"
 #include <algorithm>
 #include <atomic>

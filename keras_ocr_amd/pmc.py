@@ -70,7 +70,7 @@ def under_profiler():
     return "rocprof" in blob
 
 
-def measure_traffic(bench_path, prof_name, timeout=240):
+def measure_traffic(bench_path, prof_name, timeout=150):
     """Run the bench command twice under `rocprofv3 --kernel-trace --pmc <one counter>` (short: 1 warm-up + 1 step, no extra
     legs) and return the per-launch traffic of `prof_name`'s kernel, averaged over every launch of that child process,
     next to the algorithmic bytes of the same launches (the child's `roofline.process`).  Raises on any failure."""
@@ -81,8 +81,12 @@ def measure_traffic(bench_path, prof_name, timeout=240):
         raise RuntimeError("already running under a rocprofiler tool")
     out = tempfile.mkdtemp(prefix="kocr_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK"):
-        env.pop(v, None)
+    # the child is a stand-alone single-rank run: drop everything a torchrun parent exported (with
+    # TORCHELASTIC_USE_AGENT_STORE set the child would wait for the parent agent's store on its own fresh port)
+    for v in list(env):
+        if v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                 "ROLE_NAME", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE", "TORCH_NCCL_ASYNC_ERROR_HANDLING") or v.startswith("TORCHELASTIC_"):
+            env.pop(v, None)
     child = [sys.executable, os.path.abspath(bench_path), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-alt-mode",
              "--no-extra", "--profile-all", "--no-live-traffic"]
     sums, launches, line = {}, {}, None

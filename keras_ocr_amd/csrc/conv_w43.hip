@@ -35,6 +35,7 @@
 // max-pool (POOL = 1) additionally needs even H and W % 64 == 0 (M-tile = 2 rows x 64 columns, the two rows of a
 // pooling window are accumulator registers r and r + 8 of one lane).  Everything else stays on conv_wsplit.hip.
 #include "split_common.h"
+#include <type_traits>
 #include <cmath>
 #include <algorithm>
 #include <vector>
@@ -842,11 +843,15 @@ __global__ __launch_bounds__(256) void conv_w43n_kernel(W4Params p) {
 // channel groups only: the FOUR input rows y0-1 .. y0+2 of a 16-channel group are transformed and split ONCE into LDS
 // (4 rows x 32 quads x 6 points x 3 pieces = 72 KB, double buffered) and the three vertical taps read them back at a
 // row offset -- 4 row transforms per 2 output rows instead of 6, spread over 3 x 36 MFMAs per wave.
-//   M-tile = 2 rows x 64 columns (the geometry of the fused-pool tiles), wave (wm, wn) owns M-tile wm x couts
-//   [32 wn, 32 wn + 32) x 6 points = 96 accumulators; a group = two points x 6 products = 12 MFMAs alternating between
-//   the two points' accumulators; 9 groups per channel group, 12 transform-split-store chunks (2 items x 6 points)
-//   spread 2,1,1 over them; the weights (conv_w43n's layout and order, one (channel group, ky) step ahead in registers)
-//   are re-fetched point by point; one block barrier per channel group.
+//   M-tile = 2 rows x 64 columns (the geometry of the fused-pool tiles).  Wave (ph, wn) owns BOTH M-tiles x couts
+//   [32 wn, 32 wn + 32) x the three points 3 ph .. 3 ph + 2 = 96 accumulators, so that a weight fragment serves two
+//   M-tiles (with one M-tile per wave the weight stream was 10 TB/s from L2 and the chip clocked 1.5 GHz); a group = one
+//   (ky, point) = 12 MFMAs alternating between the two M-tiles; 9 groups per channel group, 12 transform-split-store
+//   chunks (2 items x 6 points) spread 2,1,1 over them; the weights (conv_w43n's layout and order, one (channel group,
+//   ky) step ahead in registers) are re-fetched point by point; one block barrier per channel group.  The output
+//   transform is linear in the six points: in the epilogue every wave forms the partial outputs of both M-tiles from its
+//   three points, hands the partner wave (ph ^ 1) the partials of M-tile 1 - ph through the LDS buffer the K loop has
+//   just released (two block barriers per tile) and finishes M-tile ph itself.
 // POOL = 1: fused 2x2 max-pool (full-resolution store optional); POOL = 0: full-resolution store only.
 // ===================================================================================================
 template <int POOL>
@@ -857,7 +862,7 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short As[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave & 1, wm = wave >> 1;
+  const int wn = wave & 1, ph = wave >> 1;  // cout half, point half (points 3 ph .. 3 ph + 2)
   const int l31 = lane & 31, l5 = lane >> 5;
   const int total = p.total_tiles;  // pairs of M-tiles; one cout block
   const int ncg = p.Cin >> 4;
@@ -935,31 +940,33 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
   const size_t w_step = (size_t)2 * 18 * 64 * 8;  // ushorts per (channel group, ky) step: two 32-cout tiles
   const unsigned short* w_ptr = p.wgt + ((size_t)wn * 18 * 64 + lane) * 8;
   const int ns = 3 * ncg;
-  bf8 bw[6][3];
-  f16v acc[6];
-  // M row l31 of M-tile wm: image row (l31 >> 4) [+ ky], quad 16 wm + (l31 & 15), k half l5
-  const int a_lane = (l31 >> 4) * ROW_STRIDE + l5 * KH_STRIDE + (((16 * wm + (l31 & 15)) * 8) ^ (l5 * 32));
-  auto load_a = [&](bf8 (&a)[2][3], const unsigned short* bufp, int ky, int pp) __attribute__((always_inline)) {
-    const unsigned short* base = bufp + a_lane + ky * ROW_STRIDE + 2 * pp * 3 * PLANE_R;
+  bf8 bw[3][3];
+  f16v acc[3][2];  // [point of this wave's half][M-tile]
+  // M row l31 of M-tile m: image row (l31 >> 4) [+ ky], quad 16 m + (l31 & 15) (= + 128 ushorts: bit 7, clear of the
+  // swizzle's bit 5), k half l5
+  const int a_lane = (l31 >> 4) * ROW_STRIDE + l5 * KH_STRIDE + (((l31 & 15) * 8) ^ (l5 * 32));
+  auto load_a = [&](bf8 (&a)[2][3], const unsigned short* bufp, int ky, int pl) __attribute__((always_inline)) {
+    const unsigned short* base = bufp + a_lane + ky * ROW_STRIDE + (3 * ph + pl) * 3 * PLANE_R;
 #pragma unroll
     for (int s = 2; s >= 0; --s)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) a[e][s] = *reinterpret_cast<const bf8*>(base + (e * 3 + s) * PLANE_R);
+      for (int m = 0; m < 2; ++m) a[m][s] = *reinterpret_cast<const bf8*>(base + s * PLANE_R + m * 128);
   };
-  auto mfma12 = [&](const bf8 (&a)[2][3], int pp) __attribute__((always_inline)) {
-    // smallest terms first; the two points alternate so consecutive MFMAs are independent
+  auto mfma12 = [&](const bf8 (&a)[2][3], int pl) __attribute__((always_inline)) {
+    const bf8 b0 = bw[pl][0], b1 = bw[pl][1], b2 = bw[pl][2];
+    // smallest terms first; the two M-tiles alternate so consecutive MFMAs are independent
 #pragma unroll
-    for (int e = 0; e < 2; ++e) acc[2 * pp + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[e][2], bw[2 * pp + e][0], acc[2 * pp + e], 0, 0, 0);
+    for (int m = 0; m < 2; ++m) acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b0, acc[pl][m], 0, 0, 0);
 #pragma unroll
-    for (int e = 0; e < 2; ++e) acc[2 * pp + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[e][0], bw[2 * pp + e][2], acc[2 * pp + e], 0, 0, 0);
+    for (int m = 0; m < 2; ++m) acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b2, acc[pl][m], 0, 0, 0);
 #pragma unroll
-    for (int e = 0; e < 2; ++e) acc[2 * pp + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[e][1], bw[2 * pp + e][1], acc[2 * pp + e], 0, 0, 0);
+    for (int m = 0; m < 2; ++m) acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b1, acc[pl][m], 0, 0, 0);
 #pragma unroll
-    for (int e = 0; e < 2; ++e) acc[2 * pp + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[e][1], bw[2 * pp + e][0], acc[2 * pp + e], 0, 0, 0);
+    for (int m = 0; m < 2; ++m) acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b0, acc[pl][m], 0, 0, 0);
 #pragma unroll
-    for (int e = 0; e < 2; ++e) acc[2 * pp + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[e][0], bw[2 * pp + e][1], acc[2 * pp + e], 0, 0, 0);
+    for (int m = 0; m < 2; ++m) acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b1, acc[pl][m], 0, 0, 0);
 #pragma unroll
-    for (int e = 0; e < 2; ++e) acc[2 * pp + e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[e][0], bw[2 * pp + e][0], acc[2 * pp + e], 0, 0, 0);
+    for (int m = 0; m < 2; ++m) acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b0, acc[pl][m], 0, 0, 0);
   };
   // One channel group: consume `bufc` in 9 groups (ky, point pair) while transforming the NEXT channel group from
   // raw0 / raw1 into `bufn` (chunks 2,1,1 per three groups; item 0 is finished after group 3 and its registers are refilled
@@ -1017,9 +1024,7 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
         sn = sn >= ns ? sn - ns : sn;
         const unsigned short* wq = w_ptr + (size_t)sn * w_step;
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-          for (int s = 0; s < 3; ++s) bw[2 * pp + e][s] = *reinterpret_cast<const bf8*>(wq + (size_t)((2 * pp + e) * 3 + s) * 64 * 8);
+        for (int s = 0; s < 3; ++s) bw[pp][s] = *reinterpret_cast<const bf8*>(wq + (size_t)((3 * ph + pp) * 3 + s) * 64 * 8);
       }
       if (g == 3) load_item(raw0, 0);
     }
@@ -1034,9 +1039,9 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
   load_item(raw1, 1);
   advance();  // channel group 0 loaded
 #pragma unroll
-  for (int xi = 0; xi < 6; ++xi)
+  for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-    for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w_ptr + (size_t)(xi * 3 + s) * 64 * 8);
+    for (int s = 0; s < 3; ++s) bw[pl][s] = *reinterpret_cast<const bf8*>(w_ptr + (size_t)((3 * ph + pl) * 3 + s) * 64 * 8);
 #pragma unroll
   for (int xi = 0; xi < 6; ++xi) {
     produce_point(raw0, As, xi, 0);
@@ -1051,9 +1056,11 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
   for (int L = blockIdx.x; L < total; L += G) {
     const int mp = kocr_xcd_remap(L, total);
 #pragma unroll
-    for (int x = 0; x < 6; ++x)
+    for (int x = 0; x < 3; ++x)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][m][r] = 0.f;
     __builtin_amdgcn_s_waitcnt(0x0F70);
     for (int cg = 0; cg < ncg; cg += 2) {
       phase(As, As + BUF_R, 3 * cg, 0);
@@ -1065,7 +1072,7 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
     make_geo(L + 2 * G, gn, ln, rn);
     ld_next = false;
 
-    // ---- epilogue (as conv_w43_kernel's fused-pool tiles; this wave's M-tile is 2 mp + wm) -------------------------
+    // ---- epilogue (stores as conv_w43_kernel's fused-pool tiles; this wave finishes M-tile 2 mp + ph) ------------------
     {
       const int n = wn * 32 + l31;
       const int nc = n < p.Cout ? n : p.Cout - 1;
@@ -1079,27 +1086,60 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
         if (has_post) v = v * qa + qb;
         return v;
       };
+      // The output transform is linear in the six points: every wave forms the partial outputs of BOTH M-tiles from its
+      // three points, hands the partials of the partner's M-tile (1 - ph) over through the LDS buffer the K loop has just
+      // released (16 KB per wave: [wave][r][lane] float4, the partner = wave ^ 2 has the same lane <-> (quad, cout) map)
+      // and finishes M-tile ph itself.  Point half 0 holds (m0, m1, m2), half 1 (m3, m4, m5).
+      v4f* xch = reinterpret_cast<v4f*>(As + BUF_R);  // the K loop's second buffer: free since the last block barrier
+      float out[4][16];
+      // PH (= ph, wave-uniform) and the M-tile index are compile-time constants inside: no dynamic register indexing
+      auto halves = [&](auto ph_c) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph_c)::value;
+        auto partial = [&](auto m_c, int r, float (&o)[4]) __attribute__((always_inline)) {
+          constexpr int M = decltype(m_c)::value;
+          const float u = acc[0][M][r], v = acc[1][M][r], w = acc[2][M][r];
+          if constexpr (PH == 0) {
+            const float s12 = v + w, d12 = v - w;
+            o[0] = u + s12;
+            o[1] = W4_A * d12;
+            o[2] = W4_A2 * s12;
+            o[3] = W4_A3 * d12;
+          } else {
+            const float s34 = u + v, d34 = u - v;
+            o[0] = s34;
+            o[1] = W4_B * d34;
+            o[2] = W4_B2 * s34;
+            o[3] = W4_B3 * d34 + w;
+          }
+        };
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float o[4];
+          partial(std::integral_constant<int, 1 - PH>{}, r, o);
+          xch[(wave * 16 + r) * 64 + lane] = v4f{o[0], o[1], o[2], o[3]};
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float o[4];
+          partial(std::integral_constant<int, PH>{}, r, o);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) out[j][r] = o[j];
+        }
+      };
+      if (ph == 0)
+        halves(std::integral_constant<int, 0>{});
+      else
+        halves(std::integral_constant<int, 1>{});
+      __syncthreads();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
-        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-        acc[0][r] = act((m0 + s12) + s34);
-        acc[1][r] = act(W4_A * d12 + W4_B * d34);
-        acc[2][r] = act(W4_A2 * s12 + W4_B2 * s34);
-        acc[3][r] = act((W4_A3 * d12 + W4_B3 * d34) + m5);
+        const v4f q = xch[((wave ^ 2) * 16 + r) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j][r] = act(out[j][r] + q[j]);
       }
+      __syncthreads();  // the next channel group is transformed into this buffer
       const int ocs4 = p.out_cs * 4;
-      if (p.amax_out || p.amax_pool) {
-        float mx = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[j][r]));
-        mx = live ? mx : 0.f;
-        if (p.amax_out) kocr_amax_update(p.amax_out, mx);
-        if (p.amax_pool) kocr_amax_update(p.amax_pool, mx);
-      }
-      const int mt = 2 * mp + wm;
+      const int mt = 2 * mp + ph;
       int y0, x0;
       const long pm = w4_mtile_pm0<1>(p, mt, y0, x0);
       if (!POOL || p.write_full) {
@@ -1110,8 +1150,8 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
           const int px = 4 * ((r & 3) + 8 * (r >> 2));  // quad column (r&3) + 8 (r>>2) [+ 4 l5] of row y0
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][r]), ro, vo, (px + j) * ocs4, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][r + 8]), ro, vo, (px + j + p.W) * ocs4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out[j][r]), ro, vo, (px + j) * ocs4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out[j][r + 8]), ro, vo, (px + j + p.W) * ocs4, 0);
           }
         }
       }
@@ -1124,8 +1164,8 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const int pq = 2 * ((r & 3) + 8 * (r >> 2));
-          const float v0 = fmaxf(fmaxf(acc[0][r], acc[1][r]), fmaxf(acc[0][r + 8], acc[1][r + 8]));
-          const float v1 = fmaxf(fmaxf(acc[2][r], acc[3][r]), fmaxf(acc[2][r + 8], acc[3][r + 8]));
+          const float v0 = fmaxf(fmaxf(out[0][r], out[1][r]), fmaxf(out[0][r + 8], out[1][r + 8]));
+          const float v1 = fmaxf(fmaxf(out[2][r], out[3][r]), fmaxf(out[2][r + 8], out[3][r + 8]));
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * p.pool_cs * 4, 0);
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * p.pool_cs * 4, 0);
         }

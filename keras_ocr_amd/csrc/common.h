@@ -84,6 +84,7 @@ struct ConvLayer {
   int ds_cout_pad = 0;
   unsigned short* d_ds16 = nullptr;  // 2-way fp16 split of w * 2^ds_wexp
   int ds_wexp = 0;
+  unsigned short* d_first = nullptr;  // 3 -> <= 64 first layer on raw uint8, im2col K = 27 -> 32, conv_hsplit.hip order
   unsigned short* d_hs = nullptr;  // 3x3, <= 32 couts: 3-way bf16 split, conv_hsplit.hip order
   bool tap_inner = false;  // K order [16-channel group][tap][16] (Cin % 16 == 0) instead of [tap][Cin]
   bool ready() const { return d_w != nullptr; }
@@ -222,6 +223,9 @@ bool dsplit_usable(const ConvLayer& L, const Tensor& in);
 int prepare_hsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
 bool hsplit_applicable(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in);
 int launch_conv_hsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out);
+int prepare_first(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
+bool first_applicable(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in);
+int launch_conv_first(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8, const float* lut, const Tensor& out);
 int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* up = nullptr);
 // elementwise.hip
 // row_off: input row that starts output row 0 (0 = keras 'valid' pooling; 1 = the same pooling seen

@@ -178,6 +178,150 @@ __global__ __launch_bounds__(256, 3) void conv_hs_kernel(HsParams p) {
   if (p.amax_out) kocr_amax_update(p.amax_out, mxv);
 }
 
+// ===================================================================================================
+// conv_first_kernel -- CRAFT's first layer (basenet.slice1.0, detection.py:312-322: 3x3, 3 -> 64, BN, ReLU) straight from
+// the uint8 image, on the same bf16x3 split arithmetic.  K = 27 (tap, channel) values per output pixel, padded to 32 =
+// two 16-k MFMA steps: the fp32-MFMA kernel that ran it before spent 48 padded K per pixel on the slow pipe (43 % busy,
+// 2.6 TB/s of output against the 6.8 TB/s a plain fill reaches).  Block = 256 threads, tile = 8 rows x 32 columns; thread
+// t gathers the 27 neighbours of ITS pixel (byte loads, out-of-image = the zero padding of the NORMALISED image),
+// normalises them through the compute_input table (detection.py:34-42, bit-exact float32 values, copied to LDS), splits
+// them and stores its im2col row [32 k] x 3 pieces (80-byte pixel stride: conflict-free 16-byte A reads); wave w owns
+// tile rows 2w, 2w+1 = two M-tiles x 64 couts: 2 k-steps x 2 cout tiles x 12 = 48 MFMAs.  60 KB of LDS: two blocks / CU.
+// ===================================================================================================
+struct FirstParams {
+  const uint8_t* img;         // [N][H][W][3]
+  const float* lut;           // [3][256]
+  const unsigned short* wgt;  // [2 k-steps][2 cout tiles][3 pieces][64 lanes][8]
+  float* out;
+  const float* pre_a;
+  const float* pre_b;
+  const float* post_a;
+  const float* post_b;
+  int H, W, Cout, out_cs, out_co, relu;
+  int tiles_x, tiles_y;
+};
+
+namespace {
+constexpr int F1_PS = 40;                    // ushorts per pixel of a plane: 32 k + 8 padding (80 bytes)
+constexpr int F1_PLANE = 256 * F1_PS;        // 10240 ushorts
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void conv_first_kernel(FirstParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[3 * F1_PLANE];
+  __shared__ float lut_s[768];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, l5 = lane >> 5;
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x;
+  t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int n = t / p.tiles_y;
+  const int y0 = ty * HS_TH, x0 = tx * HS_TW;
+  constexpr unsigned OOB = 0x80000000u;
+  for (int i = tid; i < 768; i += 256) lut_s[i] = p.lut[i];
+
+  // ---- gather: the 27 raw bytes of this thread's pixel (clamped address, validity kept apart) ----------------------
+  const uint8_t* img = p.img + (size_t)n * p.H * p.W * 3;
+  const int py = y0 + (tid >> 5), px = x0 + (tid & 31);
+  unsigned char raw[27];
+  unsigned valid = 0;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+    const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const int off = ok ? (iy * p.W + ix) * 3 : 0;
+    valid |= (ok ? 1u : 0u) << tap;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) raw[tap * 3 + c] = img[off + c];
+  }
+  __syncthreads();  // table in LDS
+  float v[32];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) v[k] = ((valid >> (k / 3)) & 1u) ? lut_s[(k % 3) * 256 + raw[k]] : 0.f;
+#pragma unroll
+  for (int k = 27; k < 32; ++k) v[k] = 0.f;
+  {
+    unsigned short* dst = As + tid * F1_PS;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      u2v h, m, l;
+      kocr_split4(v4f{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}, h, m, l);
+      *reinterpret_cast<u2v*>(dst + q * 4) = h;
+      *reinterpret_cast<u2v*>(dst + F1_PLANE + q * 4) = m;
+      *reinterpret_cast<u2v*>(dst + 2 * F1_PLANE + q * 4) = l;
+    }
+  }
+  __syncthreads();
+
+  // ---- 2 M-tiles (tile rows 2 wave, 2 wave + 1) x 2 cout tiles x 2 k-steps ------------------------------------------
+  f16v acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][nt][r] = 0.f;
+  const unsigned short* w_lane = p.wgt + lane * 8;
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc) {
+    bf8 a[2][3], b[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        a[m][s] = *reinterpret_cast<const bf8*>(As + s * F1_PLANE + ((2 * wave + m) * 32 + l31) * F1_PS + kc * 16 + l5 * 8);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) b[nt][s] = *reinterpret_cast<const bf8*>(w_lane + ((kc * 2 + nt) * 3 + s) * 512);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b[nt][0], acc[m][nt], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[nt][2], acc[m][nt], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b[nt][1], acc[m][nt], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b[nt][0], acc[m][nt], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[nt][1], acc[m][nt], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[nt][0], acc[m][nt], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: col (cout) = 32 nt + (lane & 31), row (tile column) = (r&3) + 8*(r>>2) + 4*(lane>>5) ------------------
+  float* oimg = p.out + (size_t)n * p.H * p.W * p.out_cs + p.out_co;
+  const unsigned long long ob = (unsigned long long)oimg;
+  const unsigned long long obu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ob >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)ob);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)obu, 0, 0x80000000, 0x00020000);
+  const bool has_post = p.post_a != nullptr;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int co = nt * 32 + l31;
+    const int nc = co < p.Cout ? co : p.Cout - 1;
+    const float pa = p.pre_a[nc], pb = p.pre_b[nc];
+    const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int y = y0 + 2 * wave + m;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * l5;
+        float o = acc[m][nt][r] * pa + pb;
+        if (p.relu) o = fmaxf(o, 0.f);
+        if (has_post) o = o * qa + qb;
+        const bool ok = y < p.H && x < p.W && co < p.Cout;
+        const unsigned vo = ok ? (unsigned)(((y * p.W + x) * p.out_cs + co) * 4) : OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro, vo, 0, 0);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -243,6 +387,63 @@ int launch_conv_hsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   ProfScope ps(ctx, nm, flops, bytes);
   const size_t grid = (size_t)in.N * p.tiles_y * p.tiles_x;
   hipLaunchKernelGGL(conv_hs_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
+// ---- first layer on raw uint8 --------------------------------------------------------------------------------------
+int prepare_first(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
+  if (L.KH != 3 || L.KW != 3 || L.dil != 1 || L.Cin != 3 || L.Cout > 64) return KOCR_OK;
+  const int Cout = L.Cout;
+  std::vector<unsigned short> u((size_t)2 * 2 * 3 * 512, 0);
+  for (int tap = 0; tap < 9; ++tap)
+    for (int c = 0; c < 3; ++c)
+      for (int o = 0; o < Cout; ++o) {
+        const float g = w_is_oihw ? w[((size_t)o * 3 + c) * 9 + tap] : w[((size_t)tap * 3 + c) * Cout + o];
+        const int kk = tap * 3 + c, kc = kk / 16, k = kk % 16;
+        const int lane = (k >> 3) * 32 + (o & 31), j = k & 7;
+        unsigned short pc[3];
+        kocr_split3_host(g, pc);
+        for (int s = 0; s < 3; ++s) u[((((size_t)kc * 2 + o / 32) * 3 + s) * 64 + lane) * 8 + j] = pc[s];
+      }
+  void* d = nullptr;
+  KOCR_TRY(ctx->dev_alloc(&d, u.size() * sizeof(unsigned short)));
+  KOCR_HIP(ctx, hipMemcpy(d, u.data(), u.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  L.d_first = (unsigned short*)d;
+  return KOCR_OK;
+}
+
+bool first_applicable(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in) {
+  static const bool off = getenv("KOCR_FIRST") && atoi(getenv("KOCR_FIRST")) == 0;
+  return !off && ctx->split_mode == KOCR_SPLIT_BF16X3 && L.d_first && (size_t)in.H * in.W * 64 * 4 < ((size_t)1 << 31);
+}
+
+int launch_conv_first(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8, const float* lut, const Tensor& out) {
+  if ((size_t)out.H * out.W * out.cs * 4 >= ((size_t)1 << 31)) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": image too large");
+  FirstParams p;
+  p.img = in_u8;
+  p.lut = lut;
+  p.wgt = L.d_first;
+  p.out = out.p;
+  p.pre_a = L.d_pre_a;
+  p.pre_b = L.d_pre_b;
+  p.post_a = L.d_post_a;
+  p.post_b = L.d_post_b;
+  p.H = in.H;
+  p.W = in.W;
+  p.Cout = L.Cout;
+  p.out_cs = out.cs;
+  p.out_co = out.co;
+  p.relu = L.relu;
+  p.tiles_x = (in.W + HS_TW - 1) / HS_TW;
+  p.tiles_y = (in.H + HS_TH - 1) / HS_TH;
+  const size_t M = in.pixels();
+  const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
+  const double bytes = (double)M * 3 + 4.0 * ((double)M * L.Cout + (double)L.Kreal * L.Cout);
+  ProfScope ps(ctx, "conv_hs_first_256x64", flops, bytes);
+  const size_t grid = (size_t)in.N * p.tiles_y * p.tiles_x;
+  if (grid > 0x7fffffff) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": too many tiles");
+  hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }

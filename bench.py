@@ -16,8 +16,11 @@ scaling, no data-path collective); value = N * 32 * K / max-over-ranks time of t
 which runs with the HIP-event profiler OFF.  A second loop of the same K steps with the profiler ON
 gives `stage_ms_per_step` and the `roofline` of the dominant kernel; further legs (never `value`):
 host-array input (`value_host_arrays`, PCIe inclusive), the other split mode, CRNN only (configs[2]),
-CRAFT only (configs[1]) and one rank's share of configs[4].  `parity` compares page 0 of the timed
-batch with the CPU oracle run of the `cpu_baseline` leg.
+CRAFT only (configs[1]), one rank's share of configs[4], and -- on every rank, also at N = 1 -- `cfg5_sharded`:
+ONE configs[4] batch of 32 x N pages of 1536x1536 (256 pages at N = 8) through `dist.ShardedPipeline`, each rank's block
+resident in its HBM, with the three RCCL result all-gathers INSIDE the timed region (`gather_ms`).  `parity` compares
+pages 0, 9, 18 and 31 of the timed batch with the CPU oracle (page 0 is the `cpu_baseline` run), counting the heat-map
+pixels that sit on the other side of a getBoxes threshold (oracle/parity.py).
 """
 import argparse
 import json
@@ -38,6 +41,7 @@ SCALE = 2
 WORDS_PER_PAGE = 20       # SURVEY.md 8(d) cfg 4: "~20 words each"
 FP32_MFMA_PEAK_TF = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 / fp16 MFMA peak, same table
+PARITY_PAGES = (0, 9, 18, 31)  # pages of the timed batch compared with the CPU oracle (as tests/test_baseline_sizes_gpu.py)
 
 
 def make_pages(n, side, seed, words=WORDS_PER_PAGE):
@@ -87,25 +91,70 @@ def cpu_baseline(craft_w, crnn_w, page):
     cores = min(os.cpu_count() or 1, 32)  # more torch threads than this slow the oracle down
     torch.set_num_threads(cores)
     t = time.perf_counter()
-    out = opipe.recognize(craft_w, crnn_w, [page], scale=SCALE)
+    heat = []
+    out = opipe.recognize(craft_w, crnn_w, [page], scale=SCALE, heat_out=heat)
     dt = time.perf_counter() - t
     return {"value": 1.0 / dt, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"1 synthetic {SIDE}x{SIDE} page, scale={SCALE}, full pipeline, {len(out[0])} words, "
-                      f"{dt:.1f} s on torch-CPU oracle (not TF)"}, out[0]
+                      f"{dt:.1f} s on torch-CPU oracle (not TF)"}, out[0], heat[0][0]
 
 
-def parity_of(gpu_page, oracle_page):
-    """Page 0 of the timed batch: GPU pipeline vs the CPU oracle (strings exact, boxes in input pixels)."""
+def parity_of(gpu_page, oracle_page, flipped=None, page=0):
+    """One page of the timed batch: GPU pipeline vs the CPU oracle (strings exact, boxes in input pixels).  With
+    `flipped` (the heat-map pixels that sit on the other side of a getBoxes threshold, oracle/parity.py) a box the
+    oracle has and the GPU has not -- or the reverse -- is accepted only when such a pixel lies in its neighbourhood."""
     gs, os_ = [t for t, _ in gpu_page], [t for t, _ in oracle_page]
     same_n = len(gpu_page) == len(oracle_page)
     diff = None
     if same_n and gpu_page:
         diff = float(max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max()
                          for (_, a), (_, b) in zip(gpu_page, oracle_page)))
-    return {"page": 0, "words_gpu": len(gpu_page), "words_oracle": len(oracle_page),
-            "strings_equal": gs == os_, "boxes_max_abs_diff_px": diff,
-            "ok": bool(same_n and gs == os_ and (diff is None or diff <= 1e-3)),
-            "note": "oracle = oracle/ (CPU restatement of the reference path); box tolerance 1e-3 px, strings exact"}
+    res = {"page": page, "words_gpu": len(gpu_page), "words_oracle": len(oracle_page),
+           "strings_equal": gs == os_, "boxes_max_abs_diff_px": diff,
+           "ok": bool(same_n and gs == os_ and (diff is None or diff <= 1e-3)),
+           "note": "oracle = oracle/ (CPU restatement of the reference path); box tolerance 1e-3 px, strings exact"}
+    if flipped is not None and not res["ok"]:
+        from oracle.parity import page_report
+
+        rep = page_report(gpu_page, oracle_page, flipped, float(SCALE))
+        res["flip_accounting"] = rep
+        res["ok"] = rep["ok"]
+    if flipped is not None:
+        res["flipped_threshold_pixels"] = int(len(flipped))
+    return res
+
+
+def parity_pages(ctx, craft_w, crnn_w, pages, gpu_out, page0_oracle, page0_heat):
+    """`parity` object of the bench line: pages PARITY_PAGES of the timed batch against the CPU oracle."""
+    from oracle import pipeline as opipe
+    from oracle.parity import flips
+
+    per_page, ok = [], True
+    for i in [q for q in PARITY_PAGES if q < len(pages)]:
+        if i == 0:
+            want, h_ref = page0_oracle, page0_heat
+        else:
+            heat = []
+            want = opipe.recognize(craft_w, crnn_w, [pages[i]], scale=SCALE, heat_out=heat)[0]
+            h_ref = heat[0][0]
+        big = ctx.resize_pad(pages[i][None], (pages[i].shape[1] * SCALE, pages[i].shape[0] * SCALE))
+        h_gpu = ctx.craft_forward(big)[0]
+        r = parity_of(gpu_out[i], want, flips(h_gpu, h_ref), page=i)
+        r["heat_max_abs_err"] = float(np.abs(h_gpu - h_ref).max())
+        r.pop("note")
+        per_page.append(r)
+        ok = ok and r["ok"] and r["heat_max_abs_err"] <= 2e-4
+    return {"pages": [r["page"] for r in per_page], "ok": bool(ok),
+            "words_gpu": sum(r["words_gpu"] for r in per_page), "words_oracle": sum(r["words_oracle"] for r in per_page),
+            "strings_equal": all(r["strings_equal"] for r in per_page),
+            "boxes_max_abs_diff_px": max([r["boxes_max_abs_diff_px"] for r in per_page if r["boxes_max_abs_diff_px"] is not None],
+                                         default=None),
+            "heat_max_abs_err": max(r["heat_max_abs_err"] for r in per_page),
+            "flipped_threshold_pixels": sum(r["flipped_threshold_pixels"] for r in per_page),
+            "per_page": per_page,
+            "note": "oracle = oracle/ (CPU restatement of the reference path); strings exact, boxes to 1e-3 px, heat-maps to "
+                    "2e-4; a missing / extra box is accepted only next to a heat-map pixel that lies on the other side of a "
+                    "getBoxes threshold (counted: flipped_threshold_pixels)"}
 
 
 def respawn_under_torchrun(args):
@@ -278,6 +327,26 @@ def main():
             "value": world * args.batch * args.steps / dt_host, "unit": "images/s", "ms_per_step": dt_host / args.steps * 1e3,
             "same_result_as_device_path": [[t for t, _ in g] for g in out_host] == [[t for t, _ in g] for g in out],
             "note": "pipe.recognize(numpy pages): 56.6 MB H2D per 32 pages + the result D2H inside the timed region"}
+    if not args.no_extra:
+        # BASELINE configs[4] as ONE batch over the whole job: 32 x N pages of 1536x1536 (256 at N = 8), scale 3 (capped:
+        # detector input 2048x2048), each rank's contiguous block of 32 already in its HBM; dist.ShardedPipeline runs the
+        # local chain and the three RCCL all-gathers of the packed results -- all inside the timed region
+        p5s = torch.from_numpy(make_pages(args.batch, 1536, seed=5 + rank, words=80)).cuda()
+        sp = k.dist.ShardedPipeline(k.pipeline.Pipeline(detector=det, recognizer=rec, scale=3))
+        n_tot = args.batch * world
+        sp.recognize_device(p5s.data_ptr(), n_tot, 1536, 1536)
+        tm = {}
+        reps = 2
+        dt5, o5s = timed(lambda: sp.recognize_device(p5s.data_ptr(), n_tot, 1536, 1536, timing=tm), reps)
+        extra["cfg5_sharded"] = {
+            "workload": f"BASELINE configs[4]: ONE batch of {n_tot} pages 1536x1536 (scale 3 -> 2048x2048) sharded over {world} "
+                        "rank(s) by dist.ShardedPipeline, contiguous blocks resident in each rank's HBM; result all-gathers "
+                        "(counts, boxes, label rows) over RCCL inside the timed region; every rank ends with the full result",
+            "value": n_tot * reps / dt5, "unit": "images/s (whole job)", "ms_per_batch": dt5 / reps * 1e3,
+            "gather_ms": tm.get("gather_s", 0.0) / reps * 1e3, "pages_returned_on_every_rank": len(o5s),
+            "words": sum(len(g) for g in o5s), "gather_payload_bytes_per_rank": tm.get("gather_payload_bytes_per_rank"),
+            "backend": torch.distributed.get_backend()}
+        del p5s
     crnn_us_per_crop = None
     if rank == 0:
         # secondary BASELINE metric: ms/crop of the CRNN alone (configs[2]: 512 pre-cropped 31x200 strips)
@@ -385,12 +454,13 @@ def main():
                        "parallelism": f"dp{world} (images sharded, one process per GPU, RCCL process group; no data-path collective)",
                        "split_mode": args.split},
             "roofline": {"bound": "mfma", "kernel": name,
-                         "achieved": executed, "peak": peak,
-                         "unit": "TFLOP/s", "frac": executed / peak,
-                         "note": "achieved = matrix-core FLOPs ISSUED (algorithmic direct-convolution fp32 FLOPs x "
-                                 + issue["why"] + ") / kernel time (HIP events, profiled loop of the same K steps) against the "
-                                 "dense peak of the pipe the kernel runs on; algorithmic_* = the same launches priced as plain "
-                                 "fp32 direct convolutions (SURVEY.md 8(d))",
+                         "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak,
+                         "note": "achieved = ALGORITHMIC direct-convolution fp32 FLOPs of the launches (SURVEY.md 8(d)) / kernel "
+                                 "time (HIP events, profiled loop of the same K steps); peak = dense peak of the matrix pipe the "
+                                 "kernel runs on; issued_* = the matrix-core FLOPs the kernel actually issues for them "
+                                 "(algorithmic x " + issue["why"] + "): the utilisation of that pipe, not the roofline fraction",
+                         "issued_tflops": executed,
                          "issued_frac_of_pipe_peak": executed / peak,
                          "algorithmic_fp32_tflops": achieved,
                          "algorithmic_frac_of_bf16_peak": achieved / BF16_MFMA_PEAK_TF,
@@ -418,8 +488,8 @@ def main():
         if alt is not None:
             res["alt_split_mode"] = alt
         if not args.no_cpu_baseline:
-            res["cpu_baseline"], oracle_page = cpu_baseline(craft_w, crnn_w, pages[0])
-            res["parity"] = parity_of(out[0], oracle_page)
+            res["cpu_baseline"], oracle_page, oracle_heat = cpu_baseline(craft_w, crnn_w, pages[0])
+            res["parity"] = parity_pages(ctx, craft_w, crnn_w, pages, out, oracle_page, oracle_heat)
         json_out.write(json.dumps(res) + "\n")
         json_out.flush()
     torch.distributed.barrier()

@@ -71,39 +71,62 @@ def ranks_seen(group=None):
 def packed_payload_bytes(per_rank_images, cap):
     """Bytes ONE rank contributes to the three all-gathers of `gather_packed` (counts, boxes, label rows)."""
     cap = max(int(cap), 1)
-    return {"counts": 4 * (per_rank_images + 1), "boxes": cap * 8 * 4, "labels": cap * LABEL_WIDTH * 4,
-            "total": 4 * (per_rank_images + 1) + cap * 8 * 4 + cap * LABEL_WIDTH * 4}
+    return {"counts": 4 * (per_rank_images + 2), "boxes": cap * 8 * 4, "labels": cap * LABEL_WIDTH * 4,
+            "total": 4 * (per_rank_images + 2) + cap * 8 * 4 + cap * LABEL_WIDTH * 4}
 
 
-def gather_packed(box_groups, labels, per_rank_images, group=None):
+class ShardError(RuntimeError):
+    """Raised on EVERY rank when the local chain of at least one rank failed (its message names the rank and the
+    original exception); the failing rank chains its own exception as __cause__."""
+
+
+def gather_packed(box_groups, labels, per_rank_images, group=None, error=None, timing=None):
     """all-gather of the per-image box counts, then of fixed-capacity packed results.
 
     Every rank contributes ``per_rank_images`` count slots (its shard, zero padded), a (cap, 8) float32
     box tensor and a (cap, 48) int32 label tensor, where cap = the largest crop count of any rank (known
     after the counts exchange).  Three collectives, no pickling; on the nccl backend the tensors stay in
     HBM and travel over xGMI.  Returns (box_groups, labels) of the whole batch in image order.
+
+    ``error``: the exception the local chain raised, if any.  The counts exchange carries a status slot, so a
+    data-dependent failure on one rank (the reference raises IndexError at detection.py:272 on an empty contour
+    list, ZeroDivisionError at tools.py:95) makes EVERY rank raise ``ShardError`` after the first collective instead
+    of leaving the others blocked in the box / label gathers.  ``timing`` (a dict) receives ``gather_s``.
     """
+    import time
     import torch
     import torch.distributed as dist
 
+    if error is not None:
+        box_groups, labels = [], np.zeros((0, LABEL_WIDTH), np.int32)
     counts_local = [len(b) for b in box_groups]
     m_local = int(sum(counts_local))
     labels = np.asarray(labels, np.int32).reshape(m_local, LABEL_WIDTH)
     boxes_local = (np.concatenate([np.asarray(b, np.float32).reshape(-1, 8) for b in box_groups if len(b)])
                    if m_local else np.zeros((0, 8), np.float32))
     if not (dist.is_available() and dist.is_initialized()):
+        if error is not None:
+            raise error
         return [np.asarray(b) for b in box_groups], labels
+    t0 = time.perf_counter()
     world = dist.get_world_size(group)
     dev = _comm_device(group)
-    # 1. counts: per_rank_images + 1 ints per rank (last slot = number of images this rank really had)
-    c = torch.zeros(per_rank_images + 1, dtype=torch.int32)
+    # 1. counts: per_rank_images + 2 ints per rank (slot -2 = number of images this rank really had, slot -1 = status)
+    c = torch.zeros(per_rank_images + 2, dtype=torch.int32)
     c[:len(counts_local)] = torch.tensor(counts_local, dtype=torch.int32)
-    c[-1] = len(counts_local)
+    c[-2] = len(counts_local)
+    c[-1] = 0 if error is None else 1
     c = c.to(dev)
-    all_c = torch.empty(world * (per_rank_images + 1), dtype=torch.int32, device=dev)
+    all_c = torch.empty(world * (per_rank_images + 2), dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(all_c, c, group=group)
-    all_c = all_c.cpu().numpy().reshape(world, per_rank_images + 1)
-    cap = max(int(all_c[:, :-1].sum(axis=1).max()), 1)
+    all_c = all_c.cpu().numpy().reshape(world, per_rank_images + 2)
+    failed = [r for r in range(world) if all_c[r, -1] != 0]
+    if failed:
+        msg = f"sharded recognize failed on rank(s) {failed}"
+        if error is not None:
+            raise ShardError(f"{msg}: {type(error).__name__}: {error}") from error
+        raise ShardError(msg)
+    cap = max(int(all_c[:, :-2].sum(axis=1).max()), 1)
     # 2. + 3. packed boxes and label rows, capacity = the busiest rank's crop count
     b = torch.zeros((cap, 8), dtype=torch.float32)
     b[:m_local] = torch.from_numpy(boxes_local)
@@ -115,10 +138,13 @@ def gather_packed(box_groups, labels, per_rank_images, group=None):
     dist.all_gather_into_tensor(all_l, l.to(dev), group=group)
     all_b = all_b.cpu().numpy().reshape(world, cap, 4, 2)
     all_l = all_l.cpu().numpy().reshape(world, cap, LABEL_WIDTH)
+    if timing is not None:
+        timing["gather_s"] = timing.get("gather_s", 0.0) + (time.perf_counter() - t0)
+        timing["gather_payload_bytes_per_rank"] = packed_payload_bytes(per_rank_images, cap)["total"]
     out_boxes, out_labels = [], []
     for r in range(world):
         pos = 0
-        for i in range(int(all_c[r, -1])):
+        for i in range(int(all_c[r, -2])):
             n = int(all_c[r, i])
             # an image without boxes is np.array([]) in the reference (detection.py:286)
             out_boxes.append(all_b[r, pos:pos + n].copy() if n else np.zeros((0,), np.float32))
@@ -141,7 +167,8 @@ class ShardedPipeline:
             return dist.get_rank(self.group), dist.get_world_size(self.group)
         return 0, 1
 
-    def recognize(self, images, detection_kwargs=None, recognition_kwargs=None):
+    def recognize(self, images, detection_kwargs=None, recognition_kwargs=None, timing=None):
+        """``timing`` (optional dict) receives ``gather_s``: the time spent in the three result all-gathers."""
         from . import tools
 
         if not isinstance(images, np.ndarray):
@@ -153,11 +180,25 @@ class ShardedPipeline:
         # the padded size comes from the WHOLE batch (pipeline.py:48-57), not from the shard
         _, _, _, hmax, wmax = self.pipeline._plan([im.shape for im in images])  # pylint: disable=protected-access
         start, end = shard_bounds(len(images), world, rank)
-        if end > start:
-            box_groups, labels = self.pipeline.recognize_raw(images[start:end], hmax, wmax, detection_kwargs,
-                                                             recognition_kwargs)
-        else:
-            box_groups, labels = [], np.zeros((0, LABEL_WIDTH), np.int32)
-        per = -(-len(images) // world)
-        box_groups, labels = gather_packed(box_groups, labels, per, self.group)
+        return self._run_shard(lambda: self.pipeline.recognize_raw(images[start:end], hmax, wmax, detection_kwargs,
+                                                                   recognition_kwargs),
+                               end > start, -(-len(images) // world), timing)
+
+    def recognize_device(self, d_ptr, n_total, h, w, detection_kwargs=None, timing=None):
+        """The same for a batch whose images are already resident in THIS rank's HBM (``d_ptr`` = device pointer of this
+        rank's contiguous block of images of the (n_total, h, w, 3) uint8 batch): every image has the same size, so the
+        whole batch's padded size is the shard's."""
+        rank, world = self._rank_world()
+        start, end = shard_bounds(n_total, world, rank)
+        return self._run_shard(lambda: self.pipeline.recognize_device_raw(d_ptr, end - start, h, w, detection_kwargs),
+                               end > start, -(-n_total // world), timing)
+
+    def _run_shard(self, run, has_work, per, timing):
+        box_groups, labels, err = [], np.zeros((0, LABEL_WIDTH), np.int32), None
+        if has_work:
+            try:
+                box_groups, labels = run()
+            except Exception as e:  # noqa: BLE001 -- exchanged as a status flag so that no rank is left in a collective
+                err = e
+        box_groups, labels = gather_packed(box_groups, labels, per, self.group, error=err, timing=timing)
         return self.pipeline.assemble(box_groups, labels)

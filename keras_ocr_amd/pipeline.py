@@ -63,7 +63,7 @@ class Pipeline:
         ctx = getattr(self.detector, "_ctx", None)
         if ctx is None or getattr(self.recognizer, "_ctx", None) is not ctx:
             # duck-typed / separately-placed stages: the reference's stage-wise path (pipeline.py:44-75)
-            return self._recognize_stagewise(images, detection_kwargs)
+            return self._recognize_stagewise(images, detection_kwargs, hmax, wmax)
         scales, dhs, dws, hmax_, wmax_ = self._plan([im.shape for im in images])
         hmax = hmax_ if hmax is None else max(hmax, hmax_)
         wmax = wmax_ if wmax is None else max(wmax, wmax_)
@@ -73,11 +73,14 @@ class Pipeline:
             micro_batch=micro_batch, **detection_kwargs)
         return self._adjust(box_groups, scales), labels
 
-    def _recognize_stagewise(self, images, detection_kwargs):
+    def _recognize_stagewise(self, images, detection_kwargs, hmax=None, wmax=None):
         """pipeline.py:44-75 with the public stage APIs only (any object with ``detect`` /
-        ``recognize_from_boxes``); strings are mapped back to label rows through the recognizer's alphabet."""
+        ``recognize_from_boxes``); strings are mapped back to label rows through the recognizer's alphabet.
+        ``hmax`` / ``wmax``: padded size imposed by the caller (a sharded batch pads to the WHOLE batch's size)."""
         resized = [tools.resize_image(image, max_scale=self.scale, max_size=self.max_size) for image in images]
         max_height, max_width = np.array([image.shape[:2] for image, _ in resized]).max(axis=0)
+        max_height = max(int(max_height), int(hmax or 0))
+        max_width = max(int(max_width), int(wmax or 0))
         scales = [scale for _, scale in resized]
         padded = np.array([tools.pad(image, width=max_width, height=max_height) for image, _ in resized])
         box_groups = self.detector.detect(images=padded, **detection_kwargs)
@@ -92,6 +95,10 @@ class Pipeline:
     def recognize_device(self, d_ptr, n, h, w, detection_kwargs=None):
         """Same as recognize() for a batch already resident in HBM: ``d_ptr`` = device pointer of an
         (n,h,w,3) uint8 tensor (e.g. ``torch.Tensor.data_ptr()``)."""
+        return self.assemble(*self.recognize_device_raw(d_ptr, n, h, w, detection_kwargs))
+
+    def recognize_device_raw(self, d_ptr, n, h, w, detection_kwargs=None):
+        """recognize_device up to (but not including) string assembly: ``(box_groups, label_rows)`` as recognize_raw."""
         detection_kwargs = dict(detection_kwargs or {})
         ctx = self.detector._ctx  # pylint: disable=protected-access
         scales, dhs, dws, hmax, wmax = self._plan([(h, w, 3)] * n)
@@ -99,7 +106,7 @@ class Pipeline:
         stride = h * w * 3
         box_groups, labels = ctx.pipeline([int(d_ptr) + i * stride for i in range(n)], [h] * n, [w] * n, dhs, dws,
                                           hmax, wmax, micro_batch=micro_batch, on_device=True, **detection_kwargs)
-        return self.assemble(self._adjust(box_groups, scales), labels)
+        return self._adjust(box_groups, scales), labels
 
     @staticmethod
     def _adjust(box_groups, scales):

@@ -1,0 +1,46 @@
+"""Oracle: end-to-end comparison of a GPU result with the CPU oracle's.  TEST INFRASTRUCTURE ONLY (imported by tests/
+and by bench.py's ``parity`` leg).
+
+getBoxes looks at the heat-map only through three comparisons (text > 0.4, link > 0.4, component max >= 0.7;
+detection.py:221-241) and the GPU post-processing is bit-identical to the oracle's on the SAME heat-map
+(tests/test_postproc_gpu.py), so an end-to-end difference can only come from a pixel whose heat value lies within the
+fp32 heat-map error of a threshold and lands on the other side.  ``flips`` counts those pixels; ``page_report`` requires
+every oracle box that no flipped pixel touches to be reproduced to 1e-3 px with the identical string."""
+import numpy as np
+
+
+def flips(heat_gpu, heat_ref):
+    """pixels whose thresholded text / link value differs between the two heat-maps (one image)"""
+    f = ((heat_gpu[..., 0] > np.float32(0.4)) != (heat_ref[..., 0] > np.float32(0.4))) | \
+        ((heat_gpu[..., 1] > np.float32(0.4)) != (heat_ref[..., 1] > np.float32(0.4)))
+    return np.argwhere(f)  # (y, x) in heat-map pixels
+
+
+def page_report(got, want, flipped, scale):
+    """got / want: lists of (text, box) in INPUT-image pixels; flipped: heat-map pixels (detector input / 2).
+    Returns counts: boxes reproduced to 1e-3 px (``boxes_equal``), of those with a different string
+    (``strings_differ``), oracle boxes not reproduced but explained by a flipped pixel in their neighbourhood
+    (``boxes_moved_by_flips``), not explained (``unexplained``), and the surplus / deficit of GPU boxes."""
+    gb = [np.asarray(b, np.float64) for _, b in got]
+    used = set()
+    rep = {"boxes_equal": 0, "strings_differ": 0, "boxes_moved_by_flips": 0, "unexplained": 0,
+           "count_diff": abs(len(got) - len(want)), "flipped_pixels": int(len(flipped)), "max_box_diff_px": 0.0}
+    for text, box in want:
+        box = np.asarray(box, np.float64)
+        d = [float(np.abs(box - b).max()) if i not in used else np.inf for i, b in enumerate(gb)]
+        j = int(np.argmin(d)) if d else -1
+        if j >= 0 and d[j] <= 1e-3:
+            used.add(j)
+            rep["boxes_equal"] += 1
+            rep["strings_differ"] += int(got[j][0] != text)
+            rep["max_box_diff_px"] = max(rep["max_box_diff_px"], d[j])
+            continue
+        # not reproduced: must be explained by a flipped pixel inside the word's neighbourhood (box in heat-map
+        # pixels = input px * scale / 2, grown by the dilation radius bound)
+        hb = box * scale / 2.0
+        x0, y0, x1, y1 = hb[:, 0].min() - 24, hb[:, 1].min() - 24, hb[:, 0].max() + 24, hb[:, 1].max() + 24
+        near = any(x0 <= x <= x1 and y0 <= y <= y1 for y, x in flipped)
+        rep["boxes_moved_by_flips"] += 1
+        rep["unexplained"] += int(not near)
+    rep["ok"] = bool(rep["strings_differ"] == 0 and rep["unexplained"] == 0 and rep["count_diff"] <= len(flipped))
+    return rep

@@ -280,8 +280,15 @@ def invert3(M):
     return t
 
 
-def warp_perspective_u8(image, M, dsize):
-    """cv2.warpPerspective(image, M, dsize) — 2-D uint8, INTER_LINEAR, BORDER_CONSTANT 0."""
+def warp_perspective_u8(image, M, dsize, assoc="pixel"):
+    """cv2.warpPerspective(image, M, dsize) — 2-D uint8, INTER_LINEAR, BORDER_CONSTANT 0.
+
+    ``assoc``: floating-point association of the coordinate numerators.  "pixel" (the oracle's and the device code's
+    order) evaluates ``(Mi0 x + Mi1 y) + Mi2`` per pixel.  "blockwise" is the order OpenCV's WarpPerspectiveInvoker is
+    believed to use (imgwarp.cpp; not executable here, no cv2): per block of 64 columns starting at bx,
+    ``X0 = (Mi0 bx + Mi1 y) + Mi2`` and per pixel ``X0 + Mi0 x1`` with x = bx + x1 (likewise Y and W).  The two differ
+    by one float64 rounding; that can move a 1/32-pixel coordinate across a rounding tie and with it a crop pixel by
+    one grey level.  tests/test_oracle_cpu.py::test_warp_association_orders_differ_in_few_pixels counts how often."""
     dw, dh = int(dsize[0]), int(dsize[1])
     H, W = image.shape[:2]
     Mi = np.array(invert3(M), dtype=np.float64)
@@ -290,9 +297,19 @@ def warp_perspective_u8(image, M, dsize):
         return out
     xs = np.arange(dw, dtype=np.float64)[None, :]
     ys = np.arange(dh, dtype=np.float64)[:, None]
-    X0 = (Mi[0, 0] * xs + Mi[0, 1] * ys) + Mi[0, 2]
-    Y0 = (Mi[1, 0] * xs + Mi[1, 1] * ys) + Mi[1, 2]
-    W0 = (Mi[2, 0] * xs + Mi[2, 1] * ys) + Mi[2, 2]
+    if assoc == "pixel":
+        X0 = (Mi[0, 0] * xs + Mi[0, 1] * ys) + Mi[0, 2]
+        Y0 = (Mi[1, 0] * xs + Mi[1, 1] * ys) + Mi[1, 2]
+        W0 = (Mi[2, 0] * xs + Mi[2, 1] * ys) + Mi[2, 2]
+    elif assoc == "blockwise":
+        bw = min(64, dw)                      # BLOCK_SZ^2 / min(BLOCK_SZ / 2, height) columns per block
+        bx = (xs // bw) * bw
+        x1 = xs - bx
+        X0 = ((Mi[0, 0] * bx + Mi[0, 1] * ys) + Mi[0, 2]) + Mi[0, 0] * x1
+        Y0 = ((Mi[1, 0] * bx + Mi[1, 1] * ys) + Mi[1, 2]) + Mi[1, 0] * x1
+        W0 = ((Mi[2, 0] * bx + Mi[2, 1] * ys) + Mi[2, 2]) + Mi[2, 0] * x1
+    else:
+        raise ValueError(assoc)
     with np.errstate(divide="ignore", invalid="ignore"):
         Wi = np.where(W0 != 0, 32.0 / W0, 0.0)
     fX = np.clip(X0 * Wi, -2147483648.0, 2147483647.0)

@@ -36,6 +36,11 @@ def test_parity_object():
     count = bench.parity_of([("ab", box)], [])
     assert not count["ok"] and count["boxes_max_abs_diff_px"] is None
     assert bench.parity_of([], [])["ok"]
+    # a box the GPU does not have is accepted only next to a flipped threshold pixel (heat-map px = input px * scale / 2)
+    far = bench.parity_of([("ab", box)], [("ab", box), ("c", box + 300)], flipped=np.array([[2, 3]]))
+    assert not far["ok"] and far["flip_accounting"]["unexplained"] == 1
+    near = bench.parity_of([("ab", box)], [("ab", box), ("c", box + 300)], flipped=np.array([[301, 305]]))
+    assert near["ok"] and near["flip_accounting"]["boxes_moved_by_flips"] == 1 and near["flipped_threshold_pixels"] == 1
 
 
 def test_issued_work_model():

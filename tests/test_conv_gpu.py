@@ -4,12 +4,20 @@ PyTorch fp32 reference of the same op (floating-point kernel -> torch fp32 refer
 Tolerance: both sides accumulate in fp32 in different orders; |err| <= 2e-5 * sqrt(K) *
 max|out| is far above fp32 round-off for these sizes and far below the heat-map tolerance.
 """
+import zlib
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+
+
+def _seed(*key):
+    """per-case seed that does not depend on PYTHONHASHSEED (str hashes are salted per process)"""
+    return zlib.crc32(repr(key).encode())
+
 
 CASES = [
     # N, H, W, Cin, Cout, k, dil
@@ -55,7 +63,7 @@ def _ref(x, w, dil, pre_a, pre_b, relu, post_a, post_b):
 @pytest.mark.parametrize("variant", ["bias_relu", "relu_then_bn", "linear"])
 def test_conv_matches_torch(ctx, case, variant):
     n, h, w, cin, cout, k, dil = case
-    rng = np.random.default_rng(hash((case, variant)) % (2 ** 32))
+    rng = np.random.default_rng(_seed(case, variant))
     x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
     wt = (rng.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32)
     pre_a = rng.uniform(0.5, 1.5, cout).astype(np.float32)
@@ -125,7 +133,7 @@ SPLIT_CASES = [
 @pytest.mark.parametrize("case", SPLIT_CASES, ids=[str(c) for c in SPLIT_CASES])
 def test_split_kernel_is_fp32_class_against_fp64(ctx, case):
     n, h, w, cin, cout = case
-    rng = np.random.default_rng(hash(case) % (2 ** 32))
+    rng = np.random.default_rng(_seed(case))
     x = np.maximum(rng.standard_normal((n, h, w, cin)), 0).astype(np.float32)  # post-ReLU-like, half zeros
     wt = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32)
     got = ctx.conv2d_nhwc(x, wt).astype(np.float64)
@@ -159,7 +167,7 @@ DSPLIT_CASES = [
 @pytest.mark.parametrize("case", DSPLIT_CASES, ids=[str(c) for c in DSPLIT_CASES])
 def test_direct_split_kernel_is_fp32_class_against_fp64(ctx, case):
     n, h, w, cin, cout, k, dil = case
-    rng = np.random.default_rng(hash(case) % (2 ** 32))
+    rng = np.random.default_rng(_seed(case))
     x = np.maximum(rng.standard_normal((n, h, w, cin)), 0).astype(np.float32)
     wt = (rng.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32)
     pre_a = rng.uniform(0.5, 1.5, cout).astype(np.float32)

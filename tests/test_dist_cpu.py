@@ -174,5 +174,83 @@ def test_packed_payload_bytes():
     from keras_ocr_amd import dist as kd
 
     p = kd.packed_payload_bytes(32, 1128)
-    assert p == {"counts": 132, "boxes": 1128 * 32, "labels": 1128 * 192, "total": 132 + 1128 * 224}
-    assert kd.packed_payload_bytes(4, 0)["total"] == 20 + 224
+    assert p == {"counts": 136, "boxes": 1128 * 32, "labels": 1128 * 192, "total": 136 + 1128 * 224}
+    assert kd.packed_payload_bytes(4, 0)["total"] == 24 + 224
+
+
+class _FailingPipeline(_FakePipeline):
+    """recognize_raw raises on the rank whose shard contains the image of height 13 (a data-dependent failure such as the
+    reference's IndexError at detection.py:272)."""
+
+    def recognize_raw(self, images, hmax, wmax, detection_kwargs=None, recognition_kwargs=None):
+        if any(im.shape[0] == 13 for im in images):
+            raise IndexError("list index out of range (empty contour list)")
+        return super().recognize_raw(images, hmax, wmax, detection_kwargs, recognition_kwargs)
+
+
+def _worker_fail(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import keras_ocr_amd
+
+    keras_ocr_amd.dist.init_from_env(backend="gloo")
+    images = [np.zeros((10 + i, 20, 3), np.uint8) for i in range(6)]   # height 13 = image 3 -> rank 1's shard
+    sp = keras_ocr_amd.dist.ShardedPipeline(_FailingPipeline())
+    try:
+        sp.recognize(images)
+        q.put((rank, "no error", None))
+    except keras_ocr_amd.dist.ShardError as e:
+        q.put((rank, str(e), type(e.__cause__).__name__ if e.__cause__ is not None else None))
+    # the group is still usable: no rank was left behind in a collective
+    ok = keras_ocr_amd.dist.ShardedPipeline(_FakePipeline()).recognize(images[:3])
+    q.put((rank, "after", len(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_failure_on_one_rank_raises_on_every_rank_gloo_world2():
+    """a data-dependent failure of one rank's shard must not leave the other ranks blocked in the box / label
+    all-gathers: the counts exchange carries a status flag and every rank raises ShardError after the FIRST collective."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fail, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(4))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    errs = {r: (m, c) for r, m, c in res if m != "after"}
+    assert "rank(s) [1]" in errs[0][0] and errs[0][1] is None            # rank 0 learns of it through the status slot
+    assert "rank(s) [1]" in errs[1][0] and "IndexError" in errs[1][0] and errs[1][1] == "IndexError"
+    assert [(r, n) for r, m, n in res if m == "after"] == [(0, 3), (1, 3)]
+
+
+def test_stagewise_path_pads_to_the_imposed_size(monkeypatch):
+    """duck-typed stages (no shared libkocr context) take the stage-wise path; a sharded call must still pad
+    to the WHOLE batch's size, not to the shard's own maximum."""
+    import keras_ocr_amd as k
+
+    seen = {}
+
+    class Det:
+        def detect(self, images, **kw):
+            seen["shape"] = images.shape
+            return [np.array([])] * len(images)
+
+    class Rec:
+        alphabet = k.recognition.DEFAULT_ALPHABET
+
+        def recognize_from_boxes(self, images, box_groups, **kw):
+            return [[] for _ in images]
+
+    # tools.resize_image runs on the GPU; the padding rule under test does not depend on its pixels
+    monkeypatch.setattr(k.tools, "resize_image", lambda image, max_scale, max_size: (
+        np.zeros((image.shape[0] * max_scale, image.shape[1] * max_scale, 3), np.uint8), max_scale))
+    pipe = k.pipeline.Pipeline(detector=Det(), recognizer=Rec(), scale=2)
+    pipe.recognize_raw([np.zeros((10, 12, 3), np.uint8)], hmax=64, wmax=80)
+    assert seen["shape"] == (1, 64, 80, 3)
+    pipe.recognize_raw([np.zeros((10, 12, 3), np.uint8)])
+    assert seen["shape"] == (1, 20, 24, 3)

@@ -1,0 +1,41 @@
+"""The fallback kernels behind the library's environment switches, verified in FRESH processes (the switches are read
+once per process): the fp64-bounded convolution tests and the CRAFT heat-map-vs-oracle tests must also hold with
+
+  KOCR_W43=0     no F(4,3) kernels          -> wide 3x3 layers on conv_ws (F(2,3)) / conv_ds
+  KOCR_W43R=0    no row-reuse arrangement   -> 64-cout layers on conv_w43n
+  KOCR_HSPLIT=0  no <= 32-cout split kernel -> head / upconv4.conv.3 on the fp32 Winograd kernel
+  KOCR_FIRST=0   no split first-layer kernel-> first layer on the fp32 MFMA kernel (conv_mfma MODE 2)
+  KOCR_HEADFUSE=0 no fused detector head    -> upconv4.conv.3 and conv_cls.* as separate launches
+
+(these paths were reached by the driver's suite only through the shapes that happen to select
+them.)  Each configuration is one pytest child process over the same test files, same bounds."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CONFIGS = [
+    {"KOCR_W43": "0"},
+    {"KOCR_W43R": "0"},
+    {"KOCR_HSPLIT": "0"},
+    {"KOCR_FIRST": "0"},
+    {"KOCR_HEADFUSE": "0"},
+]
+
+
+@pytest.mark.parametrize("switches", CONFIGS, ids=[",".join(f"{k}={v}" for k, v in c.items()) for c in CONFIGS])
+def test_parity_suites_hold_on_the_fallback_path(switches):
+    env = dict(os.environ)
+    env.update(switches)
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(ROOT, "tests", "test_conv_gpu.py"), os.path.join(ROOT, "tests", "test_craft_gpu.py"),
+           "-k", "fp32_class or heatmap_f32_input or heatmap_u8_input or cfg2_size"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900, check=False)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, f"{switches}: child pytest failed\n{tail}"
+    assert " passed" in r.stdout and "failed" not in r.stdout.splitlines()[-1], tail

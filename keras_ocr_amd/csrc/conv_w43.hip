@@ -1174,6 +1174,402 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
   }
 }
 
+// ===================================================================================================
+// conv_w43v_kernel -- the row-reuse idea of conv_w43r_kernel for layers with Cout > 64 (round 3).  A tile is a block of
+// output rows x columns of ONE image (256 pixels, two M-tiles of 2 rows x 64 columns -- the fused-pool geometry) x 128
+// couts; the K loop runs over channel groups only: every input row the tile touches is transformed and split ONCE per
+// 16-channel group into LDS (double buffered) and the three vertical taps read it back at a row offset:
+//   GEO = 0: tile = 2 rows x 128 columns (M-tiles side by side),  4 input rows per 2 output rows (conv_w43_kernel: 6),
+//            72 KB per buffer, two gather items (row, quad, channel quad) per thread and channel group;
+//   GEO = 1: tile = 4 rows x 64 columns (M-tiles stacked),        6 input rows per 4 output rows,
+//            54 KB per buffer, one full gather item + one HALF item (two channels, 8-byte loads) per thread.
+// That is a third / a half less transform + split VALU work, LDS stores and raw-pixel loads per MFMA than conv_w43_kernel
+// and one block barrier per 216 MFMAs instead of three.  Wave wn owns both M-tiles x couts [32 wn, 32 wn + 32) x all six
+// points = 192 accumulators, exactly as in conv_w43_kernel, so the output transform stays inside the wave; weights:
+// conv_w43_kernel's layout and order ([16-ch group][ky][32-cout tile][xi][piece][lane][8]), one (channel group, ky)
+// step ahead in registers.  Per channel group: ky = 0 consumes 6 points while item 0's six points of the NEXT channel
+// group are produced (one per point, 1 MFMA : 3 VALU), ky = 1 the same with item 1, ky = 2 produces nothing.
+// Needs Cin % 32 == 0, dilation 1 and H even, W % 128 == 0 (GEO 0) / H % 4 == 0, W % 64 == 0 (GEO 1).
+// POOL = 1: fused 2x2 max-pool (full-resolution store optional).
+// ===================================================================================================
+// input transform of point xi (fp32, fixed operation order; T = v4f or v2f)
+template <class T>
+__device__ __forceinline__ T w4_transform(const T (&d)[6], int xi) {
+  switch (xi) {
+    case 0: return (W4_A2B2 * d[0] - W4_A2PB2 * d[2]) + d[4];
+    case 1: return (d[4] - W4_B2 * d[2]) + W4_A * (d[3] - W4_B2 * d[1]);
+    case 2: return (d[4] - W4_B2 * d[2]) - W4_A * (d[3] - W4_B2 * d[1]);
+    case 3: return (d[4] - W4_A2 * d[2]) + W4_B * (d[3] - W4_A2 * d[1]);
+    case 4: return (d[4] - W4_A2 * d[2]) - W4_B * (d[3] - W4_A2 * d[1]);
+    default: return (W4_A2B2 * d[1] - W4_A2PB2 * d[3]) + d[5];
+  }
+}
+
+template <int POOL, int GEO>
+__global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
+  constexpr int NROWS = GEO ? 6 : 4;            // input rows of the tile's window
+  constexpr int QPR = GEO ? 16 : 32;            // quads per tile row
+  constexpr int KHS = QPR * 8;                  // ushorts of one k half of a row: QPR quads x 8 channels
+  constexpr int ROW_STRIDE = 2 * KHS;           // ushorts per input row of a plane
+  constexpr int PLANE_R = NROWS * ROW_STRIDE;   // one (xi, piece) plane
+  constexpr int BUF_R = 6 * 3 * PLANE_R;        // one channel group: 72 KB / 54 KB
+  constexpr int TCOLS = QPR * 4;                // tile columns
+  extern __shared__ __attribute__((aligned(16))) unsigned short As[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = cout sub-tile
+  const int l31 = lane & 31, l5 = lane >> 5;
+  const int nblk_n = p.Cout_pad >> 7;
+  const int total = p.total_tiles;
+  const int ncg = p.Cin >> 4;
+  const int ns = 3 * ncg;
+  const int G = gridDim.x;
+  constexpr unsigned OOB = 0x80000000u;
+
+  // pixel tile mp -> its first M-tile in conv_w43_kernel's fused-pool numbering (row pair major, 64-column blocks) and
+  // the M-tile after it: side by side (GEO 0) or the next row pair (GEO 1)
+  auto tile_mt = [&](int mp, int m) {
+    if constexpr (GEO) {
+      const int rq = mp / p.tiles_per_row, cb = mp - rq * p.tiles_per_row;  // rq: (image, row quad)
+      return (2 * rq + m) * p.tiles_per_row + cb;
+    } else {
+      return 2 * mp + m;
+    }
+  };
+
+  // ---- producer state -----------------------------------------------------------------------------------------
+  // item 0: input row r0 of the window, quad qd0, channel quad q4 (16-byte loads).  item 1: GEO 0: row r0 + 2, same quad
+  // and channels; GEO 1: row 4 + (tid >> 7), quad (tid >> 3) & 15, channel PAIR tid & 7 (8-byte loads).
+  const int q4 = tid & 3, qd0 = (tid >> 2) & (QPR - 1), r0 = GEO ? (tid >> 6) : (tid >> 7);
+  const int cp = tid & 7, qd1 = GEO ? ((tid >> 3) & 15) : qd0, r1 = GEO ? 4 + (tid >> 7) : r0 + 2;
+  int ldst[2];
+  ldst[0] = r0 * ROW_STRIDE + (q4 >> 1) * KHS + (((qd0 * 8) ^ ((q4 >> 1) * 32)) + (q4 & 1) * 4);
+  if constexpr (GEO)
+    ldst[1] = r1 * ROW_STRIDE + (cp >> 2) * KHS + (((qd1 * 8) ^ ((cp >> 2) * 32)) + (cp & 3) * 2);
+  else
+    ldst[1] = r1 * ROW_STRIDE + (q4 >> 1) * KHS + (((qd1 * 8) ^ ((q4 >> 1) * 32)) + (q4 & 1) * 4);
+  struct Geo {
+    unsigned off0[2];  // byte offset of raw pixel d0 of each item
+    unsigned ok;       // bit it: the item's input row lies inside the image (and the tile exists)
+    const float* base;
+  };
+  auto make_geo = [&](int L, Geo& g, bool& left, bool& right) __attribute__((always_inline)) {
+    int mp, nt_unused;
+    w4_decode(p, kocr_xcd_remap(L < total ? L : 0, total), nblk_n, mp, nt_unused);
+    int y0, x0;
+    const long pm = w4_mtile_pm0<1>(p, tile_mt(mp, 0), y0, x0);
+    g.base = p.in + (pm * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
+    g.off0[0] = (unsigned)(((r0 * p.W + 4 * qd0) * p.in_cs + q4 * 4) * 4);
+    g.off0[1] = (unsigned)(((r1 * p.W + 4 * qd1) * p.in_cs + (GEO ? cp * 2 : q4 * 4)) * 4);
+    g.ok = ((L < total && (unsigned)(y0 - 1 + r0) < (unsigned)p.H) ? 1u : 0u) |
+           ((L < total && (unsigned)(y0 - 1 + r1) < (unsigned)p.H) ? 2u : 0u);
+    // d0 / d5 are column zero padding only at the image edges (W is a multiple of the tile width); bit 0: item 0, bit 1: item 1
+    left = x0 == 0;
+    right = x0 + TCOLS >= p.W;
+  };
+  Geo gc, gn;
+  bool lc, rc, ln, rn;
+  int ld_cg = 0;  // channel group of the NEXT load inside its tile
+  bool ld_next = false;
+  typedef typename std::conditional<GEO != 0, v2f, v4f>::type raw1_t;
+  auto load_item0 = [&](v4f (&raw)[6]) __attribute__((always_inline)) {
+    const int soff = ld_cg * 64;
+    const bool ok = (ld_next ? gn.ok : gc.ok) & 1u;
+    const unsigned off0 = (ld_next ? gn.off0[0] : gc.off0[0]) | (ok ? 0u : OOB);
+    const bool left = (ld_next ? ln : lc) && qd0 == 0, right = (ld_next ? rn : rc) && qd0 == QPR - 1;
+    const unsigned stride = (unsigned)(p.in_cs * 4);
+    const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const unsigned padk = (k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u);
+      raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (off0 + k * stride) | padk, soff, 0));
+    }
+  };
+  auto load_item1 = [&](raw1_t (&raw)[6]) __attribute__((always_inline)) {
+    const int soff = ld_cg * 64;
+    const bool ok = ((ld_next ? gn.ok : gc.ok) >> 1) & 1u;
+    const unsigned off0 = (ld_next ? gn.off0[1] : gc.off0[1]) | (ok ? 0u : OOB);
+    const bool left = (ld_next ? ln : lc) && qd1 == 0, right = (ld_next ? rn : rc) && qd1 == QPR - 1;
+    const unsigned stride = (unsigned)(p.in_cs * 4);
+    const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const unsigned padk = (k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u);
+      if constexpr (GEO)
+        raw[k] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (off0 + k * stride) | padk, soff, 0));
+      else
+        raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (off0 + k * stride) | padk, soff, 0));
+    }
+  };
+  auto advance = [&]() __attribute__((always_inline)) {
+    const bool wrap = ld_cg == ncg - 1;
+    ld_cg = wrap ? 0 : ld_cg + 1;
+    ld_next = ld_next || wrap;
+  };
+  auto produce4 = [&](const v4f (&d)[6], unsigned short* bufp, int xi, int it) __attribute__((always_inline)) {
+    const v4f V = w4_transform(d, xi);
+    u2v h, m, l;
+    kocr_split4(V, h, m, l);
+    unsigned short* dst = bufp + xi * 3 * PLANE_R + ldst[it];
+    *reinterpret_cast<u2v*>(dst) = h;
+    *reinterpret_cast<u2v*>(dst + PLANE_R) = m;
+    *reinterpret_cast<u2v*>(dst + 2 * PLANE_R) = l;
+  };
+  auto produce2 = [&](const v2f (&d)[6], unsigned short* bufp, int xi) __attribute__((always_inline)) {
+    const v2f V = w4_transform(d, xi);
+    unsigned h, m, l;
+    kocr_split2(V, h, m, l);
+    unsigned short* dst = bufp + xi * 3 * PLANE_R + ldst[1];
+    *reinterpret_cast<unsigned*>(dst) = h;
+    *reinterpret_cast<unsigned*>(dst + PLANE_R) = m;
+    *reinterpret_cast<unsigned*>(dst + 2 * PLANE_R) = l;
+  };
+  v4f raw0[6];
+  raw1_t raw1[6];
+  auto produce_item1 = [&](unsigned short* bufp, int xi) __attribute__((always_inline)) {
+    if constexpr (GEO)
+      produce2(raw1, bufp, xi);
+    else
+      produce4(raw1, bufp, xi, 1);
+  };
+
+  // ---- consumer state ------------------------------------------------------------------------------------------
+  const int ntiles32 = p.Cout_pad >> 5;
+  const size_t w_step = (size_t)ntiles32 * 18 * 64 * 8;  // ushorts per (channel group, ky) step
+  auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * 4 + wn) * 18 * 64 + lane) * 8; };
+  bf8 bw[6][3];
+  f16v acc[6][2];
+  // M row l31 of M-tile m: window row (l31 >> 4) + ky [+ 2 m: GEO 1], quad (l31 & 15) [+ 16 m: GEO 0], k half l5
+  const int a_lane = (l31 >> 4) * ROW_STRIDE + l5 * KHS + (((l31 & 15) * 8) ^ (l5 * 32));
+  constexpr int M_OFF = GEO ? 2 * ROW_STRIDE : 128;  // M-tile 1: two rows down / 16 quads to the right
+  auto load_a = [&](bf8 (&a)[2][3], const unsigned short* bufp, int ky, int xi) __attribute__((always_inline)) {
+    const unsigned short* base = bufp + a_lane + ky * ROW_STRIDE + xi * 3 * PLANE_R;
+#pragma unroll
+    for (int s = 2; s >= 0; --s)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m][s] = *reinterpret_cast<const bf8*>(base + s * PLANE_R + m * M_OFF);
+  };
+  auto mfma12 = [&](const bf8 (&a)[2][3], int xi) __attribute__((always_inline)) {
+    const bf8 b0 = bw[xi][0], b1 = bw[xi][1], b2 = bw[xi][2];
+    // smallest terms first; the two M-tiles alternate so consecutive MFMAs are independent
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b0, acc[xi][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b2, acc[xi][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b1, acc[xi][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b0, acc[xi][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b1, acc[xi][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b0, acc[xi][m], 0, 0, 0);
+  };
+  // One (channel group, ky) step: consume rows ky .. ky + 1 (+ M-tile offset) of `bufc` (6 points x 12 MFMAs); KY = 0 / 1
+  // also transforms item 0 / 1 of the NEXT channel group into `bufn`, one point per MFMA group.  The weights of the next
+  // step (w_next) replace this step's point by point.  a0 holds point 0 of this step on entry and point 0 of the next
+  // step on exit; for KY = 2 the next step lives in `bufn`, published by the block barrier before the last point's MFMAs.
+  bf8 a0[2][3], a1[2][3];
+  auto step = [&](auto ky_c, const unsigned short* bufc, unsigned short* bufn, const unsigned short* w_next) __attribute__((always_inline)) {
+    constexpr int KY = decltype(ky_c)::value;
+    auto load_b = [&](int xi) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w_next + (size_t)(xi * 3 + s) * 64 * 8);
+    };
+    auto produce = [&](int xi) __attribute__((always_inline)) {
+      if constexpr (KY == 0) produce4(raw0, bufn, xi, 0);
+      if constexpr (KY == 1) produce_item1(bufn, xi);
+    };
+    auto interleave = [&]() __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);  // the 6 LDS fetches of the next point first
+      if constexpr (KY == 0 || (KY == 1 && !GEO)) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // 3 VALU
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);  // the point's 3 LDS stores
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      } else if constexpr (KY == 1) {  // half item: about half the VALU work
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(a1, bufc, KY, 2 * q + 1);
+      produce(2 * q);
+      mfma12(a0, 2 * q);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(2 * q);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q < 2) {
+        load_a(a0, bufc, KY, 2 * q + 2);
+        produce(2 * q + 1);
+        mfma12(a1, 2 * q + 1);
+        interleave();
+      } else if constexpr (KY < 2) {
+        load_a(a0, bufc, KY + 1, 0);
+        produce(5);
+        mfma12(a1, 5);
+        interleave();
+      } else {
+        __syncthreads();  // the next channel group is complete in bufn, bufc is free
+        load_a(a0, bufn, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma12(a1, 5);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(2 * q + 1);
+    }
+  };
+
+  // ---- prologue ------------------------------------------------------------------------------------------------
+  make_geo(blockIdx.x, gc, lc, rc);
+  make_geo(blockIdx.x + G, gn, ln, rn);
+  load_item0(raw0);
+  load_item1(raw1);
+  advance();  // channel group 0 loaded
+  {
+    int mp0, nt0;
+    w4_decode(p, kocr_xcd_remap(blockIdx.x, total), nblk_n, mp0, nt0);
+    const unsigned short* w0 = w_tile(nt0);
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) bw[xi][s] = *reinterpret_cast<const bf8*>(w0 + (size_t)(xi * 3 + s) * 64 * 8);
+  }
+#pragma unroll
+  for (int xi = 0; xi < 6; ++xi) {
+    produce4(raw0, As, xi, 0);
+    produce_item1(As, xi);
+  }
+  load_item0(raw0);
+  load_item1(raw1);
+  advance();  // channel group 1 loaded
+  __syncthreads();
+  load_a(a0, As, 0, 0);
+
+  for (int L = blockIdx.x; L < total; L += G) {
+    int mp, nt, mp_n, nt_n;
+    w4_decode(p, kocr_xcd_remap(L, total), nblk_n, mp, nt);
+    w4_decode(p, kocr_xcd_remap(L + G < total ? L + G : L, total), nblk_n, mp_n, nt_n);
+    const unsigned short* w_ptr = w_tile(nt);
+    const unsigned short* w_after = w_tile(nt_n);
+    auto w_at = [&](int s) { return s < ns ? w_ptr + (size_t)s * w_step : w_after; };
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][m][r] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int cg = 0; cg < ncg; cg += 2) {
+      // even channel group: consume buffer 0, produce the odd one into buffer 1 (items refilled with channel group + 2)
+      step(std::integral_constant<int, 0>{}, As, As + BUF_R, w_at(3 * cg + 1));
+      load_item0(raw0);
+      step(std::integral_constant<int, 1>{}, As, As + BUF_R, w_at(3 * cg + 2));
+      load_item1(raw1);
+      advance();
+      step(std::integral_constant<int, 2>{}, As, As + BUF_R, w_at(3 * cg + 3));
+      // odd channel group: consume buffer 1, produce the next even one (possibly the next tile's first) into buffer 0
+      step(std::integral_constant<int, 0>{}, As + BUF_R, As, w_at(3 * cg + 4));
+      load_item0(raw0);
+      step(std::integral_constant<int, 1>{}, As + BUF_R, As, w_at(3 * cg + 5));
+      load_item1(raw1);
+      advance();
+      step(std::integral_constant<int, 2>{}, As + BUF_R, As, w_at(3 * cg + 6));
+    }
+    gc = gn;
+    lc = ln;
+    rc = rn;
+    make_geo(L + 2 * G, gn, ln, rn);
+    ld_next = false;
+
+    // ---- epilogue (conv_w43_kernel's fused-pool tile geometry: M-tile = 2 rows x 64 columns) ----------------------
+    {
+      const int n = (nt * 4 + wn) * 32 + l31;
+      const int nc = n < p.Cout ? n : p.Cout - 1;
+      const float pa = p.pre_a[nc], pb = p.pre_b[nc];
+      const bool has_post = p.post_a != nullptr;
+      const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
+      const bool live = n < p.Cout;
+      auto act = [&](float v) {
+        v = v * pa + pb;
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (has_post) v = v * qa + qb;
+        return v;
+      };
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float m0 = acc[0][m][r], m1 = acc[1][m][r], m2 = acc[2][m][r], m3 = acc[3][m][r], m4 = acc[4][m][r],
+                      m5 = acc[5][m][r];
+          const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+          acc[0][m][r] = act((m0 + s12) + s34);
+          acc[1][m][r] = act(W4_A * d12 + W4_B * d34);
+          acc[2][m][r] = act(W4_A2 * s12 + W4_B2 * s34);
+          acc[3][m][r] = act((W4_A3 * d12 + W4_B3 * d34) + m5);
+        }
+      const int ocs4 = p.out_cs * 4;
+      if (p.amax_out || p.amax_pool) {
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[j][m][r]));
+        mx = live ? mx : 0.f;
+        if (p.amax_out) kocr_amax_update(p.amax_out, mx);
+        if (p.amax_pool) kocr_amax_update(p.amax_pool, mx);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        int y0, x0;
+        const long pm = w4_mtile_pm0<1>(p, tile_mt(mp, m), y0, x0);
+        if (!POOL || p.write_full) {
+          const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (pm * p.out_cs + p.out_co), 0x7FFFFFFFu);
+          const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int px = 4 * ((r & 3) + 8 * (r >> 2));  // quad column (r&3) + 8 (r>>2) [+ 4 l5] of row y
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vo, (px + j) * ocs4, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r + 8]), ro, vo, (px + j + p.W) * ocs4, 0);
+            }
+          }
+        }
+        if constexpr (POOL) {
+          // 2x2 max: rows y (r) and y+1 (r+8), columns (0,1) and (2,3) of the quad
+          const long nimg = pm / ((long)p.H * p.W);
+          const long pp0 = (nimg * (p.H >> 1) + (y0 >> 1)) * (p.W >> 1) + (x0 >> 1);
+          const __amdgpu_buffer_rsrc_t rp = w4_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
+          const unsigned vp = live ? (unsigned)((8 * l5 * p.pool_cs + n) * 4) : OOB;  // 4 quads = 8 pooled px per l5
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int pq = 2 * ((r & 3) + 8 * (r >> 2));
+            const float v0 = fmaxf(fmaxf(acc[0][m][r], acc[1][m][r]), fmaxf(acc[0][m][r + 8], acc[1][m][r + 8]));
+            const float v1 = fmaxf(fmaxf(acc[2][m][r], acc[3][m][r]), fmaxf(acc[2][m][r + 8], acc[3][m][r + 8]));
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * p.pool_cs * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * p.pool_cs * 4, 0);
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -1287,6 +1683,28 @@ static int w4r_launch(kocr_ctx* ctx, W4Params& p) {
   return KOCR_OK;
 }
 
+template <int POOL, int GEO>
+static int w4v_launch(kocr_ctx* ctx, W4Params& p) {
+  constexpr int LDSV = GEO ? 2 * 6 * 3 * 6 * 256 * 2 : 2 * LDS_BYTES;  // 2 x 54 KB / 2 x 72 KB
+  static std::atomic<bool> attr_done[64];
+  const int dev = ctx->device & 63;
+  if (!attr_done[dev]) {
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43v_kernel<POOL, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSV));
+    attr_done[dev] = true;
+  }
+  static std::atomic<int> n_cus[64];
+  if (!n_cus[dev]) {
+    hipDeviceProp_t prop;
+    KOCR_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    n_cus[dev] = prop.multiProcessorCount;
+  }
+  const int n_cu = n_cus[dev];
+  const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
+  hipLaunchKernelGGL((conv_w43v_kernel<POOL, GEO>), dim3(grid), dim3(256), LDSV, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
 int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool, bool need_full) {
   const bool fuse = pool && L.dil == 1 && in.H % 2 == 0 && in.W % 64 == 0;
   const size_t M = in.pixels();
@@ -1329,8 +1747,17 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   static const bool no_rr = getenv("KOCR_W43R") && atoi(getenv("KOCR_W43R")) == 0;
   const bool rowreuse = narrow && !no_rr && L.dil == 1 && in.H % 2 == 0 && in.W % 128 == 0 && (!pool || fuse) &&
                         (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31);
-  if (rowreuse && !fuse) p.tiles_per_row = in.W / 64;  // the 2-row x 64-column M-tile geometry without the pooling
-  p.n_mpairs = rowreuse ? p.total_mtiles / 2 : narrow ? (p.total_mtiles + 3) / 4 : (p.total_mtiles + 1) / 2;
+  // Cout > 64 on the same image geometry: the vertical-reuse arrangement (conv_w43v_kernel)
+  static const bool no_v = getenv("KOCR_W43V") && atoi(getenv("KOCR_W43V")) == 0;
+  // geometry: 4 rows x 64 columns (H % 4 == 0, W % 64 == 0) or 2 rows x 128 columns (H even, W % 128 == 0); KOCR_W43V_GEO
+  // forces one of them where both apply (developer switch)
+  static const int geo_env = getenv("KOCR_W43V_GEO") ? atoi(getenv("KOCR_W43V_GEO")) : -1;
+  const bool v_ok = !narrow && !no_v && L.dil == 1 && (!pool || fuse) && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31);
+  const bool geo1_ok = v_ok && in.H % 4 == 0 && in.W % 64 == 0, geo0_ok = v_ok && in.H % 2 == 0 && in.W % 128 == 0;
+  const int vgeo = (geo1_ok && geo_env != 0) ? 1 : (geo0_ok && geo_env != 1) ? 0 : geo1_ok ? 1 : -1;
+  const bool vreuse = vgeo >= 0;
+  if ((rowreuse || vreuse) && !fuse) p.tiles_per_row = in.W / 64;  // the 2-row x 64-column M-tile geometry without the pooling
+  p.n_mpairs = (rowreuse || vreuse) ? p.total_mtiles / 2 : narrow ? (p.total_mtiles + 3) / 4 : (p.total_mtiles + 1) / 2;
   p.total_tiles = p.n_mpairs * (p.Cout_pad / (narrow ? 64 : 128));
   // Tile order.  The split weights of one cout block are Cin * 3 * 128 * 36 B; with every cout block of a deep layer in
   // flight on an XCD they overflow its 4 MB L2 and are re-streamed from the Infinity Cache by every round of tiles.
@@ -1340,9 +1767,9 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_w4s_%s%s:%s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_w4%s_%s%s:%s", vreuse ? (vgeo ? "v" : "u") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_w4s_%s%s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
+    snprintf(nm, sizeof nm, "conv_w4%s_%s%s", vreuse ? (vgeo ? "v" : "u") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   {
@@ -1370,7 +1797,19 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
       }
     }
 #endif
-    if (rowreuse) {
+    if (vreuse) {
+      if (vgeo == 1) {
+        if (fuse)
+          KOCR_TRY((w4v_launch<1, 1>(ctx, p)));
+        else
+          KOCR_TRY((w4v_launch<0, 1>(ctx, p)));
+      } else {
+        if (fuse)
+          KOCR_TRY((w4v_launch<1, 0>(ctx, p)));
+        else
+          KOCR_TRY((w4v_launch<0, 0>(ctx, p)));
+      }
+    } else if (rowreuse) {
       if (fuse)
         KOCR_TRY(w4r_launch<1>(ctx, p));
       else

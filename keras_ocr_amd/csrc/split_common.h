@@ -38,6 +38,22 @@ __device__ __forceinline__ void kocr_split4(const v4f v, u2v& h, u2v& m, u2v& l)
   l = u2v{__builtin_amdgcn_perm(ul[1], ul[0], 0x07060302u), __builtin_amdgcn_perm(ul[3], ul[2], 0x07060302u)};
 }
 
+// the same for two values: one dword (2 bf16) per piece
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void kocr_split2(const v2f v, unsigned& h, unsigned& m, unsigned& l) {
+  unsigned uh[2], um[2], ul[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    uh[c] = __float_as_uint(v[c]) & 0xFFFF0000u;
+    const float r = v[c] - __uint_as_float(uh[c]);
+    um[c] = __float_as_uint(r) & 0xFFFF0000u;
+    ul[c] = __float_as_uint(r - __uint_as_float(um[c]));
+  }
+  h = __builtin_amdgcn_perm(uh[1], uh[0], 0x07060302u);
+  m = __builtin_amdgcn_perm(um[1], um[0], 0x07060302u);
+  l = __builtin_amdgcn_perm(ul[1], ul[0], 0x07060302u);
+}
+
 // fp16 mode: 2-way RNE fp16 split of four values, v ~ h + l with |v - h - l| <= 2^-22 |v| (2^-24 rms) while l is a
 // normal fp16 (the caller scales the tensor by an exact power of two so that max |v| ~ 2^14)
 __device__ __forceinline__ void kocr_split4_h(const v4f v, u2v& h, u2v& l) {

@@ -63,9 +63,34 @@ struct W4Params {
   int m_fastest;  // tile order: 1 = consecutive tiles share the cout block (weights stay in the XCD's L2)
   unsigned* amax_out;
   unsigned* amax_pool;
+  // exact division of tile indices (< 2^31) by launch constants without the ~40-instruction integer division sequence:
+  // q = (t + ((n - t) >> 1)) >> sh with t = mulhi(n, mul)  (Granlund-Montgomery); [0] = multiplier, [1] = shift
+  unsigned dv_tpr[2];  // by tiles_per_row
+  unsigned dv_hh[2];   // by H / 2
+  unsigned dv_mp[2];   // by n_mpairs
+  unsigned dv_nb[2];   // by the number of cout blocks
 };
 
+// host: multiplier / shift of the division by d (1 <= d < 2^31)
+static inline void w4_div_magic(unsigned d, unsigned (&out)[2]) {
+  if (d <= 1) {
+    out[0] = 0;
+    out[1] = 0;  // q = (0 + (n >> 1)) >> 0 would be wrong: d == 1 is special-cased on the device through sh == 0 && mul == 0
+    return;
+  }
+  unsigned L = 0;
+  while ((1ull << L) < d) ++L;  // ceil(log2 d), >= 1
+  out[0] = (unsigned)(((1ull << 32) * ((1ull << L) - d)) / d + 1);
+  out[1] = L - 1;
+}
+
 namespace {
+
+__device__ __forceinline__ unsigned w4_fdiv(unsigned n, const unsigned (&dv)[2]) {
+  if (dv[0] == 0 && dv[1] == 0) return n;  // d == 1 (wave-uniform)
+  const unsigned t = __umulhi(n, dv[0]);
+  return (t + ((n - t) >> 1)) >> dv[1];
+}
 
 // interpolation points 0, +-a, +-b, inf (all constants exact in fp32)
 constexpr double W4_PA = 0.625, W4_PB = 1.5;
@@ -83,9 +108,9 @@ constexpr int LDS_BYTES = 2 * BUF * 2;       // 72 KB
 template <int POOL>
 __device__ __forceinline__ long w4_mtile_pm0(const W4Params& p, int mt, int& y0, int& x0) {
   if constexpr (POOL) {
-    const int rp_lin = mt / p.tiles_per_row, cb = mt - rp_lin * p.tiles_per_row;
+    const int rp_lin = (int)w4_fdiv((unsigned)mt, p.dv_tpr), cb = mt - rp_lin * p.tiles_per_row;
     const int hh = p.H >> 1;
-    const int nimg = rp_lin / hh, rp = rp_lin - nimg * hh;
+    const int nimg = (int)w4_fdiv((unsigned)rp_lin, p.dv_hh), rp = rp_lin - nimg * hh;
     y0 = 2 * rp;
     x0 = cb * 64;
     return ((long)nimg * p.H + y0) * p.W + x0;
@@ -98,10 +123,10 @@ __device__ __forceinline__ long w4_mtile_pm0(const W4Params& p, int mt, int& y0,
 // tile index -> (pixel tile, cout block)
 __device__ __forceinline__ void w4_decode(const W4Params& p, int tile, int nblk_n, int& mp, int& nt) {
   if (p.m_fastest) {
-    nt = tile / p.n_mpairs;
+    nt = (int)w4_fdiv((unsigned)tile, p.dv_mp);
     mp = tile - nt * p.n_mpairs;
   } else {
-    mp = tile / nblk_n;
+    mp = (int)w4_fdiv((unsigned)tile, p.dv_nb);
     nt = tile - mp * nblk_n;
   }
 }
@@ -388,12 +413,10 @@ __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
       const bool has_post = p.post_a != nullptr;
       const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
       const bool live = n < p.Cout;
-      auto act = [&](float v) {
-        v = v * pa + pb;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (has_post) v = v * qa + qb;
-        return v;
-      };
+      // branch-free epilogue arithmetic: ReLU as a max with 0 or -inf; the CRNN's post-ReLU BatchNorm affine (has_post) runs
+      // as its own pass under a wave-uniform branch instead of a per-element select
+      const float lo = p.relu ? 0.f : -INFINITY;
+      auto act = [&](float v) { return fmaxf(v * pa + pb, lo); };
       // inverse transform + BN + ReLU in place: acc[0..3][m][r] become the quad's four outputs
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -407,7 +430,20 @@ __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
           acc[2][m][r] = act(W4_A2 * s12 + W4_B2 * s34);
           acc[3][m][r] = act((W4_A3 * d12 + W4_B3 * d34) + m5);
         }
-      const int ocs4 = p.out_cs * 4;
+      if (has_post) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][m][r] = acc[j][m][r] * qa + qb;
+      }
+      // the output pixel stride is made opaque per tile: hoisted out of the persistent loop the 128 store offsets would be
+      // kept in (spilled) scalar registers and fetched back with one v_readlane per store
+      int ocs4 = p.out_cs * 4;
+      asm volatile("" : "+s"(ocs4));
+      int pcs4 = p.pool_cs * 4;
+      asm volatile("" : "+s"(pcs4));
       if (p.amax_out || p.amax_pool) {
         float mx = 0.f;
 #pragma unroll
@@ -441,8 +477,8 @@ __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
             }
           }
           // 2x2 max: rows y (r) and y+1 (r+8), columns (0,1) and (2,3) of the quad
-          const long nimg = pm / ((long)p.H * p.W);
-          const long pp0 = (nimg * (p.H >> 1) + (y0 >> 1)) * (p.W >> 1) + (x0 >> 1);
+          // pm = (nimg H + y0) W + x0  ->  pooled pixel (nimg H/2 + y0/2) W/2 + x0/2 = (pm - x0) / 4 ... exactly, H and W even
+          const long pp0 = ((pm - x0) >> 2) + (x0 >> 1);
           const __amdgpu_buffer_rsrc_t rp = w4_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
           const unsigned vp = mlive ? (unsigned)((8 * l5 * p.pool_cs + n) * 4) : OOB;  // 4 quads = 8 pooled px per l5
 #pragma unroll
@@ -450,8 +486,8 @@ __global__ __launch_bounds__(256) void conv_w43_kernel(W4Params p) {
             const int pq = 2 * ((r & 3) + 8 * (r >> 2));
             const float v0 = fmaxf(fmaxf(acc[0][m][r], acc[1][m][r]), fmaxf(acc[0][m][r + 8], acc[1][m][r + 8]));
             const float v1 = fmaxf(fmaxf(acc[2][m][r], acc[3][m][r]), fmaxf(acc[2][m][r + 8], acc[3][m][r + 8]));
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * p.pool_cs * 4, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * p.pool_cs * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * pcs4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * pcs4, 0);
           }
         }
       } else if constexpr (DIL) {
@@ -750,12 +786,10 @@ __global__ __launch_bounds__(256) void conv_w43n_kernel(W4Params p) {
       const bool has_post = p.post_a != nullptr;
       const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
       const bool live = n < p.Cout;
-      auto act = [&](float v) {
-        v = v * pa + pb;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (has_post) v = v * qa + qb;
-        return v;
-      };
+      // branch-free epilogue arithmetic: ReLU as a max with 0 or -inf; the CRNN's post-ReLU BatchNorm affine (has_post) runs
+      // as its own pass under a wave-uniform branch instead of a per-element select
+      const float lo = p.relu ? 0.f : -INFINITY;
+      auto act = [&](float v) { return fmaxf(v * pa + pb, lo); };
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -768,7 +802,20 @@ __global__ __launch_bounds__(256) void conv_w43n_kernel(W4Params p) {
           acc[2][m][r] = act(W4_A2 * s12 + W4_B2 * s34);
           acc[3][m][r] = act((W4_A3 * d12 + W4_B3 * d34) + m5);
         }
-      const int ocs4 = p.out_cs * 4;
+      if (has_post) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][m][r] = acc[j][m][r] * qa + qb;
+      }
+      // the output pixel stride is made opaque per tile: hoisted out of the persistent loop the 128 store offsets would be
+      // kept in (spilled) scalar registers and fetched back with one v_readlane per store
+      int ocs4 = p.out_cs * 4;
+      asm volatile("" : "+s"(ocs4));
+      int pcs4 = p.pool_cs * 4;
+      asm volatile("" : "+s"(pcs4));
       if (p.amax_out || p.amax_pool) {
         float mx = 0.f;
 #pragma unroll
@@ -801,8 +848,8 @@ __global__ __launch_bounds__(256) void conv_w43n_kernel(W4Params p) {
               }
             }
           }
-          const long nimg = pm / ((long)p.H * p.W);
-          const long pp0 = (nimg * (p.H >> 1) + (y0 >> 1)) * (p.W >> 1) + (x0 >> 1);
+          // pm = (nimg H + y0) W + x0  ->  pooled pixel (nimg H/2 + y0/2) W/2 + x0/2 = (pm - x0) / 4 ... exactly, H and W even
+          const long pp0 = ((pm - x0) >> 2) + (x0 >> 1);
           const __amdgpu_buffer_rsrc_t rp = w4_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
           const unsigned vp = mlive ? (unsigned)((8 * l5 * p.pool_cs + n) * 4) : OOB;
 #pragma unroll
@@ -810,8 +857,8 @@ __global__ __launch_bounds__(256) void conv_w43n_kernel(W4Params p) {
             const int pq = 2 * ((r & 3) + 8 * (r >> 2));
             const float v0 = fmaxf(fmaxf(acc[0][m][r], acc[1][m][r]), fmaxf(acc[0][m][r + 8], acc[1][m][r + 8]));
             const float v1 = fmaxf(fmaxf(acc[2][m][r], acc[3][m][r]), fmaxf(acc[2][m][r + 8], acc[3][m][r + 8]));
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * p.pool_cs * 4, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * p.pool_cs * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * pcs4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * pcs4, 0);
           }
         }
       } else {
@@ -854,11 +901,31 @@ __global__ __launch_bounds__(256) void conv_w43n_kernel(W4Params p) {
 //   just released (two block barriers per tile) and finishes M-tile ph itself.
 // POOL = 1: fused 2x2 max-pool (full-resolution store optional); POOL = 0: full-resolution store only.
 // ===================================================================================================
-template <int POOL>
+// input transform of point xi (fp32, fixed operation order; T = v4f or v2f)
+template <class T>
+__device__ __forceinline__ T w4_transform(const T (&d)[6], int xi) {
+  switch (xi) {
+    case 0: return (W4_A2B2 * d[0] - W4_A2PB2 * d[2]) + d[4];
+    case 1: return (d[4] - W4_B2 * d[2]) + W4_A * (d[3] - W4_B2 * d[1]);
+    case 2: return (d[4] - W4_B2 * d[2]) - W4_A * (d[3] - W4_B2 * d[1]);
+    case 3: return (d[4] - W4_A2 * d[2]) + W4_B * (d[3] - W4_A2 * d[1]);
+    case 4: return (d[4] - W4_A2 * d[2]) - W4_B * (d[3] - W4_A2 * d[1]);
+    default: return (W4_A2B2 * d[1] - W4_A2PB2 * d[3]) + d[5];
+  }
+}
+
+// GEO (round 3): 0 = tile of 2 rows x 128 columns as described above; 1 = tile of 4 rows x 64 columns (H % 4 == 0,
+// W % 64 == 0; the two M-tiles stacked): SIX input rows per FOUR output rows, one full gather item + one HALF item (two
+// channels, 8-byte loads) per thread and channel group, 54 KB per buffer -- a quarter less transform / split work again.
+template <int POOL, int GEO>
 __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
-  constexpr int ROW_STRIDE = 2 * KH_STRIDE;     // ushorts per input row of a plane: 2 k halves x 32 quads x 8 channels
-  constexpr int PLANE_R = 4 * ROW_STRIDE;       // one (xi, piece) plane: 4 input rows
-  constexpr int BUF_R = 6 * 3 * PLANE_R;        // one channel group: 72 KB
+  constexpr int NROWS = GEO ? 6 : 4;            // input rows of the tile's window
+  constexpr int QPR = GEO ? 16 : 32;            // quads per tile row
+  constexpr int KHS = QPR * 8;                  // ushorts of one k half of a row
+  constexpr int ROW_STRIDE = 2 * KHS;           // ushorts per input row of a plane
+  constexpr int PLANE_R = NROWS * ROW_STRIDE;   // one (xi, piece) plane
+  constexpr int BUF_R = 6 * 3 * PLANE_R;        // one channel group: 72 KB / 54 KB
+  constexpr int TCOLS = QPR * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned short As[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -869,42 +936,55 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
   const int G = gridDim.x;
   constexpr unsigned OOB = 0x80000000u;
 
-  // ---- producer state: items it = 0, 1: input row (tid >> 7) + 2 it of the 4-row window, quad qd, channel quad q4 ----
-  const int q4 = tid & 3, qd = (tid >> 2) & 31, rh = tid >> 7;
+  // pixel tile mp -> M-tile m in conv_w43_kernel's fused-pool numbering: side by side (GEO 0) or the next row pair (GEO 1)
+  auto tile_mt = [&](int mp, int m) {
+    if constexpr (GEO) {
+      const int rq = (int)w4_fdiv((unsigned)mp, p.dv_tpr), cb = mp - rq * p.tiles_per_row;  // rq: (image, row quad)
+      return (2 * rq + m) * p.tiles_per_row + cb;
+    } else {
+      return 2 * mp + m;
+    }
+  };
+
+  // ---- producer state -----------------------------------------------------------------------------------------
+  // item 0: input row r0 of the window, quad qd0, channel quad q4 (16-byte loads).  item 1: GEO 0: row r0 + 2, same quad
+  // and channels; GEO 1: row 4 + (tid >> 7), quad (tid >> 3) & 15, channel PAIR tid & 7 (8-byte loads).
+  const int q4 = tid & 3, qd0 = (tid >> 2) & (QPR - 1), r0 = GEO ? (tid >> 6) : (tid >> 7);
+  const int cp = tid & 7, qd1 = GEO ? ((tid >> 3) & 15) : qd0, r1 = GEO ? 4 + (tid >> 7) : r0 + 2;
   int ldst[2];
-#pragma unroll
-  for (int it = 0; it < 2; ++it)
-    ldst[it] = (rh + 2 * it) * ROW_STRIDE + (q4 >> 1) * KH_STRIDE + (((qd * 8) ^ ((q4 >> 1) * 32)) + (q4 & 1) * 4);
+  ldst[0] = r0 * ROW_STRIDE + (q4 >> 1) * KHS + (((qd0 * 8) ^ ((q4 >> 1) * 32)) + (q4 & 1) * 4);
+  if constexpr (GEO)
+    ldst[1] = r1 * ROW_STRIDE + (cp >> 2) * KHS + (((qd1 * 8) ^ ((cp >> 2) * 32)) + (cp & 3) * 2);
+  else
+    ldst[1] = r1 * ROW_STRIDE + (q4 >> 1) * KHS + (((qd1 * 8) ^ ((q4 >> 1) * 32)) + (q4 & 1) * 4);
   struct Geo {
     unsigned off0[2];  // byte offset of raw pixel d0 of each item
     unsigned ok;       // bit it: the item's input row lies inside the image (and the tile exists)
     const float* base;
   };
-  const bool lpad = qd == 0;  // d0 / d5 are column zero padding only at the image edges: W % 128 == 0, tiles_per_row even
   auto make_geo = [&](int L, Geo& g, bool& left, bool& right) __attribute__((always_inline)) {
     const int mp = kocr_xcd_remap(L < total ? L : 0, total);
     int y0, x0;
-    const long pm = w4_mtile_pm0<1>(p, 2 * mp, y0, x0);
+    const long pm = w4_mtile_pm0<1>(p, tile_mt(mp, 0), y0, x0);
     g.base = p.in + (pm * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
-    g.ok = 0;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int row = rh + 2 * it;  // input row y0 - 1 + row
-      g.off0[it] = (unsigned)(((row * p.W + 4 * qd) * p.in_cs + q4 * 4) * 4);
-      g.ok |= ((L < total && (unsigned)(y0 - 1 + row) < (unsigned)p.H) ? 1u : 0u) << it;
-    }
-    left = lpad && x0 == 0;
-    right = qd == 31 && x0 + 128 >= p.W;
+    g.off0[0] = (unsigned)(((r0 * p.W + 4 * qd0) * p.in_cs + q4 * 4) * 4);
+    g.off0[1] = (unsigned)(((r1 * p.W + 4 * qd1) * p.in_cs + (GEO ? cp * 2 : q4 * 4)) * 4);
+    g.ok = ((L < total && (unsigned)(y0 - 1 + r0) < (unsigned)p.H) ? 1u : 0u) |
+           ((L < total && (unsigned)(y0 - 1 + r1) < (unsigned)p.H) ? 2u : 0u);
+    // d0 / d5 are column zero padding only at the image edges (W is a multiple of the tile width)
+    left = x0 == 0;
+    right = x0 + TCOLS >= p.W;
   };
   Geo gc, gn;
   bool lc, rc, ln, rn;
   int ld_cg = 0;  // channel group of the NEXT load inside its tile
   bool ld_next = false;
-  auto load_item = [&](v4f (&raw)[6], int it) __attribute__((always_inline)) {
+  typedef typename std::conditional<GEO != 0, v2f, v4f>::type raw1_t;
+  auto load_item0 = [&](v4f (&raw)[6]) __attribute__((always_inline)) {
     const int soff = ld_cg * 64;
-    const bool ok = ((ld_next ? gn.ok : gc.ok) >> it) & 1u;
-    const unsigned off0 = (ld_next ? gn.off0[it] : gc.off0[it]) | (ok ? 0u : OOB);
-    const bool left = ld_next ? ln : lc, right = ld_next ? rn : rc;
+    const bool ok = (ld_next ? gn.ok : gc.ok) & 1u;
+    const unsigned off0 = (ld_next ? gn.off0[0] : gc.off0[0]) | (ok ? 0u : OOB);
+    const bool left = (ld_next ? ln : lc) && qd0 == 0, right = (ld_next ? rn : rc) && qd0 == QPR - 1;
     const unsigned stride = (unsigned)(p.in_cs * 4);
     const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
 #pragma unroll
@@ -913,27 +993,52 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
       raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (off0 + k * stride) | padk, soff, 0));
     }
   };
+  auto load_item1 = [&](raw1_t (&raw)[6]) __attribute__((always_inline)) {
+    const int soff = ld_cg * 64;
+    const bool ok = ((ld_next ? gn.ok : gc.ok) >> 1) & 1u;
+    const unsigned off0 = (ld_next ? gn.off0[1] : gc.off0[1]) | (ok ? 0u : OOB);
+    const bool left = (ld_next ? ln : lc) && qd1 == 0, right = (ld_next ? rn : rc) && qd1 == QPR - 1;
+    const unsigned stride = (unsigned)(p.in_cs * 4);
+    const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const unsigned padk = (k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u);
+      if constexpr (GEO)
+        raw[k] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (off0 + k * stride) | padk, soff, 0));
+      else
+        raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (off0 + k * stride) | padk, soff, 0));
+    }
+  };
   auto advance = [&]() __attribute__((always_inline)) {
     const bool wrap = ld_cg == ncg - 1;
     ld_cg = wrap ? 0 : ld_cg + 1;
     ld_next = ld_next || wrap;
   };
-  auto produce_point = [&](const v4f (&d)[6], unsigned short* bufp, int xi, int it) __attribute__((always_inline)) {
-    v4f V;
-    switch (xi) {
-      case 0: V = (W4_A2B2 * d[0] - W4_A2PB2 * d[2]) + d[4]; break;
-      case 1: V = (d[4] - W4_B2 * d[2]) + W4_A * (d[3] - W4_B2 * d[1]); break;
-      case 2: V = (d[4] - W4_B2 * d[2]) - W4_A * (d[3] - W4_B2 * d[1]); break;
-      case 3: V = (d[4] - W4_A2 * d[2]) + W4_B * (d[3] - W4_A2 * d[1]); break;
-      case 4: V = (d[4] - W4_A2 * d[2]) - W4_B * (d[3] - W4_A2 * d[1]); break;
-      default: V = (W4_A2B2 * d[1] - W4_A2PB2 * d[3]) + d[5]; break;
-    }
+  auto produce4 = [&](const v4f (&d)[6], unsigned short* bufp, int xi, int it) __attribute__((always_inline)) {
+    const v4f V = w4_transform(d, xi);
     u2v h, m, l;
     kocr_split4(V, h, m, l);
     unsigned short* dst = bufp + xi * 3 * PLANE_R + ldst[it];
     *reinterpret_cast<u2v*>(dst) = h;
     *reinterpret_cast<u2v*>(dst + PLANE_R) = m;
     *reinterpret_cast<u2v*>(dst + 2 * PLANE_R) = l;
+  };
+  auto produce2 = [&](const v2f (&d)[6], unsigned short* bufp, int xi) __attribute__((always_inline)) {
+    const v2f V = w4_transform(d, xi);
+    unsigned h, m, l;
+    kocr_split2(V, h, m, l);
+    unsigned short* dst = bufp + xi * 3 * PLANE_R + ldst[1];
+    *reinterpret_cast<unsigned*>(dst) = h;
+    *reinterpret_cast<unsigned*>(dst + PLANE_R) = m;
+    *reinterpret_cast<unsigned*>(dst + 2 * PLANE_R) = l;
+  };
+  v4f raw0[6];
+  raw1_t raw1[6];
+  auto produce_item1 = [&](unsigned short* bufp, int xi) __attribute__((always_inline)) {
+    if constexpr (GEO)
+      produce2(raw1, bufp, xi);
+    else
+      produce4(raw1, bufp, xi, 1);
   };
 
   // ---- consumer state ------------------------------------------------------------------------------------------
@@ -942,15 +1047,15 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
   const int ns = 3 * ncg;
   bf8 bw[3][3];
   f16v acc[3][2];  // [point of this wave's half][M-tile]
-  // M row l31 of M-tile m: image row (l31 >> 4) [+ ky], quad 16 m + (l31 & 15) (= + 128 ushorts: bit 7, clear of the
-  // swizzle's bit 5), k half l5
-  const int a_lane = (l31 >> 4) * ROW_STRIDE + l5 * KH_STRIDE + (((l31 & 15) * 8) ^ (l5 * 32));
+  // M row l31 of M-tile m: window row (l31 >> 4) + ky [+ 2 m: GEO 1], quad (l31 & 15) [+ 16 m: GEO 0], k half l5
+  const int a_lane = (l31 >> 4) * ROW_STRIDE + l5 * KHS + (((l31 & 15) * 8) ^ (l5 * 32));
+  constexpr int M_OFF = GEO ? 2 * ROW_STRIDE : 128;  // M-tile 1: two rows down / 16 quads to the right
   auto load_a = [&](bf8 (&a)[2][3], const unsigned short* bufp, int ky, int pl) __attribute__((always_inline)) {
     const unsigned short* base = bufp + a_lane + ky * ROW_STRIDE + (3 * ph + pl) * 3 * PLANE_R;
 #pragma unroll
     for (int s = 2; s >= 0; --s)
 #pragma unroll
-      for (int m = 0; m < 2; ++m) a[m][s] = *reinterpret_cast<const bf8*>(base + s * PLANE_R + m * 128);
+      for (int m = 0; m < 2; ++m) a[m][s] = *reinterpret_cast<const bf8*>(base + s * PLANE_R + m * M_OFF);
   };
   auto mfma12 = [&](const bf8 (&a)[2][3], int pl) __attribute__((always_inline)) {
     const bf8 b0 = bw[pl][0], b1 = bw[pl][1], b2 = bw[pl][2];
@@ -973,7 +1078,6 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
   // at once with the channel group after next, item 1 after group 8).  s0 = index of this channel group's first weight
   // step; the weights of step s0 + ky + 1 replace those of (s0 + ky) point pair by point pair.  a0 (flip = 0) /
   // a1 (flip = 1) holds group 0 on entry, the other one the next channel group's group 0 on exit.
-  v4f raw0[6], raw1[6];
   bf8 a0[2][3], a1[2][3];
   auto phase = [&](const unsigned short* bufc, unsigned short* bufn, int s0, int flip) __attribute__((always_inline)) {
 #pragma unroll
@@ -989,27 +1093,34 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
 #pragma unroll
       for (int c = c0; c < c0 + nchunks; ++c) {
         if (c < 6)
-          produce_point(raw0, bufn, c, 0);
+          produce4(raw0, bufn, c, 0);
         else
-          produce_point(raw1, bufn, c - 6, 1);
+          produce_item1(bufn, c - 6);
       }
       if (g < 8) {
         mfma12(cur, pp);
         __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);  // the LDS fetches of the next group first
-        if (g % 3 == 0) {  // two chunks: 1 MFMA : 5 VALU
+        // VALU per MFMA: two full chunks 5, one full chunk 3, (GEO 1) two half chunks 3, one half chunk 2
+        auto ilv = [&](auto v_c, auto st_c) __attribute__((always_inline)) {
+          constexpr int V = decltype(v_c)::value, ST = decltype(st_c)::value;
 #pragma unroll
           for (int i = 0; i < 11; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
           }
-          __builtin_amdgcn_sched_group_barrier(0x200, 6, 0);
-        } else {  // one chunk: 1 MFMA : 3 VALU
-#pragma unroll
-          for (int i = 0; i < 11; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, ST, 0);
+        };
+        const bool half = GEO && c0 >= 6;
+        if (nchunks == 2) {
+          if (half)
+            ilv(std::integral_constant<int, 3>{}, std::integral_constant<int, 6>{});
+          else
+            ilv(std::integral_constant<int, 5>{}, std::integral_constant<int, 6>{});
+        } else {
+          if (half)
+            ilv(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{});
+          else
+            ilv(std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       } else {
@@ -1026,17 +1137,17 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) bw[pp][s] = *reinterpret_cast<const bf8*>(wq + (size_t)((3 * ph + pp) * 3 + s) * 64 * 8);
       }
-      if (g == 3) load_item(raw0, 0);
+      if (g == 3) load_item0(raw0);
     }
-    load_item(raw1, 1);
+    load_item1(raw1);
     advance();
   };
 
   // ---- prologue ------------------------------------------------------------------------------------------------
   make_geo(blockIdx.x, gc, lc, rc);
   make_geo(blockIdx.x + G, gn, ln, rn);
-  load_item(raw0, 0);
-  load_item(raw1, 1);
+  load_item0(raw0);
+  load_item1(raw1);
   advance();  // channel group 0 loaded
 #pragma unroll
   for (int pl = 0; pl < 3; ++pl)
@@ -1044,11 +1155,11 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
     for (int s = 0; s < 3; ++s) bw[pl][s] = *reinterpret_cast<const bf8*>(w_ptr + (size_t)((3 * ph + pl) * 3 + s) * 64 * 8);
 #pragma unroll
   for (int xi = 0; xi < 6; ++xi) {
-    produce_point(raw0, As, xi, 0);
-    produce_point(raw1, As, xi, 1);
+    produce4(raw0, As, xi, 0);
+    produce_item1(As, xi);
   }
-  load_item(raw0, 0);
-  load_item(raw1, 1);
+  load_item0(raw0);
+  load_item1(raw1);
   advance();  // channel group 1 loaded
   __syncthreads();
   load_a(a0, As, 0, 0);
@@ -1080,12 +1191,10 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
       const bool has_post = p.post_a != nullptr;
       const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
       const bool live = n < p.Cout;
-      auto act = [&](float v) {
-        v = v * pa + pb;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (has_post) v = v * qa + qb;
-        return v;
-      };
+      // branch-free epilogue arithmetic: ReLU as a max with 0 or -inf; the CRNN's post-ReLU BatchNorm affine (has_post) runs
+      // as its own pass under a wave-uniform branch instead of a per-element select
+      const float lo = p.relu ? 0.f : -INFINITY;
+      auto act = [&](float v) { return fmaxf(v * pa + pb, lo); };
       // The output transform is linear in the six points: every wave forms the partial outputs of BOTH M-tiles from its
       // three points, hands the partials of the partner's M-tile (1 - ph) over through the LDS buffer the K loop has just
       // released (16 KB per wave: [wave][r][lane] float4, the partner = wave ^ 2 has the same lane <-> (quad, cout) map)
@@ -1137,11 +1246,19 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) out[j][r] = act(out[j][r] + q[j]);
       }
+      if (has_post) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) out[j][r] = out[j][r] * qa + qb;
+      }
       __syncthreads();  // the next channel group is transformed into this buffer
-      const int ocs4 = p.out_cs * 4;
-      const int mt = 2 * mp + ph;
+      int ocs4 = p.out_cs * 4;
+      asm volatile("" : "+s"(ocs4));
+      int pcs4 = p.pool_cs * 4;
+      asm volatile("" : "+s"(pcs4));
       int y0, x0;
-      const long pm = w4_mtile_pm0<1>(p, mt, y0, x0);
+      const long pm = w4_mtile_pm0<1>(p, tile_mt(mp, ph), y0, x0);
       if (!POOL || p.write_full) {
         const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (pm * p.out_cs + p.out_co), 0x7FFFFFFFu);
         const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
@@ -1157,8 +1274,7 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
       }
       if constexpr (POOL) {
         // 2x2 max: rows y0 (r) and y0 + 1 (r + 8), columns (0,1) and (2,3) of the quad
-        const long nimg = pm / ((long)p.H * p.W);
-        const long pp0 = (nimg * (p.H >> 1) + (y0 >> 1)) * (p.W >> 1) + (x0 >> 1);
+        const long pp0 = ((pm - x0) >> 2) + (x0 >> 1);  // (nimg H/2 + y0/2) W/2 + x0/2: H, W even
         const __amdgpu_buffer_rsrc_t rp = w4_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
         const unsigned vp = live ? (unsigned)((8 * l5 * p.pool_cs + n) * 4) : OOB;  // 4 quads = 8 pooled px per l5
 #pragma unroll
@@ -1166,8 +1282,8 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
           const int pq = 2 * ((r & 3) + 8 * (r >> 2));
           const float v0 = fmaxf(fmaxf(out[0][r], out[1][r]), fmaxf(out[0][r + 8], out[1][r + 8]));
           const float v1 = fmaxf(fmaxf(out[2][r], out[3][r]), fmaxf(out[2][r + 8], out[3][r + 8]));
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * p.pool_cs * 4, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * p.pool_cs * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * pcs4, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * pcs4, 0);
         }
       }
     }
@@ -1192,19 +1308,6 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
 // Needs Cin % 32 == 0, dilation 1 and H even, W % 128 == 0 (GEO 0) / H % 4 == 0, W % 64 == 0 (GEO 1).
 // POOL = 1: fused 2x2 max-pool (full-resolution store optional).
 // ===================================================================================================
-// input transform of point xi (fp32, fixed operation order; T = v4f or v2f)
-template <class T>
-__device__ __forceinline__ T w4_transform(const T (&d)[6], int xi) {
-  switch (xi) {
-    case 0: return (W4_A2B2 * d[0] - W4_A2PB2 * d[2]) + d[4];
-    case 1: return (d[4] - W4_B2 * d[2]) + W4_A * (d[3] - W4_B2 * d[1]);
-    case 2: return (d[4] - W4_B2 * d[2]) - W4_A * (d[3] - W4_B2 * d[1]);
-    case 3: return (d[4] - W4_A2 * d[2]) + W4_B * (d[3] - W4_A2 * d[1]);
-    case 4: return (d[4] - W4_A2 * d[2]) - W4_B * (d[3] - W4_A2 * d[1]);
-    default: return (W4_A2B2 * d[1] - W4_A2PB2 * d[3]) + d[5];
-  }
-}
-
 template <int POOL, int GEO>
 __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
   constexpr int NROWS = GEO ? 6 : 4;            // input rows of the tile's window
@@ -1229,7 +1332,7 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
   // the M-tile after it: side by side (GEO 0) or the next row pair (GEO 1)
   auto tile_mt = [&](int mp, int m) {
     if constexpr (GEO) {
-      const int rq = mp / p.tiles_per_row, cb = mp - rq * p.tiles_per_row;  // rq: (image, row quad)
+      const int rq = (int)w4_fdiv((unsigned)mp, p.dv_tpr), cb = mp - rq * p.tiles_per_row;  // rq: (image, row quad)
       return (2 * rq + m) * p.tiles_per_row + cb;
     } else {
       return 2 * mp + m;
@@ -1502,12 +1605,10 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
       const bool has_post = p.post_a != nullptr;
       const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
       const bool live = n < p.Cout;
-      auto act = [&](float v) {
-        v = v * pa + pb;
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (has_post) v = v * qa + qb;
-        return v;
-      };
+      // branch-free epilogue arithmetic: ReLU as a max with 0 or -inf; the CRNN's post-ReLU BatchNorm affine (has_post) runs
+      // as its own pass under a wave-uniform branch instead of a per-element select
+      const float lo = p.relu ? 0.f : -INFINITY;
+      auto act = [&](float v) { return fmaxf(v * pa + pb, lo); };
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1520,7 +1621,20 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
           acc[2][m][r] = act(W4_A2 * s12 + W4_B2 * s34);
           acc[3][m][r] = act((W4_A3 * d12 + W4_B3 * d34) + m5);
         }
-      const int ocs4 = p.out_cs * 4;
+      if (has_post) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][m][r] = acc[j][m][r] * qa + qb;
+      }
+      // the output pixel stride is made opaque per tile: hoisted out of the persistent loop the 128 store offsets would be
+      // kept in (spilled) scalar registers and fetched back with one v_readlane per store
+      int ocs4 = p.out_cs * 4;
+      asm volatile("" : "+s"(ocs4));
+      int pcs4 = p.pool_cs * 4;
+      asm volatile("" : "+s"(pcs4));
       if (p.amax_out || p.amax_pool) {
         float mx = 0.f;
 #pragma unroll
@@ -1552,8 +1666,8 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
         }
         if constexpr (POOL) {
           // 2x2 max: rows y (r) and y+1 (r+8), columns (0,1) and (2,3) of the quad
-          const long nimg = pm / ((long)p.H * p.W);
-          const long pp0 = (nimg * (p.H >> 1) + (y0 >> 1)) * (p.W >> 1) + (x0 >> 1);
+          // pm = (nimg H + y0) W + x0  ->  pooled pixel (nimg H/2 + y0/2) W/2 + x0/2 = (pm - x0) / 4 ... exactly, H and W even
+          const long pp0 = ((pm - x0) >> 2) + (x0 >> 1);
           const __amdgpu_buffer_rsrc_t rp = w4_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
           const unsigned vp = live ? (unsigned)((8 * l5 * p.pool_cs + n) * 4) : OOB;  // 4 quads = 8 pooled px per l5
 #pragma unroll
@@ -1561,8 +1675,8 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
             const int pq = 2 * ((r & 3) + 8 * (r >> 2));
             const float v0 = fmaxf(fmaxf(acc[0][m][r], acc[1][m][r]), fmaxf(acc[0][m][r + 8], acc[1][m][r + 8]));
             const float v1 = fmaxf(fmaxf(acc[2][m][r], acc[3][m][r]), fmaxf(acc[2][m][r + 8], acc[3][m][r + 8]));
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * p.pool_cs * 4, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * p.pool_cs * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * pcs4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * pcs4, 0);
           }
         }
       }
@@ -1661,13 +1775,14 @@ static int w4n_launch(kocr_ctx* ctx, W4Params& p) {
   return KOCR_OK;
 }
 
-template <int POOL>
+template <int POOL, int GEO>
 static int w4r_launch(kocr_ctx* ctx, W4Params& p) {
-  constexpr int LDSR = 2 * LDS_BYTES;  // 2 x 72 KB
+  // 2 x 72 KB, or 54 KB + the epilogue's 64 KB exchange area (which starts at the second 54 KB buffer)
+  constexpr int LDSR = GEO ? 6 * 3 * 6 * 256 * 2 + 4 * 16 * 64 * 16 : 2 * LDS_BYTES;
   static std::atomic<bool> attr_done[64];
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
-    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43r_kernel<POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSR));
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43r_kernel<POOL, GEO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSR));
     attr_done[dev] = true;
   }
   static std::atomic<int> n_cus[64];
@@ -1678,7 +1793,7 @@ static int w4r_launch(kocr_ctx* ctx, W4Params& p) {
   }
   const int n_cu = n_cus[dev];
   const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
-  hipLaunchKernelGGL((conv_w43r_kernel<POOL>), dim3(grid), dim3(256), LDSR, ctx->stream, p);
+  hipLaunchKernelGGL((conv_w43r_kernel<POOL, GEO>), dim3(grid), dim3(256), LDSR, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }
@@ -1745,13 +1860,15 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   const bool narrow = L.w4_cout_pad == 64;  // 64-cout arrangement: 4 M-tiles x 64 couts per tile
   // ... or, when the image tiles as 2 rows x 128 columns, the row-reuse arrangement (2 M-tiles of 2 rows x 64 columns)
   static const bool no_rr = getenv("KOCR_W43R") && atoi(getenv("KOCR_W43R")) == 0;
-  const bool rowreuse = narrow && !no_rr && L.dil == 1 && in.H % 2 == 0 && in.W % 128 == 0 && (!pool || fuse) &&
-                        (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31);
+  static const int geo_env = getenv("KOCR_W43V_GEO") ? atoi(getenv("KOCR_W43V_GEO")) : -1;  // developer switch: force a geometry
+  const bool r_ok = narrow && !no_rr && L.dil == 1 && (!pool || fuse) && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31);
+  const bool rgeo1_ok = r_ok && in.H % 4 == 0 && in.W % 64 == 0, rgeo0_ok = r_ok && in.H % 2 == 0 && in.W % 128 == 0;
+  const int rgeo = (rgeo1_ok && geo_env != 0) ? 1 : (rgeo0_ok && geo_env != 1) ? 0 : rgeo1_ok ? 1 : -1;
+  const bool rowreuse = rgeo >= 0;
   // Cout > 64 on the same image geometry: the vertical-reuse arrangement (conv_w43v_kernel)
   static const bool no_v = getenv("KOCR_W43V") && atoi(getenv("KOCR_W43V")) == 0;
   // geometry: 4 rows x 64 columns (H % 4 == 0, W % 64 == 0) or 2 rows x 128 columns (H even, W % 128 == 0); KOCR_W43V_GEO
   // forces one of them where both apply (developer switch)
-  static const int geo_env = getenv("KOCR_W43V_GEO") ? atoi(getenv("KOCR_W43V_GEO")) : -1;
   const bool v_ok = !narrow && !no_v && L.dil == 1 && (!pool || fuse) && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31);
   const bool geo1_ok = v_ok && in.H % 4 == 0 && in.W % 64 == 0, geo0_ok = v_ok && in.H % 2 == 0 && in.W % 128 == 0;
   const int vgeo = (geo1_ok && geo_env != 0) ? 1 : (geo0_ok && geo_env != 1) ? 0 : geo1_ok ? 1 : -1;
@@ -1759,6 +1876,10 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   if ((rowreuse || vreuse) && !fuse) p.tiles_per_row = in.W / 64;  // the 2-row x 64-column M-tile geometry without the pooling
   p.n_mpairs = (rowreuse || vreuse) ? p.total_mtiles / 2 : narrow ? (p.total_mtiles + 3) / 4 : (p.total_mtiles + 1) / 2;
   p.total_tiles = p.n_mpairs * (p.Cout_pad / (narrow ? 64 : 128));
+  w4_div_magic((unsigned)p.tiles_per_row, p.dv_tpr);
+  w4_div_magic((unsigned)(in.H / 2), p.dv_hh);
+  w4_div_magic((unsigned)p.n_mpairs, p.dv_mp);
+  w4_div_magic((unsigned)(p.Cout_pad / (narrow ? 64 : 128)), p.dv_nb);
   // Tile order.  The split weights of one cout block are Cin * 3 * 128 * 36 B; with every cout block of a deep layer in
   // flight on an XCD they overflow its 4 MB L2 and are re-streamed from the Infinity Cache by every round of tiles.
   // Pixel-tile-fastest order keeps ONE cout block per XCD at a time (measured +4 % on 512 -> 512, neutral below).
@@ -1810,10 +1931,17 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
           KOCR_TRY((w4v_launch<0, 0>(ctx, p)));
       }
     } else if (rowreuse) {
-      if (fuse)
-        KOCR_TRY(w4r_launch<1>(ctx, p));
-      else
-        KOCR_TRY(w4r_launch<0>(ctx, p));
+      if (rgeo == 1) {
+        if (fuse)
+          KOCR_TRY((w4r_launch<1, 1>(ctx, p)));
+        else
+          KOCR_TRY((w4r_launch<0, 1>(ctx, p)));
+      } else {
+        if (fuse)
+          KOCR_TRY((w4r_launch<1, 0>(ctx, p)));
+        else
+          KOCR_TRY((w4r_launch<0, 0>(ctx, p)));
+      }
     } else if (narrow) {
       if (fuse)
         KOCR_TRY(w4n_launch<1>(ctx, p));

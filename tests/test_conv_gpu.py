@@ -118,10 +118,13 @@ SPLIT_CASES = [
     # (2, 64, 128, 64, 64) above takes it too
     (1, 17, 36, 32, 48),      # ragged couts, odd height, last tile mostly outside
     (2, 40, 128, 128, 64),    # upconv3.conv.3 class
-    # 32 < Cout <= 64 on images that tile as 2 rows x 128 columns: the row-reuse arrangement (conv_w43r_kernel)
-    (1, 6, 128, 32, 48),      # two channel groups, one tile per row pair, ragged couts
-    (2, 8, 256, 64, 64),      # slice1.3 class: four channel groups, two tiles per row pair, two images
-    (1, 4, 384, 96, 40),      # six channel groups, three tiles per row pair
+    # 32 < Cout <= 64 on images that tile as 4 rows x 64 columns / 2 rows x 128 columns: the row-reuse arrangement
+    # (conv_w43r_kernel, both geometries; (2, 64, 128, 64, 64) and (2, 40, 128, 128, 64) above take 4 x 64)
+    (1, 6, 128, 32, 48),      # 2 x 128 (H % 4 != 0): two channel groups, one tile per row pair, ragged couts
+    (2, 8, 256, 64, 64),      # 4 x 64: slice1.3 class, four channel groups, four tiles per row quad, two images
+    (1, 4, 384, 96, 40),      # 4 x 64: six channel groups, one row quad
+    (2, 10, 256, 64, 64),     # 2 x 128: two tiles per row pair, two images
+    (3, 12, 64, 32, 33),      # 4 x 64: one tile per row quad, one live column in the second cout half
     # Cout > 64 on images that tile as 4 rows x 64 columns or 2 rows x 128 columns: the vertical-reuse arrangement
     # (conv_w43v_kernel); (1, 96, 192, 256, 256) and (1, 64, 128, 128, 256) above take it too (4 x 64)
     (2, 8, 256, 64, 128),     # 4 x 64: slice1.7 class, four channel groups, four tiles per row quad, two images

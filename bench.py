@@ -140,20 +140,27 @@ def parity_pages(ctx, craft_w, crnn_w, pages, gpu_out, page0_oracle, page0_heat)
         big = ctx.resize_pad(pages[i][None], (pages[i].shape[1] * SCALE, pages[i].shape[0] * SCALE))
         h_gpu = ctx.craft_forward(big)[0]
         r = parity_of(gpu_out[i], want, flips(h_gpu, h_ref), page=i)
+        # the calibrated random-init head scales its two output channels by ~1e4-1e6 (weights.calibrate_craft_head), so the
+        # heat-map error is judged relative to the map's magnitude: 2e-4 absolute on maps of magnitude <= ~3 in the tests
         r["heat_max_abs_err"] = float(np.abs(h_gpu - h_ref).max())
+        r["heat_max_abs"] = float(np.abs(h_ref).max())
+        r["heat_rel_err"] = r["heat_max_abs_err"] / max(1.0, r["heat_max_abs"])
         r.pop("note")
         per_page.append(r)
-        ok = ok and r["ok"] and r["heat_max_abs_err"] <= 2e-4
+        ok = ok and r["ok"] and r["heat_rel_err"] <= 5e-5
     return {"pages": [r["page"] for r in per_page], "ok": bool(ok),
             "words_gpu": sum(r["words_gpu"] for r in per_page), "words_oracle": sum(r["words_oracle"] for r in per_page),
             "strings_equal": all(r["strings_equal"] for r in per_page),
             "boxes_max_abs_diff_px": max([r["boxes_max_abs_diff_px"] for r in per_page if r["boxes_max_abs_diff_px"] is not None],
                                          default=None),
             "heat_max_abs_err": max(r["heat_max_abs_err"] for r in per_page),
+            "heat_max_abs": max(r["heat_max_abs"] for r in per_page),
+            "heat_rel_err": max(r["heat_rel_err"] for r in per_page),
             "flipped_threshold_pixels": sum(r["flipped_threshold_pixels"] for r in per_page),
             "per_page": per_page,
             "note": "oracle = oracle/ (CPU restatement of the reference path); strings exact, boxes to 1e-3 px, heat-maps to "
-                    "2e-4; a missing / extra box is accepted only next to a heat-map pixel that lies on the other side of a "
+                    "5e-5 of their magnitude (the calibrated random-init head scales them by ~1e5; the tests hold 2e-4 absolute "
+                    "on maps of magnitude ~3); a missing / extra box is accepted only next to a heat-map pixel that lies on the other side of a "
                     "getBoxes threshold (counted: flipped_threshold_pixels)"}
 
 

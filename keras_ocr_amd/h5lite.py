@@ -47,7 +47,7 @@ class _File:
 
     # ---- object headers ------------------------------------------------------------------------
     def messages(self, addr):
-        """version-1 object header at `addr` -> list of (type, payload bytes), continuations followed"""
+        """version-1 object header at `addr` -> list of (type, payload bytes, flags), continuations followed"""
         a = addr + self.base
         if self.b[a] != 1:
             if self.b[a:a + 4] == b"OHDR":
@@ -57,16 +57,22 @@ class _File:
         size = self.u(a + 8, 4)
         blocks = [(a + 16, size)]  # 12-byte prefix padded to 8-byte alignment
         out = []
-        while blocks and len(out) < n_msgs:
+        # every block is read to its end: the header's message count also counts NIL padding messages, and a
+        # continuation block may be listed by the very last message the count allows
+        while blocks:
             p, left = blocks.pop(0)
             end = p + left
-            while p + 8 <= end and len(out) < n_msgs:
-                mtype, msize = self.u(p, 2), self.u(p + 2, 2)
+            if end > len(self.b):
+                raise ValueError("object header block runs past the end of the file")
+            while p + 8 <= end:
+                mtype, msize, flags = self.u(p, 2), self.u(p + 2, 2), self.b[p + 4]
                 body = self.b[p + 8:p + 8 + msize]
                 p += 8 + msize
                 if mtype == 0x0010:  # continuation: offset, length
                     blocks.append((int.from_bytes(body[:8], "little") + self.base, int.from_bytes(body[8:16], "little")))
-                out.append((mtype, body))
+                out.append((mtype, body, flags))
+            if len(out) > 4 * max(n_msgs, 16):
+                raise ValueError("object header lists far more messages than it declares (corrupt continuation chain?)")
         return out
 
     # ---- groups --------------------------------------------------------------------------------
@@ -133,7 +139,10 @@ class _File:
     def dataset(self, msgs):
         shape = dtype = None
         raw = None
-        for mtype, body in msgs:
+        for mtype, body, flags in msgs:
+            if mtype in (0x0001, 0x0003, 0x0008) and (flags & 0x02):
+                # the message body is a reference to a shared / committed message, not the message itself
+                raise NotImplementedError("shared (committed) dataspace / datatype / layout messages are not supported")
             if mtype == 0x0001:
                 shape = self._shape(body)
             elif mtype == 0x0003:
@@ -165,8 +174,12 @@ class _File:
                         raise NotImplementedError("chunked dataset layout")
                 else:
                     raise NotImplementedError(f"data layout message version {ver}")
-        if shape is None or dtype is None or raw is None:
-            return None
+        have = [shape is not None, dtype is not None, raw is not None]
+        if not any(have):
+            return None  # not a dataset (e.g. an empty group without a symbol table)
+        if not all(have):
+            missing = [n for n, h in zip(("dataspace", "datatype", "data layout"), have) if not h]
+            raise NotImplementedError(f"dataset object without a readable {' / '.join(missing)} message")
         count = int(np.prod(shape)) if shape else 1
         if isinstance(raw, tuple):
             a = raw[1] + self.base
@@ -179,15 +192,18 @@ class _File:
         if depth > 32:
             raise ValueError("group nesting too deep (cycle?)")
         msgs = self.messages(header_addr)
-        stab = [body for mtype, body in msgs if mtype == 0x0011]
+        stab = [body for mtype, body, _ in msgs if mtype == 0x0011]
         if stab:
             btree, heap = int.from_bytes(stab[0][:8], "little"), int.from_bytes(stab[0][8:16], "little")
             for name, child in self.btree_entries(btree, heap):
                 self.walk(child, f"{prefix}/{name}" if prefix else name, out, depth + 1)
             return
-        if any(mtype in (0x0002, 0x0006) for mtype, _ in msgs):
+        if any(mtype in (0x0002, 0x0006) for mtype, _, _ in msgs):
             raise NotImplementedError("new-style (link message) groups are not supported")
-        arr = self.dataset(msgs)
+        try:
+            arr = self.dataset(msgs)
+        except NotImplementedError as e:
+            raise NotImplementedError(f"{prefix}: {e}") from None
         if arr is not None:
             out[prefix] = arr
 

@@ -172,7 +172,8 @@ def read_keras_h5(path, kind):
     Dataset paths look like ``conv_1/conv_1/kernel:0`` or ``lstm_10/lstm_10/lstm_cell_3/recurrent_kernel:0``: first
     component = layer, last = variable."""
     out = {}
-    for name, arr in _h5_datasets(path).items():
+    stn_group, stn_src = None, {}
+    for name, arr in sorted(_h5_datasets(path).items()):
         parts = name.split("/")
         layer, var = parts[0], parts[-1].split(":")[0]
         if kind == "craft":
@@ -182,9 +183,19 @@ def read_keras_h5(path, kind):
         elif layer.startswith(("conv_", "bn_", "fc_", "lstm_")):
             out[f"{layer}/{var}"] = arr
         else:
+            # a variable of the nested, unnamed localisation model (recognition.py:268-278): its layers carry automatic
+            # names (conv2d_7, dense_3, ... whatever the process-wide counters were), so it is placed by its shape
             key = _STN_BY_SHAPE.get(tuple(arr.shape))
-            if key is None or key.split("/")[1] != var or key in out:
-                raise ValueError(f"{path}: cannot place {name} with shape {arr.shape} in the localisation network")
+            if key is None or key.split("/")[1] != var:
+                raise ValueError(f"{path}: {name} with shape {tuple(arr.shape)} is neither a named CRNN layer nor a "
+                                 "variable of the default localisation network (non-default build_params are not supported)")
+            if key in out:
+                raise ValueError(f"{path}: ambiguous localisation network: {name} and {stn_src[key]} both have shape "
+                                 f"{tuple(arr.shape)}, which identifies {key}")
+            if stn_group not in (None, layer):
+                raise ValueError(f"{path}: unnamed variables in two groups ({stn_group!r}, {layer!r}): one nested model expected")
+            stn_group = layer
+            stn_src[key] = name
             out[key] = arr
     return out
 

@@ -71,6 +71,80 @@ def test_keras_h5_round_trip_through_builtin_reader(tmp_path, kind, craft_weight
         assert got[k].shape == v.shape and got[k].dtype == np.float32 and np.array_equal(got[k], v), k
 
 
+GENERIC_VARIANTS = ["fresh", "busy", "tf20", "fullmodel"]
+
+
+@pytest.mark.parametrize("variant", GENERIC_VARIANTS)
+@pytest.mark.parametrize("kind", ["craft", "crnn", "crnn_notop"])
+def test_keras_h5_from_a_generic_keras_saver(tmp_path, kind, variant, craft_weights, crnn_weights):
+    """files from a saver that is NOT make_keras_h5.py -- tests/golden/make_keras_h5_generic.py replays the
+    reference's layer constructor calls against a stand-in of Keras's automatic naming (process-wide counters: conv2d_7,
+    dense_3, model_2, lstm_cell_11 ...; TF 2.0 without the LSTM cell scope; `model.save()` with /model_weights and
+    /optimizer_weights) and of `save_weights_to_hdf5_group`.  The reader must not depend on any of those names."""
+    import keras_ocr_amd
+
+    if not os.path.isfile(CONDA_PY):
+        pytest.skip("no /opt/conda interpreter with h5py in this environment")
+    w = craft_weights if kind == "craft" else dict(crnn_weights)
+    if kind == "crnn_notop":
+        w = {k: v for k, v in w.items() if not k.startswith("fc_12")}
+    npz, p = str(tmp_path / "w.npz"), str(tmp_path / f"{kind}_{variant}.h5")
+    np.savez(npz, **w)
+    r = subprocess.run([CONDA_PY, os.path.join(HERE, "golden", "make_keras_h5_generic.py"), npz, p, kind, variant],
+                       capture_output=True, text=True, check=False)
+    if r.returncode != 0 and "No module named 'h5py'" in r.stderr:
+        pytest.skip("h5py missing in /opt/conda")
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = keras_ocr_amd.weights.read_keras_h5(p, "craft" if kind == "craft" else "crnn")
+    assert set(got) == set(w), set(got) ^ set(w)
+    for k, v in w.items():
+        assert got[k].shape == v.shape and got[k].dtype == np.float32 and np.array_equal(got[k], v), k
+
+
+def test_stn_placement_errors_are_explicit(tmp_path, crnn_weights):
+    """The unnamed localisation layers are placed by shape: a second tensor of a shape that identifies one of them, or
+    an unnamed tensor of an unknown shape, must raise a clear error instead of loading the wrong thing."""
+    import keras_ocr_amd
+    from keras_ocr_amd import weights as kw
+
+    base = {f"{k.split('/')[0]}/{k}:0": v for k, v in crnn_weights.items() if k.startswith(("conv_1", "fc_9"))}
+    stn = {"model/conv2d/kernel:0": crnn_weights["stn_conv_1/kernel"], "model/conv2d/bias:0": crnn_weights["stn_conv_1/bias"]}
+
+    def run(extra, monkey):
+        monkey.setattr(kw, "_h5_datasets", lambda path: {**base, **stn, **extra})
+        return keras_ocr_amd.weights.read_keras_h5("x.h5", "crnn")
+
+    mp = pytest.MonkeyPatch()
+    try:
+        assert "stn_conv_1/bias" in run({}, mp)
+        with pytest.raises(ValueError, match="ambiguous localisation network"):
+            run({"model/conv2d_9/bias:0": np.zeros(16, np.float32)}, mp)
+        with pytest.raises(ValueError, match="non-default build_params"):
+            run({"model/conv2d_9/bias:0": np.zeros(17, np.float32)}, mp)
+        with pytest.raises(ValueError, match="two groups"):
+            run({"model_5/dense/bias:0": np.zeros(6, np.float32)}, mp)
+    finally:
+        mp.undo()
+
+
+def test_h5lite_reads_the_checked_in_h5py_fixture():
+    """tests/golden/tiny_h5py_fixture.h5 was written by the real h5py 3.3 (generator: the heredoc in the commit that added
+    it; values are formulas re-evaluated here), so the built-in reader is exercised even where no second interpreter
+    exists: scoped variable names, a nested model group, an empty group, big-endian float64, a scalar int64."""
+    from keras_ocr_amd import h5lite
+
+    d = h5lite.read_datasets(os.path.join(HERE, "golden", "tiny_h5py_fixture.h5"))
+    assert set(d) == {"conv_1/conv_1/kernel:0", "conv_1/conv_1/bias:0", "model_1/conv2d_7/kernel:0", "model_1/dense_3/bias:0",
+                      "lstm_10/lstm_10/lstm_cell_11/recurrent_kernel:0", "optimizer_weights/Adam/iter:0"}
+    assert np.array_equal(d["conv_1/conv_1/kernel:0"], np.arange(72, dtype=np.float32).reshape(3, 3, 2, 4) / 8 - 1)
+    assert np.array_equal(d["conv_1/conv_1/bias:0"], np.linspace(-1, 1, 4, dtype=np.float32))
+    assert np.array_equal(d["model_1/conv2d_7/kernel:0"], np.full((5, 5, 1, 2), 0.25, np.float32))
+    assert np.array_equal(d["model_1/dense_3/bias:0"], np.array([0.9, 0, 0, 0, 0.9, 0], np.float32))
+    rk = d["lstm_10/lstm_10/lstm_cell_11/recurrent_kernel:0"]
+    assert rk.dtype == np.float64 and np.array_equal(rk, np.arange(24, dtype=np.float64).reshape(2, 12))
+    assert d["optimizer_weights/Adam/iter:0"].shape == () and int(d["optimizer_weights/Adam/iter:0"]) == 25000
+
+
 def test_h5lite_rejects_what_it_does_not_understand(tmp_path):
     from keras_ocr_amd import h5lite
 
@@ -82,6 +156,16 @@ def test_h5lite_rejects_what_it_does_not_understand(tmp_path):
         code = ("import h5py, numpy as np, sys\n"
                 "f = h5py.File(sys.argv[1], 'w')\n"
                 "f.create_dataset('a/b', data=np.arange(100000, dtype='f4'), chunks=(1000,), compression='gzip')\n"
+                "f.close()\n")
+        r = subprocess.run([CONDA_PY, "-c", code, str(p)], capture_output=True, text=True, check=False)
+        if r.returncode == 0:
+            with pytest.raises(NotImplementedError):
+                h5lite.read_datasets(str(p))
+        # a dataset whose datatype message is a reference to a committed (shared) datatype: flag bit 1 of the message
+        code = ("import h5py, numpy as np, sys\n"
+                "f = h5py.File(sys.argv[1], 'w')\n"
+                "f['t'] = np.dtype('<f4')\n"
+                "f.create_dataset('a', data=np.arange(10, dtype='f4'), dtype=f['t'])\n"
                 "f.close()\n")
         r = subprocess.run([CONDA_PY, "-c", code, str(p)], capture_output=True, text=True, check=False)
         if r.returncode == 0:

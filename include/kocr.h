@@ -8,7 +8,11 @@
  *
  * Conventions
  *   - every call returns 0 on success, a negative KOCR_E* code on failure;
- *     kocr_last_error() gives the message of the last failure on that ctx.
+ *     kocr_last_error() gives the message of the last failure on that ctx.  After a non-zero
+ *     return the contents of every OUTPUT buffer of that call are undefined (partial results may
+ *     have been written); only documented exceptions hold (KOCR_ECAPACITY: the counts).  When
+ *     several failures apply, a data error the reference would raise (KOCR_EEMPTYCONTOUR,
+ *     KOCR_EZERODIV) takes precedence over KOCR_ECAPACITY.
  *   - the caller owns every buffer passed in or out; the library owns weights and
  *     workspace.  `on_device` != 0 means the pointers are HIP device pointers on the
  *     ctx's device (e.g. torch.Tensor.data_ptr()); 0 means host pointers (numpy).
@@ -188,6 +192,14 @@ int kocr_conv2d_nhwc(kocr_ctx* ctx, const float* in, int N, int H, int W, int Ci
 #define KOCR_SPLIT_F16X2 1
 int kocr_set_split_mode(kocr_ctx* ctx, int mode);
 int kocr_get_split_mode(const kocr_ctx* ctx);
+
+/* CRAFT schedule (bf16x3 mode): two chains of convolutions without a non-linearity between them are evaluated in
+ * their algebraically identical shorter form ("Folded linear layers"):
+ * fold_linear_chain -- slice5.1 -> slice5.2 -> upconv1.conv.0 (detection.py:349-353, :106-108) as one composed
+ * dilated 3x3 + a 1x1 over s4; fold_upsample -- conv1x1(concat(resize(y), skip)) (detection.py:106-115, 380-389)
+ * as resize(conv1x1_y(y)) + conv1x1_skip(skip).  Both default to on (KOCR_LINFOLD=0 / KOCR_UPFOLD=0 in the
+ * environment of kocr_create turn them off for new contexts); results differ by fp32 round-off only. */
+int kocr_set_schedule(kocr_ctx* ctx, int fold_linear_chain, int fold_upsample);
 
 /* ---- measurement -------------------------------------------------------------------- */
 /* When enabled, every kernel launch on the ctx is bracketed by hipEvents on the ctx

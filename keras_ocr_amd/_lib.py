@@ -72,6 +72,7 @@ def load_library():
         "kocr_conv2d_nhwc": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp]),
         "kocr_set_split_mode": (ci, [vp, ci]),
         "kocr_get_split_mode": (ci, [vp]),
+        "kocr_set_schedule": (ci, [vp, ci, ci]),
         "kocr_profile_enable": (ci, [vp, ci]),
         "kocr_profile_reset": (ci, [vp]),
         "kocr_profile_report": (ci, [vp, ci, ctypes.c_char_p, _c_i64_p, _c_dbl_p, _c_dbl_p, _c_dbl_p]),
@@ -384,6 +385,10 @@ class Context:
 
     def get_split_mode(self):
         return self._check(self._lib.kocr_get_split_mode(self._h))
+
+    def set_schedule(self, fold_linear_chain=True, fold_upsample=True):
+        """CRAFT schedule switches (include/kocr.h kocr_set_schedule); both on by default."""
+        self._check(self._lib.kocr_set_schedule(self._h, int(bool(fold_linear_chain)), int(bool(fold_upsample))))
 
     # -- measurement -------------------------------------------------------------------
     def profile_enable(self, on=True):

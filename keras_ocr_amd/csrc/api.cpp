@@ -123,6 +123,8 @@ int kocr_create(kocr_ctx** out, int hip_device) {
   if (hipSetDevice(hip_device) != hipSuccess) return KOCR_EHIP;
   kocr_ctx* c = new kocr_ctx();
   if (const char* e = getenv("KOCR_SPLIT")) c->split_mode = (!strcmp(e, "f16") || !strcmp(e, "fp16")) ? KOCR_SPLIT_F16X2 : KOCR_SPLIT_BF16X3;
+  if (const char* e = getenv("KOCR_LINFOLD")) c->opt_linfold = atoi(e) != 0;
+  if (const char* e = getenv("KOCR_UPFOLD")) c->opt_upfold = atoi(e) != 0;
   c->device = hip_device;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
@@ -469,6 +471,13 @@ int kocr_set_split_mode(kocr_ctx* ctx, int mode) {
 }
 
 int kocr_get_split_mode(const kocr_ctx* ctx) { return ctx ? ctx->split_mode : KOCR_EINVAL; }
+
+int kocr_set_schedule(kocr_ctx* ctx, int fold_linear_chain, int fold_upsample) {
+  if (!ctx) return KOCR_EINVAL;
+  ctx->opt_linfold = fold_linear_chain != 0;
+  ctx->opt_upfold = fold_upsample != 0;
+  return KOCR_OK;
+}
 
 int kocr_profile_enable(kocr_ctx* ctx, int on) {
   if (!ctx) return KOCR_EINVAL;

@@ -114,6 +114,9 @@ struct kocr_ctx {
   void set_err(const std::string& s) { err = s; }
 
   int split_mode = 0;  // KOCR_SPLIT_BF16X3 / KOCR_SPLIT_F16X2
+  // CRAFT schedule options (craft.cpp: folded linear layers); read ONCE from KOCR_LINFOLD / KOCR_UPFOLD when the
+  // context is created, changed through kocr_set_schedule
+  bool opt_linfold = true, opt_upfold = true;
 
   // max-|x| slots of the tensors of the current forward (see Tensor::amax): zeroed by amax_begin()
   unsigned* d_amax = nullptr;

@@ -10,8 +10,8 @@
 // cat4 = [up(y3) | s1]  (detection.py:380-389).
 // In bf16x3 mode two chains of convolutions WITHOUT a non-linearity between them are evaluated in their algebraically
 // identical shorter form (same sums, fp32 round-off apart): slice5.1 -> slice5.2 -> upconv1.conv.0 as one composed
-// dilated 3x3 plus a 1x1 over s4 (craft_load / craft_run, KOCR_LINFOLD), and conv1x1(concat(resize(y), skip)) as
-// resize(conv1x1_y(y)) + conv1x1_skip(skip) (up_conv, KOCR_UPFOLD); the up-sampled halves of cat2..4 and s5 are then
+// dilated 3x3 plus a 1x1 over s4 (craft_load / craft_run, kocr_set_schedule / KOCR_LINFOLD), and conv1x1(concat(resize(y), skip)) as
+// resize(conv1x1_y(y)) + conv1x1_skip(skip) (up_conv, kocr_set_schedule / KOCR_UPFOLD); the up-sampled halves of cat2..4 and s5 are then
 // never written.
 #include "common.h"
 #include <algorithm>
@@ -412,8 +412,7 @@ int craft_run(kocr_ctx* ctx, CraftNet* net, const void* d_img, int dtype, int N,
   KOCR_TRY(mk(d.H16, d.W16, 512, &u1a));
   bool lin_fold = false;
   if constexpr (!DRY) {
-    const char* off = getenv("KOCR_LINFOLD");
-    lin_fold = !(off && atoi(off) == 0) && ctx->split_mode == KOCR_SPLIT_BF16X3 && dsplit_usable(L("upconv1.conv.0#skip"), s4) &&
+    lin_fold = ctx->opt_linfold && ctx->split_mode == KOCR_SPLIT_BF16X3 && dsplit_usable(L("upconv1.conv.0#skip"), s4) &&
                2 * (size_t)h0.H * h0.W * 512 * 4 < ((size_t)1 << 31);
     if (lin_fold) {  // see craft_load: slice5.1 -> slice5.2 -> upconv1.conv.0 as one dilated 3x3 plus a 1x1 over s4
       Tensor t = h1;  // the first half of h1's buffer, as a contiguous 512-channel tensor
@@ -444,8 +443,7 @@ int craft_run(kocr_ctx* ctx, CraftNet* net, const void* d_img, int dtype, int N,
     if constexpr (!DRY) {
       const ConvLayer& Ls = L((std::string(name) + "#skip").c_str());
       const Tensor skip = cat.slice(c_y, cat.C - c_y);
-      const char* off = getenv("KOCR_UPFOLD");
-      const bool fold = !(off && atoi(off) == 0) && ctx->split_mode == KOCR_SPLIT_BF16X3 && dsplit_usable(Ls, skip) &&
+      const bool fold = ctx->opt_upfold && ctx->split_mode == KOCR_SPLIT_BF16X3 && dsplit_usable(Ls, skip) &&
                         2 * (size_t)t.H * t.W * t.C * 4 < ((size_t)1 << 31);  // two images of t within 32-bit offsets
       if (fold) {
         KOCR_TRY(launch_conv(ctx, L((std::string(name) + "#y").c_str()), y, nullptr, nullptr, t));

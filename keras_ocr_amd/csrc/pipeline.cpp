@@ -220,7 +220,7 @@ extern "C" int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, c
   };
   if (M == 0) return finish();
   if (!labels || M > max_crops) {
-    KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    KOCR_TRY(finish());  // an empty contour list (the reference's IndexError) takes precedence over the capacity error
     KOCR_FAIL(ctx, KOCR_ECAPACITY, "kocr_pipeline: more crops than max_crops");
   }
   // ---- crops: homographies on the device (warp.hip), no host round trip ----

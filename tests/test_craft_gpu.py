@@ -97,15 +97,13 @@ def test_folded_linear_layers_equal_the_plain_schedule(craft_ctx, craft_weights,
         img = np.random.default_rng(5).integers(0, 256, (n, h, w, 3), dtype=np.uint8)
     want = ocraft.detector_predict(craft_weights, img)
     got = {}
-    for name, env in (("folded", {}), ("no_upfold", {"KOCR_UPFOLD": "0"}), ("no_linfold", {"KOCR_LINFOLD": "0"}),
-                      ("plain", {"KOCR_UPFOLD": "0", "KOCR_LINFOLD": "0"})):
-        for k in ("KOCR_UPFOLD", "KOCR_LINFOLD"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        got[name] = craft_ctx.craft_forward(img)
-    for k in ("KOCR_UPFOLD", "KOCR_LINFOLD"):
-        monkeypatch.delenv(k, raising=False)
+    try:
+        for name, (lin, up) in (("folded", (True, True)), ("no_upfold", (True, False)), ("no_linfold", (False, True)),
+                                ("plain", (False, False))):
+            craft_ctx.set_schedule(fold_linear_chain=lin, fold_upsample=up)
+            got[name] = craft_ctx.craft_forward(img)
+    finally:
+        craft_ctx.set_schedule(True, True)
     errs = {k: float(np.abs(v - want).max()) for k, v in got.items()}
     d = {k: float(np.abs(v - got["plain"]).max()) for k, v in got.items()}
     print(f"{shape}: heat-map error vs oracle {errs}; vs plain schedule {d}")

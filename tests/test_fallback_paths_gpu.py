@@ -5,7 +5,8 @@ once per process): the fp64-bounded convolution tests and the CRAFT heat-map-vs-
   KOCR_W43R=0    no row-reuse arrangement   -> 64-cout layers on conv_w43n
   KOCR_HSPLIT=0  no <= 32-cout split kernel -> head / upconv4.conv.3 on the fp32 Winograd kernel
   KOCR_FIRST=0   no split first-layer kernel-> first layer on the fp32 MFMA kernel (conv_mfma MODE 2)
-  KOCR_HEADFUSE=0 no fused detector head    -> upconv4.conv.3 and conv_cls.* as separate launches
+  KOCR_W43V=0    no vertical-reuse arrangement -> wide layers on conv_w43_kernel (round 2's dominant kernel)
+  KOCR_LINFOLD=0 KOCR_UPFOLD=0                 -> the layer-by-layer CRAFT schedule (slice5.1, slice5.2, resize + concat)
 
 (these paths were reached by the driver's suite only through the shapes that happen to select
 them.)  Each configuration is one pytest child process over the same test files, same bounds."""
@@ -24,7 +25,8 @@ CONFIGS = [
     {"KOCR_W43R": "0"},
     {"KOCR_HSPLIT": "0"},
     {"KOCR_FIRST": "0"},
-    {"KOCR_HEADFUSE": "0"},
+    {"KOCR_W43V": "0"},
+    {"KOCR_LINFOLD": "0", "KOCR_UPFOLD": "0"},
 ]
 
 

@@ -24,6 +24,8 @@ int launch_crnn_input(kocr_ctx* ctx, const float* d_crops, float* d_x, int M, in
 int launch_crnn_to_keras(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
 int launch_stn_sample(kocr_ctx* ctx, const Tensor& x, const float* d_theta, const Tensor& out);
 int launch_lstm(kocr_ctx* ctx, const float* d_xp, const float* d_Uf, const float* d_Ub, float* d_out, int M, int T);
+size_t dense_splitk_workspace(int M, int K);
+int launch_dense_splitk(kocr_ctx* ctx, const ConvLayer& L, const float* d_in, float* d_out, float* d_partial, int M);
 int launch_ctc(kocr_ctx* ctx, const float* d_logits, int M, int T, int C, int discard, int* d_labels, float* d_probs);
 
 struct CrnnNet {
@@ -171,6 +173,7 @@ size_t crnn_workspace_bytes(int M, int n_classes) {
   t += al(m * 100 * 15 * 256 * f) * 2 + al(m * 100 * 15 * 512 * f);
   t += al(m * 50 * 7 * 512 * f) * 5;                              // p5, c6, c7 (both layouts), stn
   t += al(m * 50 * 7 * 16 * f) + al(m * 50 * 7 * 32 * f) + al(m * 64 * f) + al(m * 6 * f);
+  t += al(dense_splitk_workspace(M, 50 * 7 * 32));
   t += al(m * T * UNITS * f) + al(m * T * 8 * UNITS * f) + al(m * T * 2 * UNITS * f) * 2;
   t += al(m * T * (size_t)n_classes * f);
   return t + 8192;
@@ -259,7 +262,16 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
   KOCR_TRY(mk(M, WC / 4, HC / 4, 32, &s2));
   KOCR_TRY(conv("stn_conv_2", s1, s2));
   KOCR_TRY(mk(M, 1, 1, 64, &d1));
-  KOCR_TRY(conv("stn_dense_1", view(s2, M, 1, 1, 11200), d1));
+  {
+    // Dense(64) over 11 200 features: split-K (crnn_kernels.hip); the weight rows must be in plain k order
+    const ConvLayer& Ld = net->L["stn_dense_1"];
+    static const bool no_sk = getenv("KOCR_DENSE_SPLITK") && atoi(getenv("KOCR_DENSE_SPLITK")) == 0;
+    float* part = no_sk ? nullptr : (float*)ctx->ws_alloc(dense_splitk_workspace(M, 11200));
+    if (part && Ld.Cout == 64 && Ld.Cin == 11200)
+      KOCR_TRY(launch_dense_splitk(ctx, Ld, s2.p, d1.p, part, M));
+    else
+      KOCR_TRY(conv("stn_dense_1", view(s2, M, 1, 1, 11200), d1));
+  }
   KOCR_TRY(mk(M, 1, 1, 6, &th));
   KOCR_TRY(conv("stn_dense_2", d1, th));
   KOCR_TRY(mk(M, WC / 4, HC / 4, 512, &st));

@@ -134,6 +134,75 @@ __global__ __launch_bounds__(256) void lstm_kernel(const float* __restrict__ xp,
   }
 }
 
+// Round 3: the recurrence is a chain of T = 50 dependent steps, so its time is (time of one step) x 50 whatever the
+// batch: lstm16_kernel shortens the step.  One workgroup = 16 crops x one direction (twice as many workgroups, each with
+// half the matrix work per step: 32 x 8 v_mfma_f32_16x16x4_f32 per wave), and the wave's slice of the recurrent kernel
+// U (128 k x 32 hidden units x 4 gates = 256 values per lane) stays in REGISTERS for all 50 steps instead of being
+// re-fetched from L2 every step (256 loads per wave and step before).  Same arithmetic: fp32 MFMA, gates i, f, c, o of a
+// hidden unit in one lane, cell state in registers, h through LDS.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int UNITS>
+__global__ __launch_bounds__(256) void lstm16_kernel(const float* __restrict__ xp, const float* __restrict__ Uf,
+                                                     const float* __restrict__ Ub, float* __restrict__ out, int M, int T) {
+  static_assert(UNITS == 128, "4 waves x 32 hidden units");
+  constexpr int LD = UNITS + 1;
+  __shared__ float hs[16][LD];
+  const int dir = blockIdx.y;
+  const int m0 = blockIdx.x * 16;
+  const float* Ur = dir ? Ub : Uf;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  // N-tile (g, uh): gate g, hidden units 32 wave + 16 uh + [0, 16); this lane's column is unit j[uh]
+  const int j0 = wave * 32 + lr;
+  float ureg[8][UNITS / 4];  // [g * 2 + uh][k step]: U[4 kp + lk][g UNITS + j0 + 16 uh]
+#pragma unroll
+  for (int gu = 0; gu < 8; ++gu)
+#pragma unroll
+    for (int kp = 0; kp < UNITS / 4; ++kp)
+      ureg[gu][kp] = Ur[(size_t)(4 * kp + lk) * (4 * UNITS) + (gu >> 1) * UNITS + j0 + 16 * (gu & 1)];
+  for (int i = tid; i < 16 * LD; i += 256) (&hs[0][0])[i] = 0.f;
+  float c[2][4];
+#pragma unroll
+  for (int uh = 0; uh < 2; ++uh)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[uh][r] = 0.f;
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const int tin = dir ? (T - 1 - t) : t;
+    f32x4 acc[8];
+    // 16x16 C/D map: column = lane & 15, row = 4 (lane >> 4) + r
+#pragma unroll
+    for (int gu = 0; gu < 8; ++gu)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * lk + r;
+        acc[gu][r] = m < M ? xp[((size_t)m * T + tin) * (8 * UNITS) + dir * 4 * UNITS + (gu >> 1) * UNITS + j0 + 16 * (gu & 1)] : 0.f;
+      }
+#pragma unroll
+    for (int kp = 0; kp < UNITS / 4; ++kp) {
+      const float a = hs[lr][4 * kp + lk];  // A: row (crop) = lane & 15, k = lane >> 4
+#pragma unroll
+      for (int gu = 0; gu < 8; ++gu) acc[gu] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ureg[gu][kp], acc[gu], 0, 0, 0);
+    }
+    __syncthreads();  // every wave has finished reading h(t-1)
+#pragma unroll
+    for (int uh = 0; uh < 2; ++uh)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * lk + r;
+        const float ig = sigmoidf_(acc[0 + uh][r]), fg = sigmoidf_(acc[2 + uh][r]);
+        const float gg = tanhf(acc[4 + uh][r]), og = sigmoidf_(acc[6 + uh][r]);
+        c[uh][r] = fg * c[uh][r] + ig * gg;
+        const float h = og * tanhf(c[uh][r]);
+        const int j = j0 + 16 * uh;
+        hs[row][j] = h;
+        const int m = m0 + row;
+        if (m < M) out[((size_t)m * T + t) * (2 * UNITS) + dir * UNITS + j] = h;
+      }
+    __syncthreads();
+  }
+}
+
 // logits: [M][T][C]; labels: [M][T-discard] (-1 padded); probs (nullable): [M][T-discard][C].
 // One wave per crop; lane l owns classes l, l+64, ... (any alphabet size).
 __global__ void ctc_kernel(const float* __restrict__ logits, int M, int T, int C, int discard, int* __restrict__ labels,
@@ -216,10 +285,66 @@ int launch_stn_sample(kocr_ctx* ctx, const Tensor& x, const float* d_theta, cons
   return KOCR_OK;
 }
 
+// ---- stn_dense_1 (recognition.py:276: Dense(64, relu) over the flattened 50 x 7 x 32 localisation features) ---------------
+// A 512 x 11200 x 64 GEMM: four 128-row tiles on the implicit-GEMM kernel left 252 CUs idle for 0.65 ms.  Split-K in two
+// deterministic passes: partial[s][m][o] = sum over K slice s (fp32 FMA chain in k order), then out = act(sum_s partial).
+constexpr int DSK_ROWS = 16, DSK_KCHUNK = 448;
+__global__ __launch_bounds__(256) void dense_splitk_partial_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                  float* __restrict__ partial, int M, int K, int ldw) {
+  __shared__ float xs[DSK_ROWS][DSK_KCHUNK + 1];
+  const int m0 = blockIdx.x * DSK_ROWS, s = blockIdx.y, k0 = s * DSK_KCHUNK;
+  const int kn = min(DSK_KCHUNK, K - k0);
+  for (int i = threadIdx.x; i < DSK_ROWS * DSK_KCHUNK; i += 256) {
+    const int r = i / DSK_KCHUNK, k = i - r * DSK_KCHUNK;
+    xs[r][k] = (m0 + r < M && k < kn) ? x[(size_t)(m0 + r) * K + k0 + k] : 0.f;
+  }
+  __syncthreads();
+  const int o = threadIdx.x & 63, rg = threadIdx.x >> 6;  // output column, group of four rows
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* wp = w + (size_t)k0 * ldw + o;
+  for (int k = 0; k < kn; ++k) {
+    const float wv = wp[(size_t)k * ldw];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = fmaf(xs[4 * rg + r][k], wv, acc[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (m0 + 4 * rg + r < M) partial[((size_t)s * M + m0 + 4 * rg + r) * 64 + o] = acc[r];
+}
+
+__global__ void dense_splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, const float* __restrict__ pre_a,
+                                           const float* __restrict__ pre_b, int M, int S, int relu) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * 64) return;
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += partial[(size_t)s * M * 64 + i];
+  v = v * pre_a[i & 63] + pre_b[i & 63];
+  out[i] = relu ? fmaxf(v, 0.f) : v;
+}
+
+// in: [M][K] contiguous, L: a 1x1 layer with Cout == 64 and Cin == K (weights [Kpad][Cout_pad], k-major), out: [M][64] contiguous;
+// d_partial: ceil(K / 448) * M * 64 floats
+size_t dense_splitk_workspace(int M, int K) { return (size_t)((K + DSK_KCHUNK - 1) / DSK_KCHUNK) * M * 64 * sizeof(float); }
+int launch_dense_splitk(kocr_ctx* ctx, const ConvLayer& L, const float* d_in, float* d_out, float* d_partial, int M) {
+  if (L.Cout != 64 || L.KH != 1 || L.KW != 1 || L.d_post_a) KOCR_FAIL(ctx, KOCR_EINVAL, "dense_splitk: unsupported layer " + L.name);
+  const int K = L.Cin, S = (K + DSK_KCHUNK - 1) / DSK_KCHUNK;
+  ProfScope ps(ctx, "dense_splitk", 2.0 * M * (double)K * 64, 4.0 * ((double)M * K + (double)K * 64));
+  hipLaunchKernelGGL(dense_splitk_partial_kernel, dim3((M + DSK_ROWS - 1) / DSK_ROWS, S), dim3(256), 0, ctx->stream, d_in, L.d_w,
+                     d_partial, M, K, L.Cout_pad);
+  hipLaunchKernelGGL(dense_splitk_reduce_kernel, dim3((M * 64 + 255) / 256), dim3(256), 0, ctx->stream, d_partial, d_out, L.d_pre_a,
+                     L.d_pre_b, M, S, L.relu);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
 int launch_lstm(kocr_ctx* ctx, const float* d_xp, const float* d_Uf, const float* d_Ub, float* d_out, int M, int T) {
   if (M <= 0) return KOCR_OK;
   ProfScope ps(ctx, "lstm_recurrence", 2.0 * 2 * M * (double)T * 128 * 512, 0);
-  hipLaunchKernelGGL(lstm_kernel<128>, dim3((M + 31) / 32, 2), dim3(256), 0, ctx->stream, d_xp, d_Uf, d_Ub, d_out, M, T);
+  static const bool old = getenv("KOCR_LSTM16") && atoi(getenv("KOCR_LSTM16")) == 0;
+  if (old)
+    hipLaunchKernelGGL(lstm_kernel<128>, dim3((M + 31) / 32, 2), dim3(256), 0, ctx->stream, d_xp, d_Uf, d_Ub, d_out, M, T);
+  else
+    hipLaunchKernelGGL(lstm16_kernel<128>, dim3((M + 15) / 16, 2), dim3(256), 0, ctx->stream, d_xp, d_Uf, d_Ub, d_out, M, T);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }

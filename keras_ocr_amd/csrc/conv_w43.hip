@@ -1292,31 +1292,36 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
 
 // ===================================================================================================
 // conv_w43v_kernel -- the row-reuse idea of conv_w43r_kernel for layers with Cout > 64 (round 3).  A tile is a block of
-// output rows x columns of ONE image (256 pixels, two M-tiles of 2 rows x 64 columns -- the fused-pool geometry) x 128
-// couts; the K loop runs over channel groups only: every input row the tile touches is transformed and split ONCE per
-// 16-channel group into LDS (double buffered) and the three vertical taps read it back at a row offset:
-//   GEO = 0: tile = 2 rows x 128 columns (M-tiles side by side),  4 input rows per 2 output rows (conv_w43_kernel: 6),
-//            72 KB per buffer, two gather items (row, quad, channel quad) per thread and channel group;
-//   GEO = 1: tile = 4 rows x 64 columns (M-tiles stacked),        6 input rows per 4 output rows,
-//            54 KB per buffer, one full gather item + one HALF item (two channels, 8-byte loads) per thread.
-// That is a third / a half less transform + split VALU work, LDS stores and raw-pixel loads per MFMA than conv_w43_kernel
+// output rows x columns of ONE image (256 pixels = two M-tiles) x 128 couts; the K loop runs over channel groups only:
+// every input row the tile touches is transformed and split ONCE per 16-channel group into LDS (double buffered) and the
+// three vertical taps read it back at a row offset:
+//   GEO = 0: tile = 2 rows x 128 columns (M-tiles of 2 rows x 64 columns side by side), 4 input rows per 2 output rows
+//            (conv_w43_kernel: 6), 72 KB per buffer, two gather items (row, quad, channel quad) per thread and channel group;
+//   GEO = 1: tile = 4 rows x 64 columns (the same M-tiles stacked), 6 input rows per 4 output rows, 54 KB per buffer,
+//            one full gather item + one HALF item (two channels, 8-byte loads) per thread;
+//   GEO = 2: tile = 8 rows x 32 columns (M-tiles of 4 rows x 32 columns stacked; W % 32 == 0, H % 8 == 0: the 96-wide
+//            layers), 10 input rows per 8 output rows, 45 KB per buffer, one full item + one half item per thread (the
+//            64 half-row items are produced twice, by waves 0-1 and again by waves 2-3, so that every wave runs the same
+//            straight-line stream).  Two window rows share one 256-byte LDS line (row pair, k half) so that the 16-byte A
+//            reads of a 4-row M-tile stay conflict-free.  No fused pooling.
+// That is a third to a half less transform + split VALU work, LDS stores and raw-pixel loads per MFMA than conv_w43_kernel
 // and one block barrier per 216 MFMAs instead of three.  Wave wn owns both M-tiles x couts [32 wn, 32 wn + 32) x all six
 // points = 192 accumulators, exactly as in conv_w43_kernel, so the output transform stays inside the wave; weights:
 // conv_w43_kernel's layout and order ([16-ch group][ky][32-cout tile][xi][piece][lane][8]), one (channel group, ky)
 // step ahead in registers.  Per channel group: ky = 0 consumes 6 points while item 0's six points of the NEXT channel
 // group are produced (one per point, 1 MFMA : 3 VALU), ky = 1 the same with item 1, ky = 2 produces nothing.
-// Needs Cin % 32 == 0, dilation 1 and H even, W % 128 == 0 (GEO 0) / H % 4 == 0, W % 64 == 0 (GEO 1).
-// POOL = 1: fused 2x2 max-pool (full-resolution store optional).
+// Needs Cin % 32 == 0, dilation 1.  POOL = 1 (GEO 0 / 1): fused 2x2 max-pool (full-resolution store optional).
 // ===================================================================================================
 template <int POOL, int GEO>
 __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
-  constexpr int NROWS = GEO ? 6 : 4;            // input rows of the tile's window
-  constexpr int QPR = GEO ? 16 : 32;            // quads per tile row
-  constexpr int KHS = QPR * 8;                  // ushorts of one k half of a row: QPR quads x 8 channels
-  constexpr int ROW_STRIDE = 2 * KHS;           // ushorts per input row of a plane
-  constexpr int PLANE_R = NROWS * ROW_STRIDE;   // one (xi, piece) plane
-  constexpr int BUF_R = 6 * 3 * PLANE_R;        // one channel group: 72 KB / 54 KB
-  constexpr int TCOLS = QPR * 4;                // tile columns
+  static_assert(!(POOL && GEO == 2), "no fused pooling on 8 x 32 tiles");
+  constexpr int NROWS = GEO == 2 ? 10 : GEO == 1 ? 6 : 4;  // input rows of the tile's window
+  constexpr int QPR = GEO == 2 ? 8 : GEO == 1 ? 16 : 32;   // quads per tile row
+  constexpr int KHS = QPR * 8;                             // ushorts of one k half of a row: QPR quads x 8 channels
+  constexpr int ROW_STRIDE = 2 * KHS;                      // GEO 0 / 1: ushorts per input row of a plane
+  constexpr int PLANE_R = NROWS * 2 * KHS;                 // one (xi, piece) plane
+  constexpr int BUF_R = 6 * 3 * PLANE_R;                   // one channel group: 72 / 54 / 45 KB
+  constexpr int TCOLS = QPR * 4;                           // tile columns
   extern __shared__ __attribute__((aligned(16))) unsigned short As[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = cout sub-tile
@@ -1328,28 +1333,42 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
   const int G = gridDim.x;
   constexpr unsigned OOB = 0x80000000u;
 
-  // pixel tile mp -> its first M-tile in conv_w43_kernel's fused-pool numbering (row pair major, 64-column blocks) and
-  // the M-tile after it: side by side (GEO 0) or the next row pair (GEO 1)
-  auto tile_mt = [&](int mp, int m) {
-    if constexpr (GEO) {
+  // ushort offset of the 16-byte slot (window row w, k half kh, quad q) inside a plane.  GEO 2 puts the two rows of a
+  // row pair into one 256-byte line per k half: with rows 256 bytes apart the four rows of an M-tile would hit the
+  // same banks two by two.
+  auto slot = [&](int w, int kh, int q) {
+    if constexpr (GEO == 2)
+      return ((w >> 1) * 2 + kh) * 128 + (w & 1) * 64 + ((q * 8) ^ (kh * 32));
+    else
+      return w * ROW_STRIDE + kh * KHS + ((q * 8) ^ (kh * 32));
+  };
+  // first pixel of pixel tile mp (flattened (n, y, x) index), its row and column
+  auto tile_org = [&](int mp, int& y0, int& x0) -> long {
+    if constexpr (GEO == 2) {
+      const int rq = (int)w4_fdiv((unsigned)mp, p.dv_tpr), cb = mp - rq * p.tiles_per_row;  // (image, row octet), column block
+      const int ho = p.H >> 3;
+      const int nimg = (int)w4_fdiv((unsigned)rq, p.dv_hh), ro = rq - nimg * ho;
+      y0 = 8 * ro;
+      x0 = 32 * cb;
+      return ((long)nimg * p.H + y0) * p.W + x0;
+    } else if constexpr (GEO == 1) {
       const int rq = (int)w4_fdiv((unsigned)mp, p.dv_tpr), cb = mp - rq * p.tiles_per_row;  // rq: (image, row quad)
-      return (2 * rq + m) * p.tiles_per_row + cb;
+      return w4_mtile_pm0<1>(p, 2 * rq * p.tiles_per_row + cb, y0, x0);
     } else {
-      return 2 * mp + m;
+      return w4_mtile_pm0<1>(p, 2 * mp, y0, x0);
     }
   };
 
   // ---- producer state -----------------------------------------------------------------------------------------
   // item 0: input row r0 of the window, quad qd0, channel quad q4 (16-byte loads).  item 1: GEO 0: row r0 + 2, same quad
-  // and channels; GEO 1: row 4 + (tid >> 7), quad (tid >> 3) & 15, channel PAIR tid & 7 (8-byte loads).
-  const int q4 = tid & 3, qd0 = (tid >> 2) & (QPR - 1), r0 = GEO ? (tid >> 6) : (tid >> 7);
-  const int cp = tid & 7, qd1 = GEO ? ((tid >> 3) & 15) : qd0, r1 = GEO ? 4 + (tid >> 7) : r0 + 2;
+  // and channels; GEO 1 / 2: a HALF item: row, quad, channel PAIR tid & 7 (8-byte loads).
+  const int q4 = tid & 3, qd0 = (tid >> 2) & (QPR - 1), r0 = GEO == 2 ? (tid >> 5) : GEO == 1 ? (tid >> 6) : (tid >> 7);
+  const int cp = tid & 7;
+  const int qd1 = GEO == 2 ? ((tid >> 3) & 7) : GEO == 1 ? ((tid >> 3) & 15) : qd0;
+  const int r1 = GEO == 2 ? 8 + ((tid >> 6) & 1) : GEO == 1 ? 4 + (tid >> 7) : r0 + 2;
   int ldst[2];
-  ldst[0] = r0 * ROW_STRIDE + (q4 >> 1) * KHS + (((qd0 * 8) ^ ((q4 >> 1) * 32)) + (q4 & 1) * 4);
-  if constexpr (GEO)
-    ldst[1] = r1 * ROW_STRIDE + (cp >> 2) * KHS + (((qd1 * 8) ^ ((cp >> 2) * 32)) + (cp & 3) * 2);
-  else
-    ldst[1] = r1 * ROW_STRIDE + (q4 >> 1) * KHS + (((qd1 * 8) ^ ((q4 >> 1) * 32)) + (q4 & 1) * 4);
+  ldst[0] = slot(r0, q4 >> 1, qd0) + (q4 & 1) * 4;
+  ldst[1] = GEO ? slot(r1, cp >> 2, qd1) + (cp & 3) * 2 : slot(r1, q4 >> 1, qd1) + (q4 & 1) * 4;
   struct Geo {
     unsigned off0[2];  // byte offset of raw pixel d0 of each item
     unsigned ok;       // bit it: the item's input row lies inside the image (and the tile exists)
@@ -1359,13 +1378,13 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
     int mp, nt_unused;
     w4_decode(p, kocr_xcd_remap(L < total ? L : 0, total), nblk_n, mp, nt_unused);
     int y0, x0;
-    const long pm = w4_mtile_pm0<1>(p, tile_mt(mp, 0), y0, x0);
+    const long pm = tile_org(mp, y0, x0);
     g.base = p.in + (pm * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
     g.off0[0] = (unsigned)(((r0 * p.W + 4 * qd0) * p.in_cs + q4 * 4) * 4);
     g.off0[1] = (unsigned)(((r1 * p.W + 4 * qd1) * p.in_cs + (GEO ? cp * 2 : q4 * 4)) * 4);
     g.ok = ((L < total && (unsigned)(y0 - 1 + r0) < (unsigned)p.H) ? 1u : 0u) |
            ((L < total && (unsigned)(y0 - 1 + r1) < (unsigned)p.H) ? 2u : 0u);
-    // d0 / d5 are column zero padding only at the image edges (W is a multiple of the tile width); bit 0: item 0, bit 1: item 1
+    // d0 / d5 are column zero padding only at the image edges (W is a multiple of the tile width)
     left = x0 == 0;
     right = x0 + TCOLS >= p.W;
   };
@@ -1397,7 +1416,7 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       const unsigned padk = (k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u);
-      if constexpr (GEO)
+      if constexpr (GEO != 0)
         raw[k] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (off0 + k * stride) | padk, soff, 0));
       else
         raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (off0 + k * stride) | padk, soff, 0));
@@ -1429,7 +1448,7 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
   v4f raw0[6];
   raw1_t raw1[6];
   auto produce_item1 = [&](unsigned short* bufp, int xi) __attribute__((always_inline)) {
-    if constexpr (GEO)
+    if constexpr (GEO != 0)
       produce2(raw1, bufp, xi);
     else
       produce4(raw1, bufp, xi, 1);
@@ -1441,15 +1460,28 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
   auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * 4 + wn) * 18 * 64 + lane) * 8; };
   bf8 bw[6][3];
   f16v acc[6][2];
-  // M row l31 of M-tile m: window row (l31 >> 4) + ky [+ 2 m: GEO 1], quad (l31 & 15) [+ 16 m: GEO 0], k half l5
-  const int a_lane = (l31 >> 4) * ROW_STRIDE + l5 * KHS + (((l31 & 15) * 8) ^ (l5 * 32));
-  constexpr int M_OFF = GEO ? 2 * ROW_STRIDE : 128;  // M-tile 1: two rows down / 16 quads to the right
+  // A operand: M row l31 of M-tile m, tap ky.  GEO 0 / 1: window row (l31 >> 4) + ky [+ 2 m: GEO 1], quad (l31 & 15)
+  // [+ 16 m: GEO 0]; GEO 2: window row (l31 >> 3) + ky + 4 m, quad l31 & 7 -- rows advance in steps of two per 256 ushorts,
+  // so an odd row offset starts from the lane's NEXT row (a_lane1).  k half l5.
+  const int a_lane = GEO == 2 ? slot(l31 >> 3, l5, l31 & 7) : slot(l31 >> 4, l5, l31 & 15);
+  const int a_lane1 = GEO == 2 ? slot((l31 >> 3) + 1, l5, l31 & 7) : 0;
   auto load_a = [&](bf8 (&a)[2][3], const unsigned short* bufp, int ky, int xi) __attribute__((always_inline)) {
-    const unsigned short* base = bufp + a_lane + ky * ROW_STRIDE + xi * 3 * PLANE_R;
+    const unsigned short* plane = bufp + xi * 3 * PLANE_R;
 #pragma unroll
     for (int s = 2; s >= 0; --s)
 #pragma unroll
-      for (int m = 0; m < 2; ++m) a[m][s] = *reinterpret_cast<const bf8*>(base + s * PLANE_R + m * M_OFF);
+      for (int m = 0; m < 2; ++m) {
+        int off;
+        if constexpr (GEO == 2) {
+          const int c = ky + 4 * m;
+          off = ((c & 1) ? a_lane1 : a_lane) + (c >> 1) * 256;
+        } else if constexpr (GEO == 1) {
+          off = a_lane + (ky + 2 * m) * ROW_STRIDE;
+        } else {
+          off = a_lane + ky * ROW_STRIDE + m * 128;
+        }
+        a[m][s] = *reinterpret_cast<const bf8*>(plane + s * PLANE_R + off);
+      }
   };
   auto mfma12 = [&](const bf8 (&a)[2][3], int xi) __attribute__((always_inline)) {
     const bf8 b0 = bw[xi][0], b1 = bw[xi][1], b2 = bw[xi][2];
@@ -1467,7 +1499,7 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b0, acc[xi][m], 0, 0, 0);
   };
-  // One (channel group, ky) step: consume rows ky .. ky + 1 (+ M-tile offset) of `bufc` (6 points x 12 MFMAs); KY = 0 / 1
+  // One (channel group, ky) step: consume rows ky .. (+ M-tile offset) of `bufc` (6 points x 12 MFMAs); KY = 0 / 1
   // also transforms item 0 / 1 of the NEXT channel group into `bufn`, one point per MFMA group.  The weights of the next
   // step (w_next) replace this step's point by point.  a0 holds point 0 of this step on entry and point 0 of the next
   // step on exit; for KY = 2 the next step lives in `bufn`, published by the block barrier before the last point's MFMAs.
@@ -1484,7 +1516,7 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
     };
     auto interleave = [&]() __attribute__((always_inline)) {
       __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);  // the 6 LDS fetches of the next point first
-      if constexpr (KY == 0 || (KY == 1 && !GEO)) {
+      if constexpr (KY == 0 || (KY == 1 && GEO == 0)) {
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
@@ -1597,7 +1629,7 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
     make_geo(L + 2 * G, gn, ln, rn);
     ld_next = false;
 
-    // ---- epilogue (conv_w43_kernel's fused-pool tile geometry: M-tile = 2 rows x 64 columns) ----------------------
+    // ---- epilogue --------------------------------------------------------------------------------------------------
     {
       const int n = (nt * 4 + wn) * 32 + l31;
       const int nc = n < p.Cout ? n : p.Cout - 1;
@@ -1647,36 +1679,54 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
         if (p.amax_out) kocr_amax_update(p.amax_out, mx);
         if (p.amax_pool) kocr_amax_update(p.amax_pool, mx);
       }
+      int ty0, tx0;
+      const long tpm = tile_org(mp, ty0, tx0);
+      if constexpr (GEO == 2) {
+        // M-tile m = rows 4 m .. 4 m + 3 x 8 quads: accumulator register r of lane half l5 is row r >> 2, quad (r & 3) + 4 l5
+        const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (tpm * p.out_cs + p.out_co), 0x7FFFFFFFu);
+        const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        int y0, x0;
-        const long pm = w4_mtile_pm0<1>(p, tile_mt(mp, m), y0, x0);
-        if (!POOL || p.write_full) {
-          const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (pm * p.out_cs + p.out_co), 0x7FFFFFFFu);
-          const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const int px = 4 * ((r & 3) + 8 * (r >> 2));  // quad column (r&3) + 8 (r>>2) [+ 4 l5] of row y
+          for (int r = 0; r < 16; ++r) {
+            const int px = (4 * m + (r >> 2)) * p.W + 4 * (r & 3);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j)
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vo, (px + j) * ocs4, 0);
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r + 8]), ro, vo, (px + j + p.W) * ocs4, 0);
+          }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          // M-tile m: 2 rows x 64 columns, 64 columns to the right (GEO 0) or two rows down (GEO 1)
+          const long pm = tpm + (GEO ? (long)2 * m * p.W : (long)64 * m);
+          const int y0 = ty0 + (GEO ? 2 * m : 0), x0 = tx0 + (GEO ? 0 : 64 * m);
+          (void)y0;
+          if (!POOL || p.write_full) {
+            const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (pm * p.out_cs + p.out_co), 0x7FFFFFFFu);
+            const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const int px = 4 * ((r & 3) + 8 * (r >> 2));  // quad column (r&3) + 8 (r>>2) [+ 4 l5] of row y
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vo, (px + j) * ocs4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r + 8]), ro, vo, (px + j + p.W) * ocs4, 0);
+              }
             }
           }
-        }
-        if constexpr (POOL) {
-          // 2x2 max: rows y (r) and y+1 (r+8), columns (0,1) and (2,3) of the quad
-          // pm = (nimg H + y0) W + x0  ->  pooled pixel (nimg H/2 + y0/2) W/2 + x0/2 = (pm - x0) / 4 ... exactly, H and W even
-          const long pp0 = ((pm - x0) >> 2) + (x0 >> 1);
-          const __amdgpu_buffer_rsrc_t rp = w4_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
-          const unsigned vp = live ? (unsigned)((8 * l5 * p.pool_cs + n) * 4) : OOB;  // 4 quads = 8 pooled px per l5
+          if constexpr (POOL) {
+            // 2x2 max: rows y (r) and y+1 (r+8), columns (0,1) and (2,3) of the quad
+            const long pp0 = ((pm - x0) >> 2) + (x0 >> 1);  // (nimg H/2 + y0/2) W/2 + x0/2: H, W even
+            const __amdgpu_buffer_rsrc_t rp = w4_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
+            const unsigned vp = live ? (unsigned)((8 * l5 * p.pool_cs + n) * 4) : OOB;  // 4 quads = 8 pooled px per l5
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const int pq = 2 * ((r & 3) + 8 * (r >> 2));
-            const float v0 = fmaxf(fmaxf(acc[0][m][r], acc[1][m][r]), fmaxf(acc[0][m][r + 8], acc[1][m][r + 8]));
-            const float v1 = fmaxf(fmaxf(acc[2][m][r], acc[3][m][r]), fmaxf(acc[2][m][r + 8], acc[3][m][r + 8]));
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * pcs4, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * pcs4, 0);
+            for (int r = 0; r < 8; ++r) {
+              const int pq = 2 * ((r & 3) + 8 * (r >> 2));
+              const float v0 = fmaxf(fmaxf(acc[0][m][r], acc[1][m][r]), fmaxf(acc[0][m][r + 8], acc[1][m][r + 8]));
+              const float v1 = fmaxf(fmaxf(acc[2][m][r], acc[3][m][r]), fmaxf(acc[2][m][r + 8], acc[3][m][r + 8]));
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * pcs4, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * pcs4, 0);
+            }
           }
         }
       }
@@ -1800,7 +1850,7 @@ static int w4r_launch(kocr_ctx* ctx, W4Params& p) {
 
 template <int POOL, int GEO>
 static int w4v_launch(kocr_ctx* ctx, W4Params& p) {
-  constexpr int LDSV = GEO ? 2 * 6 * 3 * 6 * 256 * 2 : 2 * LDS_BYTES;  // 2 x 54 KB / 2 x 72 KB
+  constexpr int LDSV = GEO == 2 ? 2 * 6 * 3 * 10 * 128 * 2 : GEO == 1 ? 2 * 6 * 3 * 6 * 256 * 2 : 2 * LDS_BYTES;  // 2 x 45 / 54 / 72 KB
   static std::atomic<bool> attr_done[64];
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
@@ -1870,14 +1920,19 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   // geometry: 4 rows x 64 columns (H % 4 == 0, W % 64 == 0) or 2 rows x 128 columns (H even, W % 128 == 0); KOCR_W43V_GEO
   // forces one of them where both apply (developer switch)
   const bool v_ok = !narrow && !no_v && L.dil == 1 && (!pool || fuse) && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31);
-  const bool geo1_ok = v_ok && in.H % 4 == 0 && in.W % 64 == 0, geo0_ok = v_ok && in.H % 2 == 0 && in.W % 128 == 0;
-  const int vgeo = (geo1_ok && geo_env != 0) ? 1 : (geo0_ok && geo_env != 1) ? 0 : geo1_ok ? 1 : -1;
+  // 4 rows x 64 columns where the image tiles that way, else 8 rows x 32 columns (the 96-wide layers); the 2 x 128 geometry
+  // (GEO 0) is kept in the kernel template but not instantiated: it spills once it shares the code with the other two and
+  // only H % 4 != 0 images would take it -- they stay on conv_w43_kernel
+  const bool geo1_ok = v_ok && in.H % 4 == 0 && in.W % 64 == 0;
+  const bool geo2_ok = v_ok && !pool && in.H % 8 == 0 && in.W % 32 == 0;
+  const int vgeo = geo_env == 2 ? (geo2_ok ? 2 : -1) : geo1_ok ? 1 : geo2_ok ? 2 : -1;
   const bool vreuse = vgeo >= 0;
   if ((rowreuse || vreuse) && !fuse) p.tiles_per_row = in.W / 64;  // the 2-row x 64-column M-tile geometry without the pooling
   p.n_mpairs = (rowreuse || vreuse) ? p.total_mtiles / 2 : narrow ? (p.total_mtiles + 3) / 4 : (p.total_mtiles + 1) / 2;
   p.total_tiles = p.n_mpairs * (p.Cout_pad / (narrow ? 64 : 128));
+  if (vgeo == 2) p.tiles_per_row = in.W / 32;
   w4_div_magic((unsigned)p.tiles_per_row, p.dv_tpr);
-  w4_div_magic((unsigned)(in.H / 2), p.dv_hh);
+  w4_div_magic((unsigned)(vgeo == 2 ? in.H / 8 : in.H / 2), p.dv_hh);
   w4_div_magic((unsigned)p.n_mpairs, p.dv_mp);
   w4_div_magic((unsigned)(p.Cout_pad / (narrow ? 64 : 128)), p.dv_nb);
   // Tile order.  The split weights of one cout block are Cin * 3 * 128 * 36 B; with every cout block of a deep layer in
@@ -1888,9 +1943,9 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_w4%s_%s%s:%s", vreuse ? (vgeo ? "v" : "u") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_w4%s_%s%s:%s", vreuse ? (vgeo == 2 ? "t" : vgeo ? "v" : "u") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_w4%s_%s%s", vreuse ? (vgeo ? "v" : "u") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
+    snprintf(nm, sizeof nm, "conv_w4%s_%s%s", vreuse ? (vgeo == 2 ? "t" : vgeo ? "v" : "u") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   {
@@ -1919,16 +1974,13 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
     }
 #endif
     if (vreuse) {
-      if (vgeo == 1) {
+      if (vgeo == 2) {
+        KOCR_TRY((w4v_launch<0, 2>(ctx, p)));
+      } else {
         if (fuse)
           KOCR_TRY((w4v_launch<1, 1>(ctx, p)));
         else
           KOCR_TRY((w4v_launch<0, 1>(ctx, p)));
-      } else {
-        if (fuse)
-          KOCR_TRY((w4v_launch<1, 0>(ctx, p)));
-        else
-          KOCR_TRY((w4v_launch<0, 0>(ctx, p)));
       }
     } else if (rowreuse) {
       if (rgeo == 1) {

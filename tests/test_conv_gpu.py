@@ -125,14 +125,15 @@ SPLIT_CASES = [
     (1, 4, 384, 96, 40),      # 4 x 64: six channel groups, one row quad
     (2, 10, 256, 64, 64),     # 2 x 128: two tiles per row pair, two images
     (3, 12, 64, 32, 33),      # 4 x 64: one tile per row quad, one live column in the second cout half
-    # Cout > 64 on images that tile as 4 rows x 64 columns or 2 rows x 128 columns: the vertical-reuse arrangement
+    # Cout > 64 on images that tile as 4 rows x 64 columns or 8 rows x 32 columns: the vertical-reuse arrangement
     # (conv_w43v_kernel); (1, 96, 192, 256, 256) and (1, 64, 128, 128, 256) above take it too (4 x 64)
     (2, 8, 256, 64, 128),     # 4 x 64: slice1.7 class, four channel groups, four tiles per row quad, two images
     (1, 4, 192, 32, 130),     # 4 x 64: one row quad (both vertical paddings in every tile), two cout blocks, ragged couts
     (3, 12, 64, 96, 96),      # 4 x 64: one tile per row quad (both column paddings in every tile), six channel groups
-    (1, 6, 128, 32, 130),     # 2 x 128 (H % 4 != 0): two channel groups, two cout blocks, ragged couts
-    (1, 10, 384, 96, 200),    # 2 x 128: six channel groups, three tiles per row pair, 56 dead couts in the second block
-    (3, 2, 128, 32, 96),      # 2 x 128: a single row pair per image: both vertical paddings in every tile
+    (2, 16, 96, 64, 128),     # 8 x 32: slice4.34 class geometry (96 wide), two row octets, three column blocks, two images
+    (1, 8, 32, 32, 130),      # 8 x 32: a single tile per image (all four paddings), two cout blocks, ragged couts
+    (3, 24, 160, 96, 96),     # 8 x 32: five column blocks, three row octets, six channel groups, three images
+    (1, 6, 128, 32, 130),     # H % 4 != 0: stays on conv_w43_kernel (flattened-pixel tiles)
     # Cout <= 32 (conv_hsplit.hip: haloed 8x32 tile split once into LDS; needs >= 4096 pixels)
     (1, 64, 64, 32, 32),      # conv_cls.0 / .2 class, tiles exact
     (2, 70, 45, 64, 32),      # upconv4.conv.3 class: 4 chunks, ragged tiles in both directions, two images

@@ -316,6 +316,41 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
                                        (unsigned)__builtin_amdgcn_readfirstlane((int)ub);
         const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)ubu, 0, 0x7FFFFFFF, 0x00020000);
         const unsigned ch = (unsigned)nc * 4u;
+        if constexpr (UP == 2) {
+          // UP = 2: exactly 2x in both directions and W % 4 == 0 (the launcher checks).  The four outputs ox0 .. ox0 + 3
+          // (ox0 = 4 q) of a register group read the source columns k - 1, k, k + 1, k + 2 (k = ox0 / 2; clamped at the image
+          // edges by the table entries of the group's first and last pixel) of two source rows: 8 loads instead of 16, the
+          // same blend arithmetic
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) {
+                const unsigned* e = tab + ((g * 2 + m) * 32 + 8 * rr + 4 * l5) * 8;
+                const uint4 oa = *reinterpret_cast<const uint4*>(e);          // pixel 0: (y0,k-1) (y0,k) (y1,k-1) (y1,k)
+                const uint4 od = *reinterpret_cast<const uint4*>(e + 3 * 8);  // pixel 3: (y0,k+1) (y0,k+2) (y1,k+1) (y1,k+2)
+                float2 wl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wl[j] = *reinterpret_cast<const float2*>(e + j * 8 + 4);
+                float t[4], b[4];  // top / bottom source row, columns k - 1 .. k + 2
+                t[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, oa.x + ch, 0, 0));
+                t[1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, oa.y + ch, 0, 0));
+                t[2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, od.x + ch, 0, 0));
+                t[3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, od.y + ch, 0, 0));
+                b[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, oa.z + ch, 0, 0));
+                b[1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, oa.w + ch, 0, 0));
+                b[2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, od.z + ch, 0, 0));
+                b[3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, od.w + ch, 0, 0));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const int c0 = (j + 1) >> 1;  // left tap of output j: columns (k-1,k) (k,k+1) (k,k+1) (k+1,k+2)
+                  const float top = t[c0] + (t[c0 + 1] - t[c0]) * wl[j].x;
+                  const float bot = b[c0] + (b[c0 + 1] - b[c0]) * wl[j].x;
+                  acc[g][m][rr * 4 + j] += top + (bot - top) * wl[j].y;
+                }
+              }
+        } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -345,6 +380,7 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
                 acc[g][m][rr * 4 + j] += top + (bot - top) * wl[j].y;
               }
             }
+        }
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -553,7 +589,13 @@ int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout + (up ? (double)up->pixels() * L.Cout : 0.0));
   ProfScope ps(ctx, nm, flops, bytes);
-  if (up) return wcls == 128 ? ds_launch<1, 4, 0, 1>(ctx, p, M) : ds_launch<2, 2, 0, 1>(ctx, p, M);
+  if (up) {
+    // exactly 2x up-sampling with W % 4 == 0: the shared-tap epilogue (UP = 2)
+    static const bool no_up2 = getenv("KOCR_UP2X") && atoi(getenv("KOCR_UP2X")) == 0;
+    if (!no_up2 && in.H == 2 * up->H && in.W == 2 * up->W && in.W % 4 == 0)
+      return wcls == 128 ? ds_launch<1, 4, 0, 2>(ctx, p, M) : ds_launch<2, 2, 0, 2>(ctx, p, M);
+    return wcls == 128 ? ds_launch<1, 4, 0, 1>(ctx, p, M) : ds_launch<2, 2, 0, 1>(ctx, p, M);
+  }
   if (half) return wcls == 128 ? ds_launch<1, 4, 1>(ctx, p, M) : ds_launch<2, 2, 1>(ctx, p, M);
   return wcls == 128 ? ds_launch<1, 4, 0>(ctx, p, M) : ds_launch<2, 2, 0>(ctx, p, M);
 }

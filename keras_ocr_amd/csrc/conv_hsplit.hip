@@ -185,8 +185,9 @@ __global__ __launch_bounds__(256, 3) void conv_hs_kernel(HsParams p) {
 // 2.6 TB/s of output against the 6.8 TB/s a plain fill reaches).  Block = 256 threads, tile = 8 rows x 32 columns; thread
 // t gathers the 27 neighbours of ITS pixel (byte loads, out-of-image = the zero padding of the NORMALISED image),
 // normalises them through the compute_input table (detection.py:34-42, bit-exact float32 values, copied to LDS), splits
-// them and stores its im2col row [32 k] x 3 pieces (80-byte pixel stride: conflict-free 16-byte A reads); wave w owns
-// tile rows 2w, 2w+1 = two M-tiles x 64 couts: 2 k-steps x 2 cout tiles x 12 = 48 MFMAs.  60 KB of LDS: two blocks / CU.
+// them and stores its im2col row, one 16-k step at a time, x 3 pieces (48-byte pixel stride: conflict-free 16-byte A reads);
+// wave w owns tile rows 2w, 2w+1 = two M-tiles x 64 couts: 2 k-steps x 2 cout tiles x 12 = 48 MFMAs.  36 KB of LDS (the halo
+// tile and the table live in the same buffer before the operand planes do): four blocks / CU.
 // ===================================================================================================
 struct FirstParams {
   const uint8_t* img;         // [N][H][W][3]
@@ -202,13 +203,14 @@ struct FirstParams {
 };
 
 namespace {
-constexpr int F1_PS = 40;                    // ushorts per pixel of a plane: 32 k + 8 padding (80 bytes)
-constexpr int F1_PLANE = 256 * F1_PS;        // 10240 ushorts
+constexpr int F1_PS = 24;                    // ushorts per pixel of a plane: 16 k (one k-step) + 8 padding (48 bytes)
+constexpr int F1_PLANE = 256 * F1_PS;        // 6144 ushorts
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void conv_first_kernel(FirstParams p) {
+__global__ __launch_bounds__(256, 4) void conv_first_kernel(FirstParams p) {
+  // one 36 KB buffer: first the halo tile and the compute_input table, then (after a block barrier) the operand planes
   __shared__ __attribute__((aligned(16))) unsigned short As[3 * F1_PLANE];
-  __shared__ float lut_s[768];
+  float* lut_s = reinterpret_cast<float*>(As) + 512;  // behind the 10 x 28 dword halo tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, l5 = lane >> 5;
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(FirstParams p) {
   // image row as 27 aligned dwords (one load per thread; bytes outside the image are never used: `valid` below) -- then every
   // thread picks the 27 neighbours of its pixel from LDS.  (Round 2 issued 27 global byte loads per thread: 6.9 k vector-memory
   // instructions per tile against 270 here.)
-  __shared__ unsigned tile_s[HS_HH * 28];
+  unsigned* tile_s = reinterpret_cast<unsigned*>(As);
   const uint8_t* img = p.img + (size_t)n * p.H * p.W * 3;
   const int py = y0 + (tid >> 5), px = x0 + (tid & 31);
   auto row_ptr = [&](int hr) { return (long)(uintptr_t)img + ((long)(y0 + hr - 1) * p.W + (x0 - 1)) * 3; };  // first byte of halo row hr
@@ -272,20 +274,11 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(FirstParams p) {
   for (int k = 0; k < 27; ++k) v[k] = ((valid >> (k / 3)) & 1u) ? lut_s[(k % 3) * 256 + raw[k]] : 0.f;
 #pragma unroll
   for (int k = 27; k < 32; ++k) v[k] = 0.f;
-  {
-    unsigned short* dst = As + tid * F1_PS;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      u2v h, m, l;
-      kocr_split4(v4f{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}, h, m, l);
-      *reinterpret_cast<u2v*>(dst + q * 4) = h;
-      *reinterpret_cast<u2v*>(dst + F1_PLANE + q * 4) = m;
-      *reinterpret_cast<u2v*>(dst + 2 * F1_PLANE + q * 4) = l;
-    }
-  }
-  __syncthreads();
-
+  __syncthreads();  // every thread has its 27 table values: the tile / table area becomes the operand planes
   // ---- 2 M-tiles (tile rows 2 wave, 2 wave + 1) x 2 cout tiles x 2 k-steps ------------------------------------------
+  // The im2col rows a wave multiplies are the rows its OWN threads produce (thread = pixel, wave w = tile rows 2w, 2w + 1), so
+  // the exchange through LDS needs no block barrier (a wave's DS operations execute in order), and it runs one k-step at a
+  // time through a 36 KB image (16 k x 3 pieces x 256 pixels) instead of 60 KB: four blocks per CU instead of two.
   f16v acc[2][2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -296,12 +289,27 @@ __global__ __launch_bounds__(256, 2) void conv_first_kernel(FirstParams p) {
   const unsigned short* w_lane = p.wgt + lane * 8;
 #pragma unroll
   for (int kc = 0; kc < 2; ++kc) {
+    {
+      unsigned short* dst = As + tid * F1_PS;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        u2v h, m, l;
+        kocr_split4(v4f{v[16 * kc + 4 * q], v[16 * kc + 4 * q + 1], v[16 * kc + 4 * q + 2], v[16 * kc + 4 * q + 3]}, h, m, l);
+        *reinterpret_cast<u2v*>(dst + q * 4) = h;
+        *reinterpret_cast<u2v*>(dst + F1_PLANE + q * 4) = m;
+        *reinterpret_cast<u2v*>(dst + 2 * F1_PLANE + q * 4) = l;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     bf8 a[2][3], b[2][3];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int s = 0; s < 3; ++s)
-        a[m][s] = *reinterpret_cast<const bf8*>(As + s * F1_PLANE + ((2 * wave + m) * 32 + l31) * F1_PS + kc * 16 + l5 * 8);
+        a[m][s] = *reinterpret_cast<const bf8*>(As + s * F1_PLANE + ((2 * wave + m) * 32 + l31) * F1_PS + l5 * 8);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the second k-step overwrites these rows
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll

@@ -1295,10 +1295,9 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
 // output rows x columns of ONE image (256 pixels = two M-tiles) x 128 couts; the K loop runs over channel groups only:
 // every input row the tile touches is transformed and split ONCE per 16-channel group into LDS (double buffered) and the
 // three vertical taps read it back at a row offset:
-//   GEO = 0: tile = 2 rows x 128 columns (M-tiles of 2 rows x 64 columns side by side), 4 input rows per 2 output rows
-//            (conv_w43_kernel: 6), 72 KB per buffer, two gather items (row, quad, channel quad) per thread and channel group;
-//   GEO = 1: tile = 4 rows x 64 columns (the same M-tiles stacked), 6 input rows per 4 output rows, 54 KB per buffer,
-//            one full gather item + one HALF item (two channels, 8-byte loads) per thread;
+//   GEO = 1: tile = 4 rows x 64 columns (M-tiles of 2 rows x 64 columns stacked), 6 input rows per 4 output rows
+//            (conv_w43_kernel: 12), 54 KB per buffer, one full gather item (row, quad, channel quad: 16-byte loads) + one
+//            HALF item (two channels, 8-byte loads) per thread and channel group;
 //   GEO = 2: tile = 8 rows x 32 columns (M-tiles of 4 rows x 32 columns stacked; W % 32 == 0, H % 8 == 0: the 96-wide
 //            layers), 10 input rows per 8 output rows, 45 KB per buffer, one full item + one half item per thread (the
 //            64 half-row items are produced twice, by waves 0-1 and again by waves 2-3, so that every wave runs the same
@@ -1310,17 +1309,19 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
 // conv_w43_kernel's layout and order ([16-ch group][ky][32-cout tile][xi][piece][lane][8]), one (channel group, ky)
 // step ahead in registers.  Per channel group: ky = 0 consumes 6 points while item 0's six points of the NEXT channel
 // group are produced (one per point, 1 MFMA : 3 VALU), ky = 1 the same with item 1, ky = 2 produces nothing.
-// Needs Cin % 32 == 0, dilation 1.  POOL = 1 (GEO 0 / 1): fused 2x2 max-pool (full-resolution store optional).
+// (A 2 rows x 128 columns geometry, GEO = 0, exists for the 64-cout kernel conv_w43r only.)
+// Needs Cin % 32 == 0, dilation 1.  POOL = 1 (GEO 1): fused 2x2 max-pool (full-resolution store optional).
 // ===================================================================================================
 template <int POOL, int GEO>
 __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
+  static_assert(GEO == 1 || GEO == 2, "4 x 64 or 8 x 32 tiles");
   static_assert(!(POOL && GEO == 2), "no fused pooling on 8 x 32 tiles");
-  constexpr int NROWS = GEO == 2 ? 10 : GEO == 1 ? 6 : 4;  // input rows of the tile's window
-  constexpr int QPR = GEO == 2 ? 8 : GEO == 1 ? 16 : 32;   // quads per tile row
+  constexpr int NROWS = GEO == 2 ? 10 : 6;  // input rows of the tile's window
+  constexpr int QPR = GEO == 2 ? 8 : 16;    // quads per tile row
   constexpr int KHS = QPR * 8;                             // ushorts of one k half of a row: QPR quads x 8 channels
-  constexpr int ROW_STRIDE = 2 * KHS;                      // GEO 0 / 1: ushorts per input row of a plane
+  constexpr int ROW_STRIDE = 2 * KHS;                      // GEO 1: ushorts per input row of a plane
   constexpr int PLANE_R = NROWS * 2 * KHS;                 // one (xi, piece) plane
-  constexpr int BUF_R = 6 * 3 * PLANE_R;                   // one channel group: 72 / 54 / 45 KB
+  constexpr int BUF_R = 6 * 3 * PLANE_R;                   // one channel group: 54 / 45 KB
   constexpr int TCOLS = QPR * 4;                           // tile columns
   extern __shared__ __attribute__((aligned(16))) unsigned short As[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1351,24 +1352,22 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
       y0 = 8 * ro;
       x0 = 32 * cb;
       return ((long)nimg * p.H + y0) * p.W + x0;
-    } else if constexpr (GEO == 1) {
+    } else {
       const int rq = (int)w4_fdiv((unsigned)mp, p.dv_tpr), cb = mp - rq * p.tiles_per_row;  // rq: (image, row quad)
       return w4_mtile_pm0<1>(p, 2 * rq * p.tiles_per_row + cb, y0, x0);
-    } else {
-      return w4_mtile_pm0<1>(p, 2 * mp, y0, x0);
     }
   };
 
   // ---- producer state -----------------------------------------------------------------------------------------
-  // item 0: input row r0 of the window, quad qd0, channel quad q4 (16-byte loads).  item 1: GEO 0: row r0 + 2, same quad
-  // and channels; GEO 1 / 2: a HALF item: row, quad, channel PAIR tid & 7 (8-byte loads).
-  const int q4 = tid & 3, qd0 = (tid >> 2) & (QPR - 1), r0 = GEO == 2 ? (tid >> 5) : GEO == 1 ? (tid >> 6) : (tid >> 7);
+  // item 0: input row r0 of the window, quad qd0, channel quad q4 (16-byte loads).  item 1, a HALF item: row r1, quad qd1,
+  // channel PAIR tid & 7 (8-byte loads).
+  const int q4 = tid & 3, qd0 = (tid >> 2) & (QPR - 1), r0 = GEO == 2 ? (tid >> 5) : (tid >> 6);
   const int cp = tid & 7;
-  const int qd1 = GEO == 2 ? ((tid >> 3) & 7) : GEO == 1 ? ((tid >> 3) & 15) : qd0;
-  const int r1 = GEO == 2 ? 8 + ((tid >> 6) & 1) : GEO == 1 ? 4 + (tid >> 7) : r0 + 2;
+  const int qd1 = GEO == 2 ? ((tid >> 3) & 7) : ((tid >> 3) & 15);
+  const int r1 = GEO == 2 ? 8 + ((tid >> 6) & 1) : 4 + (tid >> 7);
   int ldst[2];
   ldst[0] = slot(r0, q4 >> 1, qd0) + (q4 & 1) * 4;
-  ldst[1] = GEO ? slot(r1, cp >> 2, qd1) + (cp & 3) * 2 : slot(r1, q4 >> 1, qd1) + (q4 & 1) * 4;
+  ldst[1] = slot(r1, cp >> 2, qd1) + (cp & 3) * 2;
   struct Geo {
     unsigned off0[2];  // byte offset of raw pixel d0 of each item
     unsigned ok;       // bit it: the item's input row lies inside the image (and the tile exists)
@@ -1381,7 +1380,7 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
     const long pm = tile_org(mp, y0, x0);
     g.base = p.in + (pm * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
     g.off0[0] = (unsigned)(((r0 * p.W + 4 * qd0) * p.in_cs + q4 * 4) * 4);
-    g.off0[1] = (unsigned)(((r1 * p.W + 4 * qd1) * p.in_cs + (GEO ? cp * 2 : q4 * 4)) * 4);
+    g.off0[1] = (unsigned)(((r1 * p.W + 4 * qd1) * p.in_cs + cp * 2) * 4);
     g.ok = ((L < total && (unsigned)(y0 - 1 + r0) < (unsigned)p.H) ? 1u : 0u) |
            ((L < total && (unsigned)(y0 - 1 + r1) < (unsigned)p.H) ? 2u : 0u);
     // d0 / d5 are column zero padding only at the image edges (W is a multiple of the tile width)
@@ -1392,7 +1391,6 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
   bool lc, rc, ln, rn;
   int ld_cg = 0;  // channel group of the NEXT load inside its tile
   bool ld_next = false;
-  typedef typename std::conditional<GEO != 0, v2f, v4f>::type raw1_t;
   auto load_item0 = [&](v4f (&raw)[6]) __attribute__((always_inline)) {
     const int soff = ld_cg * 64;
     const bool ok = (ld_next ? gn.ok : gc.ok) & 1u;
@@ -1406,7 +1404,7 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
       raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (off0 + k * stride) | padk, soff, 0));
     }
   };
-  auto load_item1 = [&](raw1_t (&raw)[6]) __attribute__((always_inline)) {
+  auto load_item1 = [&](v2f (&raw)[6]) __attribute__((always_inline)) {
     const int soff = ld_cg * 64;
     const bool ok = ((ld_next ? gn.ok : gc.ok) >> 1) & 1u;
     const unsigned off0 = (ld_next ? gn.off0[1] : gc.off0[1]) | (ok ? 0u : OOB);
@@ -1416,10 +1414,7 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       const unsigned padk = (k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u);
-      if constexpr (GEO != 0)
-        raw[k] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (off0 + k * stride) | padk, soff, 0));
-      else
-        raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (off0 + k * stride) | padk, soff, 0));
+      raw[k] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (off0 + k * stride) | padk, soff, 0));
     }
   };
   auto advance = [&]() __attribute__((always_inline)) {
@@ -1446,13 +1441,8 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
     *reinterpret_cast<unsigned*>(dst + 2 * PLANE_R) = l;
   };
   v4f raw0[6];
-  raw1_t raw1[6];
-  auto produce_item1 = [&](unsigned short* bufp, int xi) __attribute__((always_inline)) {
-    if constexpr (GEO != 0)
-      produce2(raw1, bufp, xi);
-    else
-      produce4(raw1, bufp, xi, 1);
-  };
+  v2f raw1[6];
+  auto produce_item1 = [&](unsigned short* bufp, int xi) __attribute__((always_inline)) { produce2(raw1, bufp, xi); };
 
   // ---- consumer state ------------------------------------------------------------------------------------------
   const int ntiles32 = p.Cout_pad >> 5;
@@ -1460,9 +1450,9 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
   auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * 4 + wn) * 18 * 64 + lane) * 8; };
   bf8 bw[6][3];
   f16v acc[6][2];
-  // A operand: M row l31 of M-tile m, tap ky.  GEO 0 / 1: window row (l31 >> 4) + ky [+ 2 m: GEO 1], quad (l31 & 15)
-  // [+ 16 m: GEO 0]; GEO 2: window row (l31 >> 3) + ky + 4 m, quad l31 & 7 -- rows advance in steps of two per 256 ushorts,
-  // so an odd row offset starts from the lane's NEXT row (a_lane1).  k half l5.
+  // A operand: M row l31 of M-tile m, tap ky.  GEO 1: window row (l31 >> 4) + ky + 2 m, quad l31 & 15; GEO 2: window row
+  // (l31 >> 3) + ky + 4 m, quad l31 & 7 -- rows advance in steps of two per 256 ushorts, so an odd row offset starts from
+  // the lane's NEXT row (a_lane1).  k half l5.
   const int a_lane = GEO == 2 ? slot(l31 >> 3, l5, l31 & 7) : slot(l31 >> 4, l5, l31 & 15);
   const int a_lane1 = GEO == 2 ? slot((l31 >> 3) + 1, l5, l31 & 7) : 0;
   auto load_a = [&](bf8 (&a)[2][3], const unsigned short* bufp, int ky, int xi) __attribute__((always_inline)) {
@@ -1475,10 +1465,8 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
         if constexpr (GEO == 2) {
           const int c = ky + 4 * m;
           off = ((c & 1) ? a_lane1 : a_lane) + (c >> 1) * 256;
-        } else if constexpr (GEO == 1) {
-          off = a_lane + (ky + 2 * m) * ROW_STRIDE;
         } else {
-          off = a_lane + ky * ROW_STRIDE + m * 128;
+          off = a_lane + (ky + 2 * m) * ROW_STRIDE;
         }
         a[m][s] = *reinterpret_cast<const bf8*>(plane + s * PLANE_R + off);
       }
@@ -1516,7 +1504,7 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
     };
     auto interleave = [&]() __attribute__((always_inline)) {
       __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);  // the 6 LDS fetches of the next point first
-      if constexpr (KY == 0 || (KY == 1 && GEO == 0)) {
+      if constexpr (KY == 0) {
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
@@ -1697,10 +1685,9 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
       } else {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          // M-tile m: 2 rows x 64 columns, 64 columns to the right (GEO 0) or two rows down (GEO 1)
-          const long pm = tpm + (GEO ? (long)2 * m * p.W : (long)64 * m);
-          const int y0 = ty0 + (GEO ? 2 * m : 0), x0 = tx0 + (GEO ? 0 : 64 * m);
-          (void)y0;
+          // M-tile m: 2 rows x 64 columns, two rows below M-tile 0
+          const long pm = tpm + (long)2 * m * p.W;
+          const int x0 = tx0;
           if (!POOL || p.write_full) {
             const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (pm * p.out_cs + p.out_co), 0x7FFFFFFFu);
             const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
@@ -1850,7 +1837,7 @@ static int w4r_launch(kocr_ctx* ctx, W4Params& p) {
 
 template <int POOL, int GEO>
 static int w4v_launch(kocr_ctx* ctx, W4Params& p) {
-  constexpr int LDSV = GEO == 2 ? 2 * 6 * 3 * 10 * 128 * 2 : GEO == 1 ? 2 * 6 * 3 * 6 * 256 * 2 : 2 * LDS_BYTES;  // 2 x 45 / 54 / 72 KB
+  constexpr int LDSV = GEO == 2 ? 2 * 6 * 3 * 10 * 128 * 2 : 2 * 6 * 3 * 6 * 256 * 2;  // 2 x 45 / 54 KB
   static std::atomic<bool> attr_done[64];
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
@@ -1920,9 +1907,8 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   // geometry: 4 rows x 64 columns (H % 4 == 0, W % 64 == 0) or 2 rows x 128 columns (H even, W % 128 == 0); KOCR_W43V_GEO
   // forces one of them where both apply (developer switch)
   const bool v_ok = !narrow && !no_v && L.dil == 1 && (!pool || fuse) && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31);
-  // 4 rows x 64 columns where the image tiles that way, else 8 rows x 32 columns (the 96-wide layers); the 2 x 128 geometry
-  // (GEO 0) is kept in the kernel template but not instantiated: it spills once it shares the code with the other two and
-  // only H % 4 != 0 images would take it -- they stay on conv_w43_kernel
+  // 4 rows x 64 columns where the image tiles that way, else 8 rows x 32 columns (the 96-wide layers); anything else (e.g.
+  // H % 4 != 0) stays on conv_w43_kernel
   const bool geo1_ok = v_ok && in.H % 4 == 0 && in.W % 64 == 0;
   const bool geo2_ok = v_ok && !pool && in.H % 8 == 0 && in.W % 32 == 0;
   const int vgeo = geo_env == 2 ? (geo2_ok ? 2 : -1) : geo1_ok ? 1 : geo2_ok ? 2 : -1;
@@ -1943,9 +1929,9 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_w4%s_%s%s:%s", vreuse ? (vgeo == 2 ? "t" : vgeo ? "v" : "u") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_w4%s_%s%s:%s", vreuse ? (vgeo == 2 ? "t" : "v") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_w4%s_%s%s", vreuse ? (vgeo == 2 ? "t" : vgeo ? "v" : "u") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
+    snprintf(nm, sizeof nm, "conv_w4%s_%s%s", vreuse ? (vgeo == 2 ? "t" : "v") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   {

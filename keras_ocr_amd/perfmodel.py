@@ -11,7 +11,6 @@ _FAMILIES = [
     ("conv_w4s", "bf16", 0.5 * 6.0, "1/2 (Winograd F(4,3): 6 multiplies per 4 outputs x 3 taps) x 6 bf16x3 split products"),
     ("conv_w4v", "bf16", 0.5 * 6.0, "1/2 (Winograd F(4,3): 6 multiplies per 4 outputs x 3 taps) x 6 bf16x3 split products"),
     ("conv_w4t", "bf16", 0.5 * 6.0, "1/2 (Winograd F(4,3): 6 multiplies per 4 outputs x 3 taps) x 6 bf16x3 split products"),
-    ("conv_w4u", "bf16", 0.5 * 6.0, "1/2 (Winograd F(4,3): 6 multiplies per 4 outputs x 3 taps) x 6 bf16x3 split products"),
     ("conv_ws", "bf16", 2.0 / 3.0 * 6.0, "2/3 (Winograd F(2,3)) x 6 bf16x3 split products"),
     ("conv_wh", "fp16", 2.0 / 3.0 * 3.0, "2/3 (Winograd F(2,3)) x 3 fp16x2 split products"),
     ("conv_ds", "bf16", 6.0, "6 bf16x3 split products (direct 1x1 / dilated convolution)"),

@@ -4,6 +4,26 @@ import numpy as np
 from . import detection, recognition, tools
 
 
+def decode_labels(alphabet, labels):
+    """Label rows -> strings, skipping the blank (= len(alphabet)) and the -1 padding (recognition.py:527-534).
+
+    One table lookup and one UTF-32 decode for the whole batch: iterating 600 x 48 numpy scalars costs 4 ms
+    per call, during which the GPU sits idle."""
+    labels = np.asarray(labels)
+    if labels.size == 0:
+        return [""] * len(labels)
+    if any(len(c) != 1 or c == "\0" for c in alphabet):
+        skip = (len(alphabet), -1)
+        return ["".join([alphabet[i] for i in row if i not in skip]) for row in labels.tolist()]
+    n = len(alphabet)
+    if labels.min() < -1 or labels.max() > n:
+        raise IndexError("label outside the alphabet")
+    table = np.array([ord(c) for c in alphabet] + [0], "<u4")
+    text = table[np.where(labels < 0, n, labels)].tobytes().decode("utf-32-le")
+    w = labels.shape[1]
+    return [text[i * w:(i + 1) * w].replace("\0", "") for i in range(labels.shape[0])]
+
+
 class Pipeline:
     """A wrapper for a combination of detector and recognizer (pipeline.py:7-26).
 
@@ -119,9 +139,7 @@ class Pipeline:
     def assemble(self, box_groups, labels):
         """(box_groups, label rows) -> the reference's return value (pipeline.py:72-75)."""
         # recognition.py:527-534: label rows -> strings, skipping the blank (= len(alphabet)) and the -1 padding
-        alphabet = self.recognizer.alphabet
-        skip = (len(alphabet), -1)
-        predictions = ["".join(alphabet[idx] for idx in row if idx not in skip) for row in np.asarray(labels)]
+        predictions = decode_labels(self.recognizer.alphabet, labels)
         out, start = [], 0
         for boxes in box_groups:
             out.append(list(zip(predictions[start:start + len(boxes)], boxes)))

@@ -101,7 +101,8 @@ class Recognizer:
         self.training_model = None
 
     def _decode(self, rows):
-        return ["".join([self.alphabet[idx] for idx in row if idx not in [self.blank_label_idx, -1]]) for row in rows]
+        from .pipeline import decode_labels
+        return decode_labels(self.alphabet, rows)
 
     def recognize(self, image):
         """Recognizer.recognize (recognition.py:467-489): one pre-cropped RGB image -> string."""

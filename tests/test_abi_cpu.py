@@ -91,3 +91,23 @@ def test_reference_api_surface():
     assert k.recognition.DEFAULT_ALPHABET == "0123456789abcdefghijklmnopqrstuvwxyz"
     assert k.recognition.DEFAULT_BUILD_PARAMS["rnn_steps_to_discard"] == 2
     assert k.detection.PRETRAINED_WEIGHTS[("clovaai_general", True)]["sha256"].startswith("4a5efbfb")
+
+
+def test_decode_labels_matches_the_per_character_loop():
+    """recognition.py:527-534: blank (= len(alphabet)) and -1 are skipped; the batched decode equals the loop."""
+    import numpy as np
+    from keras_ocr_amd.pipeline import decode_labels
+
+    rng = np.random.default_rng(5)
+    for alphabet in ("0123456789abcdefghijklmnopqrstuvwxyz", "aé漢字\U0001f600z", ["ab", "c", "d"]):
+        n = len(alphabet)
+        labels = np.full((40, 48), -1, np.int32)
+        for r in range(40):
+            k = int(rng.integers(0, 49))
+            labels[r, :k] = rng.integers(0, n + 1, k)
+        want = ["".join(alphabet[i] for i in row if i not in (n, -1)) for row in labels]
+        assert decode_labels(alphabet, labels) == want
+        assert decode_labels(alphabet, labels.tolist()) == want
+    assert decode_labels("abc", np.zeros((0, 48), np.int32)) == []
+    with pytest.raises(IndexError):
+        decode_labels("abc", np.array([[0, 7]]))

@@ -86,6 +86,7 @@ struct ConvLayer {
   int ds_wexp = 0;
   unsigned short* d_first = nullptr;  // 3 -> <= 64 first layer on raw uint8, im2col K = 27 -> 32, conv_hsplit.hip order
   unsigned short* d_hs = nullptr;  // 3x3, <= 32 couts: 3-way bf16 split, conv_hsplit.hip order
+  unsigned short* d_k5 = nullptr;  // 5x5, 16 couts, small images: 3-way bf16 split, conv_k5.hip order
   bool tap_inner = false;  // K order [16-channel group][tap][16] (Cin % 16 == 0) instead of [tap][Cin]
   bool ready() const { return d_w != nullptr; }
 };
@@ -230,6 +231,10 @@ int prepare_first(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
 bool first_applicable(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in);
 int launch_conv_first(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8, const float* lut, const Tensor& out);
 int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* up = nullptr);
+// conv_k5.hip
+int prepare_k5(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
+bool k5_applicable(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out);
+int launch_conv_k5(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out);
 // elementwise.hip
 // row_off: input row that starts output row 0 (0 = keras 'valid' pooling; 1 = the same pooling seen
 // through a vertical flip of an odd-height tensor, as in the CRNN's natural-orientation conv stack)

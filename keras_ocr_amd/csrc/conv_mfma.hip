@@ -495,6 +495,7 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
   KOCR_TRY(prepare_w43(ctx, L, w, w_is_oihw));
   KOCR_TRY(prepare_dsplit(ctx, L, w, w_is_oihw));
   KOCR_TRY(prepare_hsplit(ctx, L, w, w_is_oihw));
+  KOCR_TRY(prepare_k5(ctx, L, w, w_is_oihw));
   KOCR_TRY(prepare_first(ctx, L, w, w_is_oihw));
   if (Cin == 3 && KH == 3 && KW == 3 && dil == 1) {  // uint8 first layer: K order [tap][R,G,B,0], 48 rows
     std::vector<float> w4((size_t)48 * L.Cout_pad, 0.f);
@@ -640,6 +641,8 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
     KOCR_TRY(launch_conv_first(ctx, L, in, in_u8, lut, out));
     return pool ? launch_maxpool2x2(ctx, out, *pool) : KOCR_OK;
   }
+  if (!in_u8 && !pool && variant == 0 && conv_variant() == 0 && k5_applicable(ctx, L, in, out))  // 5x5, 16 couts, small images
+    return launch_conv_k5(ctx, L, in, out);
   // bf16x3-split Winograd on the bf16 matrix cores (fp32-class accuracy, see conv_wsplit.hip)
   if (!in_u8 && variant == 0 && conv_variant() == 0 && w43_applicable(ctx, L, in))
     return launch_conv_w43(ctx, L, in, out, pool, need_full);

@@ -27,8 +27,9 @@ PROF_TO_KERNEL = {
     "conv_ws_128x128": "void conv_ws_kernel<0, 1, 4, 0", "conv_ws_128x128_pool": "void conv_ws_kernel<1, 1, 4, 0",
     "conv_ws_256x64": "void conv_ws_kernel<0, 2, 2, 0", "conv_ws_256x64_pool": "void conv_ws_kernel<1, 2, 2, 0",
     "conv_ds_256x128": "void conv_ds_kernel<1, 4, 0, 0", "conv_ds_512x64": "void conv_ds_kernel<2, 2, 0, 0",
-    "conv_ds_256x128_up": "void conv_ds_kernel<1, 4, 0, 1", "conv_ds_512x64_up": "void conv_ds_kernel<2, 2, 0, 1",
-    "conv_hs_256x32": "conv_hs_kernel", "conv_hs_first_256x64": "conv_first_kernel",
+    # exact 2x up-sampling (every CRAFT shape); the generic-ratio variant <..., 1> shares the profiler row
+    "conv_ds_256x128_up": "void conv_ds_kernel<1, 4, 0, 2", "conv_ds_512x64_up": "void conv_ds_kernel<2, 2, 0, 2",
+    "conv_hs_256x32": "conv_hs_kernel", "conv_hs_first_256x64": "conv_first_kernel", "conv_k5_352x16": "conv_k5_kernel",
 }
 
 

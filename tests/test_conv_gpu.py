@@ -4,6 +4,7 @@ PyTorch fp32 reference of the same op (floating-point kernel -> torch fp32 refer
 Tolerance: both sides accumulate in fp32 in different orders; |err| <= 2e-5 * sqrt(K) *
 max|out| is far above fp32 round-off for these sizes and far below the heat-map tolerance.
 """
+import os
 import zlib
 
 import numpy as np
@@ -158,6 +159,43 @@ def test_split_kernel_is_fp32_class_against_fp64(ctx, case):
     print(f"split conv {case}: max err / (|x| conv |w|) = {ratio.max():.3e}, rms = {rms:.3e}")
     assert float(ratio.max()) <= 1e-6, f"max err / (|x| conv |w|) = {ratio.max():.3e}"
     assert rms <= 1.5e-7, f"rms = {rms:.3e}"
+
+
+# conv_k5.hip: 5x5, 16 couts, images of <= 384 pixels (the recogniser's stn_conv_1, recognition.py:259-262): one image
+# per block, two taps per MFMA K-step
+K5_CASES = [
+    # N, H, W, Cin
+    (3, 7, 50, 512),    # stn_conv_1 itself: 22 tiles (6 / 6 / 5 / 5 per wave), the last one partly outside
+    (2, 5, 33, 32),     # two chunks, 11 tiles (some waves own 2, some 3), ragged last tile
+    (5, 1, 9, 16),      # a single row, a single chunk, a single partly-filled tile: every tap but the centre row is padding
+    (1, 16, 24, 48),    # the largest pixel count the kernel takes (384 = 24 full tiles)
+]
+
+
+@pytest.mark.parametrize("case", K5_CASES, ids=[str(c) for c in K5_CASES])
+def test_k5_kernel_is_fp32_class_against_fp64(ctx, case):
+    n, h, w, cin = case
+    cout = 16
+    rng = np.random.default_rng(_seed(case))
+    x = np.maximum(rng.standard_normal((n, h, w, cin)), 0).astype(np.float32)
+    wt = (rng.standard_normal((5, 5, cin, cout)) * np.sqrt(2.0 / (cin * 25))).astype(np.float32)
+    pre_b = rng.uniform(-0.3, 0.3, cout).astype(np.float32)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    got = ctx.conv2d_nhwc(x, wt, pre_b=pre_b, relu=True).astype(np.float64)
+    rows = ctx.profile_report()
+    ctx.profile_enable(False)
+    if os.environ.get("KOCR_K5", "1") != "0":
+        assert any(k.startswith("conv_k5") for k in rows), f"conv_k5 did not run: {sorted(rows)}"
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
+    wtt = torch.from_numpy(wt).double().permute(3, 2, 0, 1)
+    b = torch.from_numpy(pre_b).double().view(1, -1, 1, 1)
+    want = F.relu(F.conv2d(xt, wtt, None, padding=2) + b).permute(0, 2, 3, 1).numpy()
+    bound = (F.conv2d(xt.abs(), wtt.abs(), None, padding=2) + b.abs()).permute(0, 2, 3, 1).numpy()
+    ratio = np.abs(got - want) / np.maximum(bound, 1e-30)
+    print(f"k5 conv {case}: max err / bound = {ratio.max():.3e}, rms = {np.sqrt((ratio ** 2).mean()):.3e}")
+    assert got.shape == want.shape
+    assert float(ratio.max()) <= 1e-6, f"max err / bound = {ratio.max():.3e}"
 
 
 # conv_dsplit.hip: the same bf16x3 arithmetic for 1x1 / dilated / larger kernels (>= 4096 pixels)

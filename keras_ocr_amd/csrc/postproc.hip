@@ -440,150 +440,334 @@ __device__ __forceinline__ long cross3(int2 o, int2 a, int2 b) {
   return (long)(a.x - o.x) * (b.y - o.y) - (long)(a.y - o.y) * (b.x - o.x);
 }
 
-// ---- K13: hull + min-area rectangle, one thread per component -------------------------------
-__global__ void k_boxes(CanvasArgs a) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.ncomp) return;
-  const CompInfo ci = a.info[c];
-  float* out = a.boxes + ((size_t)ci.img * a.cap + ci.slot) * 8;
-  if (a.sel[c] < 0) {  // reference: contours[0] of an empty list -> IndexError
-    atomicAdd(&a.totals[2], 1);
-    for (int i = 0; i < 8; ++i) out[i] = 0.f;
-    return;
-  }
-  // scratch: lower chain then upper chain
-  int2* lower = a.hullbuf + 2 * (2 * (size_t)ci.row_off + 4 * (size_t)c);
-  int2* upper = lower + (2 * ci.rh + 4);
-  int nl = 0, nu = 0;
-  int l = INT_MAX, r = -1, t = INT_MAX, b = -1;
-  // points sorted by (y, x): row by row, min then max
-  for (int ly = 0; ly < ci.rh; ++ly) {
-    const int mn = a.rowmin[ci.row_off + ly];
-    if (mn < 0) continue;
-    const int mx = a.rowmax[ci.row_off + ly];
-    const int y = ci.sy + ly;
-    t = min(t, y);
-    b = max(b, y);
-    l = min(l, ci.sx + mn);
-    r = max(r, ci.sx + mx);
-    for (int e = 0; e < (mx != mn ? 2 : 1); ++e) {
-      const int2 pt = make_int2(ci.sx + (e ? mx : mn), y);
-      while (nl >= 2 && cross3(lower[nl - 2], lower[nl - 1], pt) >= 0) --nl;
-      lower[nl++] = pt;
-    }
-  }
-  for (int ly = ci.rh - 1; ly >= 0; --ly) {
-    const int mn = a.rowmin[ci.row_off + ly];
-    if (mn < 0) continue;
-    const int mx = a.rowmax[ci.row_off + ly];
-    const int y = ci.sy + ly;
-    for (int e = 0; e < (mx != mn ? 2 : 1); ++e) {
-      const int2 pt = make_int2(ci.sx + (e ? mn : mx), y);  // reversed (y,x) order
-      while (nu >= 2 && cross3(upper[nu - 2], upper[nu - 1], pt) >= 0) --nu;
-      upper[nu++] = pt;
-    }
-  }
-  // hull = lower[:-1] + upper[:-1]; write it contiguously into `lower`
-  int n = 0;
-  if (nl == 1) {
-    n = 1;
-  } else {
-    n = nl - 1;
-    for (int i = 0; i + 1 < nu; ++i) lower[n++] = upper[i];
-  }
-  int2* H = lower;
-  float bx[4], by[4];
-  if (n == 1) {
-    for (int i = 0; i < 4; ++i) {
-      bx[i] = (float)H[0].x;
-      by[i] = (float)H[0].y;
-    }
-  } else if (n == 2) {
-    bx[0] = bx[1] = (float)H[0].x;
-    by[0] = by[1] = (float)H[0].y;
-    bx[2] = bx[3] = (float)H[1].x;
-    by[2] = by[3] = (float)H[1].y;
-  } else {
-    // orientation: clockwise on screen <=> positive shoelace in image coordinates
-    long area2 = 0;
-    for (int i = 0; i < n; ++i) {
-      const int2 p0 = H[i], p1 = H[(i + 1) % n];
-      area2 += (long)p0.x * p1.y - (long)p1.x * p0.y;
-    }
-    if (area2 < 0)
-      for (int i = 1, j = n - 1; i < j; ++i, --j) {
-        const int2 tmp = H[i];
-        H[i] = H[j];
-        H[j] = tmp;
+// ---- K13: hull + min-area rectangle, one WAVE per component ------------------------------------
+// Lane 0 builds the hull (monotone chain over the row extents, sequential by nature); the O(n^2) search over the hull's
+// edges for the smallest enclosing rectangle runs one edge per lane.  Everything is exact integer arithmetic and the
+// reduction keeps the FIRST edge among equal minima, i.e. what the sequential loop over the edges returns.
+__device__ __forceinline__ long shfl_long(long v, int src) {
+  const int lo = __shfl((int)v, src), hi = __shfl((int)(v >> 32), src);
+  return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ long shfl_xor_long(long v, int mask) {
+  const int lo = __shfl_xor((int)v, mask), hi = __shfl_xor((int)(v >> 32), mask);
+  return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// num_a / L_a < num_b / L_b, exactly (all non-negative, L > 0)
+__device__ __forceinline__ bool ratio_less(long num_a, long L_a, long num_b, long L_b) {
+  return (unsigned __int128)(unsigned long)num_a * (unsigned long)L_b < (unsigned __int128)(unsigned long)num_b * (unsigned long)L_a;
+}
+
+constexpr int KB_CAP = 1024;  // candidate points up to which k_boxes builds its chains in LDS
+
+// Monotone chain step: push `pt` onto a chain whose two newest points live in registers (t1 newest)
+#define KB_PUSH(chain, cnt, pt)                                   \
+  do {                                                            \
+    while ((cnt) >= 2 && cross3(t2, t1, (pt)) >= 0) {             \
+      --(cnt);                                                    \
+      t1 = t2;                                                    \
+      if ((cnt) >= 2) t2 = (chain)[(cnt)-2];                      \
+    }                                                             \
+    (chain)[(cnt)++] = (pt);                                      \
+    t2 = t1;                                                      \
+    t1 = (pt);                                                    \
+  } while (0)
+
+__global__ __launch_bounds__(64) void k_boxes(CanvasArgs a) {
+  __shared__ int2 hull_s[2 * (KB_CAP + 4)];
+  __shared__ int2 cand_s[KB_CAP];
+  const int lane = threadIdx.x;
+  for (int c = blockIdx.x; c < a.ncomp; c += gridDim.x) {
+    const CompInfo ci = a.info[c];
+    float* out = a.boxes + ((size_t)ci.img * a.cap + ci.slot) * 8;
+    if (a.sel[c] < 0) {  // reference: contours[0] of an empty list -> IndexError
+      if (lane == 0) {
+        atomicAdd(&a.totals[2], 1);
+        for (int i = 0; i < 8; ++i) out[i] = 0.f;
       }
+      continue;
+    }
+    // The hull is a monotone chain over the row extents (min and max column of every row, sorted by (y, x)): a serial
+    // dependency chain, about 1 us per point on one lane (a 700-row line artefact cost 1 ms).  The points are first reduced,
+    // in parallel and exactly, to those that can be strict hull vertices: the min point of a row only if it lies strictly
+    // left of every row above it or strictly left of every row below it (otherwise it is inside, or on an edge of, the
+    // triangle of those two rows' points and its own row's max point), the max point symmetrically; a single-point row if
+    // either holds.  The chain over this subset is the chain over all points; it runs in LDS.  Only a component with more
+    // than KB_CAP candidates (or more than 4096 rows) runs the plain chain over every point from global scratch.
+    const int* rowmin = a.rowmin + ci.row_off;
+    const int* rowmax = a.rowmax + ci.row_off;
+    int n = 0, ncand = -1;
+    int l = INT_MAX, r = -1, t = INT_MAX, b = -1;
+    __syncthreads();  // the previous component's LDS data is no longer read (one wave per block: a wave-level sync)
+    if (ci.rh <= 4096) {
+      const int R = (ci.rh + 63) >> 6;  // contiguous rows per lane, at most 64: keep flags are bit masks
+      const int r_lo = min(lane * R, ci.rh), r_hi = min(r_lo + R, ci.rh);
+      int cmin = INT_MAX, cmax = INT_MIN, cfirst = INT_MAX, clast = -1;
+      for (int ly = r_lo; ly < r_hi; ++ly) {
+        const int mn = rowmin[ly];
+        if (mn < 0) continue;
+        cmin = min(cmin, mn);
+        cmax = max(cmax, rowmax[ly]);
+        cfirst = min(cfirst, ly);
+        clast = ly;
+      }
+      // exclusive prefix / suffix extremes over the lanes
+      int ipmin = cmin, ipmax = cmax, ismin = cmin, ismax = cmax;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int a0 = __shfl_up(ipmin, off), a1 = __shfl_up(ipmax, off);
+        const int b0 = __shfl_down(ismin, off), b1 = __shfl_down(ismax, off);
+        if (lane >= off) {
+          ipmin = min(ipmin, a0);
+          ipmax = max(ipmax, a1);
+        }
+        if (lane + off < 64) {
+          ismin = min(ismin, b0);
+          ismax = max(ismax, b1);
+        }
+      }
+      int pmin = __shfl_up(ipmin, 1), pmax = __shfl_up(ipmax, 1), smin = __shfl_down(ismin, 1), smax = __shfl_down(ismax, 1);
+      if (lane == 0) {
+        pmin = INT_MAX;
+        pmax = INT_MIN;
+      }
+      if (lane == 63) {
+        smin = INT_MAX;
+        smax = INT_MIN;
+      }
+      l = ci.sx + __shfl(ipmin, 63);
+      r = ci.sx + __shfl(ipmax, 63);
+      int tf = cfirst, bl = clast;
+      for (int off = 32; off > 0; off >>= 1) {
+        tf = min(tf, __shfl_xor(tf, off));
+        bl = max(bl, __shfl_xor(bl, off));
+      }
+      t = ci.sy + tf;
+      b = ci.sy + bl;
+      // keep flags of this lane's rows: km = min points, kx = max points (bit = row - r_lo)
+      unsigned long km = 0, kx = 0;
+      int rmin = pmin, rmax = pmax;
+      for (int ly = r_lo; ly < r_hi; ++ly) {
+        const int mn = rowmin[ly];
+        if (mn < 0) continue;
+        const int mx = rowmax[ly];
+        if (mn < rmin) km |= 1ul << (ly - r_lo);
+        if (mx > rmax) kx |= 1ul << (ly - r_lo);
+        rmin = min(rmin, mn);
+        rmax = max(rmax, mx);
+      }
+      rmin = smin;
+      rmax = smax;
+      for (int ly = r_hi - 1; ly >= r_lo; --ly) {
+        const int mn = rowmin[ly];
+        if (mn < 0) continue;
+        const int mx = rowmax[ly];
+        const unsigned long bit = 1ul << (ly - r_lo);
+        if (mn < rmin) km |= bit;
+        if (mx > rmax) kx |= bit;
+        if (mx == mn) {  // one point
+          if (kx & bit) km |= bit;
+          kx &= ~bit;
+        }
+        rmin = min(rmin, mn);
+        rmax = max(rmax, mx);
+      }
+      const int cnt = __popcll(km) + __popcll(kx);
+      int incl = cnt;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      ncand = __shfl(incl, 63);
+      if (ncand <= KB_CAP) {  // compact candidate list in (y, x) order
+        int pos = incl - cnt;
+        for (int ly = r_lo; ly < r_hi; ++ly) {
+          const unsigned long bit = 1ul << (ly - r_lo);
+          if (km & bit) cand_s[pos++] = make_int2(ci.sx + rowmin[ly], ci.sy + ly);
+          if (kx & bit) cand_s[pos++] = make_int2(ci.sx + rowmax[ly], ci.sy + ly);
+        }
+      } else {
+        ncand = -1;
+      }
+      __syncthreads();
+    }
+    const bool in_lds = ncand >= 0;
+    int2* lower = in_lds ? hull_s : a.hullbuf + 2 * (2 * (size_t)ci.row_off + 4 * (size_t)c);
+    if (lane == 0) {
+      int2* upper = lower + (in_lds ? KB_CAP + 4 : 2 * ci.rh + 4);
+      int nl = 0, nu = 0;
+      int2 t1 = make_int2(0, 0), t2 = make_int2(0, 0);
+      if (in_lds) {
+        for (int i = 0; i < ncand; ++i) {
+          const int2 pt = cand_s[i];
+          KB_PUSH(lower, nl, pt);
+        }
+        for (int i = ncand - 1; i >= 0; --i) {
+          const int2 pt = cand_s[i];
+          KB_PUSH(upper, nu, pt);
+        }
+      } else {
+        // points sorted by (y, x): row by row, min then max
+        for (int ly = 0; ly < ci.rh; ++ly) {
+          const int mn = rowmin[ly];
+          if (mn < 0) continue;
+          const int mx = rowmax[ly];
+          const int y = ci.sy + ly;
+          t = min(t, y);
+          b = max(b, y);
+          l = min(l, ci.sx + mn);
+          r = max(r, ci.sx + mx);
+          for (int e = 0; e < (mx != mn ? 2 : 1); ++e) {
+            const int2 pt = make_int2(ci.sx + (e ? mx : mn), y);
+            KB_PUSH(lower, nl, pt);
+          }
+        }
+        for (int ly = ci.rh - 1; ly >= 0; --ly) {
+          const int mn = rowmin[ly];
+          if (mn < 0) continue;
+          const int mx = rowmax[ly];
+          const int y = ci.sy + ly;
+          for (int e = 0; e < (mx != mn ? 2 : 1); ++e) {
+            const int2 pt = make_int2(ci.sx + (e ? mn : mx), y);  // reversed (y,x) order
+            KB_PUSH(upper, nu, pt);
+          }
+        }
+      }
+      // hull = lower[:-1] + upper[:-1]; write it contiguously into `lower`
+      if (nl == 1) {
+        n = 1;
+      } else {
+        n = nl - 1;
+        for (int i = 0; i + 1 < nu; ++i) lower[n++] = upper[i];
+      }
+      if (n >= 3) {
+        // orientation: clockwise on screen <=> positive shoelace in image coordinates
+        long area2 = 0;
+        for (int i = 0; i < n; ++i) {
+          const int2 p0 = lower[i], p1 = lower[(i + 1) % n];
+          area2 += (long)p0.x * p1.y - (long)p1.x * p0.y;
+        }
+        if (area2 < 0)
+          for (int i = 1, j = n - 1; i < j; ++i, --j) {
+            const int2 tmp = lower[i];
+            lower[i] = lower[j];
+            lower[j] = tmp;
+          }
+      }
+    }
+    __threadfence_block();  // the hull, written by lane 0, is read by the whole wave
+    __syncthreads();
+    n = __shfl(n, 0);
+    const int2* H = lower;
     long bnum = 0, bL = 0, bumin = 0, bumax = 0, bvmin = 0, bvmax = 0;
-    int bdx = 0, bdy = 0;
-    bool have = false;
-    for (int i = 0; i < n; ++i) {
-      const int2 p0 = H[i], p1 = H[(i + 1) % n];
-      const long dx = p1.x - p0.x, dy = p1.y - p0.y;
-      const long L = dx * dx + dy * dy;
-      long umin = LONG_MAX, umax = LONG_MIN, vmin = LONG_MAX, vmax = LONG_MIN;
-      for (int j = 0; j < n; ++j) {
-        const long u = H[j].x * dx + H[j].y * dy;
-        const long v = -H[j].x * dy + H[j].y * dx;
-        umin = min(umin, u);
-        umax = max(umax, u);
-        vmin = min(vmin, v);
-        vmax = max(vmax, v);
+    int bdx = 0, bdy = 0, bidx = INT_MAX;
+    if (n >= 3) {
+      for (int i = lane; i < n; i += 64) {
+        const int2 p0 = H[i], p1 = H[i + 1 < n ? i + 1 : 0];
+        const long dx = p1.x - p0.x, dy = p1.y - p0.y;
+        const long L = dx * dx + dy * dy;
+        long umin = LONG_MAX, umax = LONG_MIN, vmin = LONG_MAX, vmax = LONG_MIN;
+        for (int j = 0; j < n; ++j) {
+          const int2 q = H[j];
+          const long u = q.x * dx + q.y * dy;
+          const long v = -q.x * dy + q.y * dx;
+          umin = min(umin, u);
+          umax = max(umax, u);
+          vmin = min(vmin, v);
+          vmax = max(vmax, v);
+        }
+        const long num = (umax - umin) * (vmax - vmin);
+        if (bidx == INT_MAX || ratio_less(num, L, bnum, bL)) {  // strictly smaller: the first of equal minima stays
+          bidx = i;
+          bnum = num;
+          bL = L;
+          bdx = (int)dx;
+          bdy = (int)dy;
+          bumin = umin;
+          bumax = umax;
+          bvmin = vmin;
+          bvmax = vmax;
+        }
       }
-      const long num = (umax - umin) * (vmax - vmin);
-      // num / L < bnum / bL, exactly
-      if (!have || (unsigned __int128)(unsigned long)num * (unsigned long)bL <
-                       (unsigned __int128)(unsigned long)bnum * (unsigned long)L) {
-        have = true;
-        bnum = num;
-        bL = L;
-        bdx = (int)dx;
-        bdy = (int)dy;
-        bumin = umin;
-        bumax = umax;
-        bvmin = vmin;
-        bvmax = vmax;
+      long rnum = bnum, rL = bL;
+      int ridx = bidx;
+      for (int off = 32; off > 0; off >>= 1) {
+        const long onum = shfl_xor_long(rnum, off), oL = shfl_xor_long(rL, off);
+        const int oidx = __shfl_xor(ridx, off);
+        bool take = false;
+        if (oidx != INT_MAX) {
+          if (ridx == INT_MAX)
+            take = true;
+          else if (ratio_less(onum, oL, rnum, rL))
+            take = true;
+          else if (!ratio_less(rnum, rL, onum, oL) && oidx < ridx)
+            take = true;
+        }
+        if (take) {
+          rnum = onum;
+          rL = oL;
+          ridx = oidx;
+        }
+      }
+      const int wl = ridx & 63;  // the lane whose own first minimum is the global one
+      bnum = shfl_long(bnum, wl);
+      bL = shfl_long(bL, wl);
+      bumin = shfl_long(bumin, wl);
+      bumax = shfl_long(bumax, wl);
+      bvmin = shfl_long(bvmin, wl);
+      bvmax = shfl_long(bvmax, wl);
+      bdx = __shfl(bdx, wl);
+      bdy = __shfl(bdy, wl);
+    }
+    if (lane != 0) continue;
+    float bx[4], by[4];
+    if (n == 1) {
+      for (int i = 0; i < 4; ++i) {
+        bx[i] = (float)H[0].x;
+        by[i] = (float)H[0].y;
+      }
+    } else if (n == 2) {
+      bx[0] = bx[1] = (float)H[0].x;
+      by[0] = by[1] = (float)H[0].y;
+      bx[2] = bx[3] = (float)H[1].x;
+      by[2] = by[3] = (float)H[1].y;
+    } else {
+      const long us[4] = {bumin, bumax, bumax, bumin};
+      const long vs[4] = {bvmin, bvmin, bvmax, bvmax};
+      for (int i = 0; i < 4; ++i) {
+        bx[i] = (float)((double)(us[i] * bdx - vs[i] * bdy) / (double)bL);
+        by[i] = (float)((double)(us[i] * bdy + vs[i] * bdx) / (double)bL);
       }
     }
-    const long us[4] = {bumin, bumax, bumax, bumin};
-    const long vs[4] = {bvmin, bvmin, bvmax, bvmax};
+    // diamond test (detection.py:276-281), float32 arithmetic
+    const float wx = bx[0] - bx[1], wy = by[0] - by[1];
+    const float hx = bx[1] - bx[2], hy = by[1] - by[2];
+    const float wlen = sqrtf(wx * wx + wy * wy);
+    const float hlen = sqrtf(hx * hx + hy * hy);
+    const float ratio = fmaxf(wlen, hlen) / (fminf(wlen, hlen) + 1e-5f);
+    float ox[4], oy[4];
+    if (fabsf(1.f - ratio) <= 0.1f) {
+      ox[0] = (float)l; oy[0] = (float)t;
+      ox[1] = (float)r; oy[1] = (float)t;
+      ox[2] = (float)r; oy[2] = (float)b;
+      ox[3] = (float)l; oy[3] = (float)b;
+    } else {
+      int k = 0;
+      float best = bx[0] + by[0];
+      for (int i = 1; i < 4; ++i) {
+        const float s = bx[i] + by[i];
+        if (s < best) {
+          best = s;
+          k = i;
+        }
+      }
+      for (int i = 0; i < 4; ++i) {
+        ox[i] = bx[(i + k) & 3];
+        oy[i] = by[(i + k) & 3];
+      }
+    }
     for (int i = 0; i < 4; ++i) {
-      bx[i] = (float)((double)(us[i] * bdx - vs[i] * bdy) / (double)bL);
-      by[i] = (float)((double)(us[i] * bdy + vs[i] * bdx) / (double)bL);
+      out[2 * i] = 2.f * ox[i];      // detection.py:285
+      out[2 * i + 1] = 2.f * oy[i];
     }
-  }
-  // diamond test (detection.py:276-281), float32 arithmetic
-  const float wx = bx[0] - bx[1], wy = by[0] - by[1];
-  const float hx = bx[1] - bx[2], hy = by[1] - by[2];
-  const float wlen = sqrtf(wx * wx + wy * wy);
-  const float hlen = sqrtf(hx * hx + hy * hy);
-  const float ratio = fmaxf(wlen, hlen) / (fminf(wlen, hlen) + 1e-5f);
-  float ox[4], oy[4];
-  if (fabsf(1.f - ratio) <= 0.1f) {
-    ox[0] = (float)l; oy[0] = (float)t;
-    ox[1] = (float)r; oy[1] = (float)t;
-    ox[2] = (float)r; oy[2] = (float)b;
-    ox[3] = (float)l; oy[3] = (float)b;
-  } else {
-    int k = 0;
-    float best = bx[0] + by[0];
-    for (int i = 1; i < 4; ++i) {
-      const float s = bx[i] + by[i];
-      if (s < best) {
-        best = s;
-        k = i;
-      }
-    }
-    for (int i = 0; i < 4; ++i) {
-      ox[i] = bx[(i + k) & 3];
-      oy[i] = by[(i + k) & 3];
-    }
-  }
-  for (int i = 0; i < 4; ++i) {
-    out[2 * i] = 2.f * ox[i];      // detection.py:285
-    out[2 * i + 1] = 2.f * oy[i];
   }
 }
 
@@ -711,7 +895,7 @@ int postproc_get_boxes(kocr_ctx* ctx, const float* d_heat, int N, int h, int w, 
     hipLaunchKernelGGL(k_merge8, grid_for(a.total), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_flatten_select, grid_for(a.total), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_row_extents, grid_for((size_t)a.total_rows * 64), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_boxes, grid_for(ncomp, 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_boxes, grid_for(ncomp, 1), dim3(64), 0, s, a);
   }
   KOCR_HIP(ctx, hipGetLastError());
   if (n_empty_out && !dev) {

@@ -106,3 +106,30 @@ def test_detect_entry_point_equals_two_step(ctx, craft_weights):
     a = ctx.get_boxes(heat, **kw)
     b = ctx.detect(img, **kw)
     assert len(a[0]) > 0 and len(a[0]) == len(b[0]) and np.array_equal(a[0], b[0])
+
+
+def _hull_shapes():
+    """One 700 x 1000 heat-map whose components aim at the hull kernel (K13): a digital diamond of 601 rows (every row
+    carries two points that can be hull vertices: more candidates than the kernel's LDS chains hold -> the global-scratch
+    path), an ellipse (a hull of many vertices in LDS), a 1-pixel line of 650 rows (reduces to two candidates), a small
+    diamond (collinear boundary points), a thin slanted bar and a small square."""
+    h, w = 700, 1000
+    yy, xx = np.mgrid[0:h, 0:w]
+    text = np.zeros((h, w), np.float32)
+    text[np.abs(xx - 310) + np.abs(yy - 320) <= 300] = 1.0                      # large diamond
+    text[((xx - 780) / 120.0) ** 2 + ((yy - 250) / 200.0) ** 2 <= 1.0] = 1.0    # ellipse
+    text[30:680, 950] = 1.0                                                    # vertical line
+    text[np.abs(xx - 760) + np.abs(yy - 560) <= 40] = 1.0                       # small diamond
+    text[(np.abs((yy - 560) - 0.37 * (xx - 880)) <= 2.0) & (np.abs(xx - 880) <= 45)] = 1.0  # slanted bar
+    text[660:666, 640:646] = 1.0                                               # square
+    return np.stack([text, np.zeros_like(text)], -1)[None]
+
+
+def test_hull_kernel_shapes_vs_oracle(ctx):
+    from oracle import postproc
+
+    y = _hull_shapes()
+    want = postproc.get_boxes(y)
+    got = ctx.get_boxes(y)
+    assert len(want[0]) == 6
+    _check(got, want)

@@ -86,6 +86,7 @@ struct ConvLayer {
   int ds_wexp = 0;
   unsigned short* d_first = nullptr;  // 3 -> <= 64 first layer on raw uint8, im2col K = 27 -> 32, conv_hsplit.hip order
   unsigned short* d_hs = nullptr;  // 3x3, <= 32 couts: 3-way bf16 split, conv_hsplit.hip order
+  unsigned short* d_hs16 = nullptr;  // the same for <= 16 couts: tap pairs on the 16x16x32 MFMA (conv_hs16_kernel)
   unsigned short* d_k5 = nullptr;  // 5x5, 16 couts, small images: 3-way bf16 split, conv_k5.hip order
   bool tap_inner = false;  // K order [16-channel group][tap][16] (Cin % 16 == 0) instead of [tap][Cin]
   bool ready() const { return d_w != nullptr; }

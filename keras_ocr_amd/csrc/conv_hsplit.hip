@@ -179,6 +179,162 @@ __global__ __launch_bounds__(256, 3) void conv_hs_kernel(HsParams p) {
 }
 
 // ===================================================================================================
+// conv_hs16_kernel -- the same for Cout <= 16 (conv_cls.4, 32 -> 16): on conv_hs_kernel's 32-column product tile half of
+// every MFMA was padding (96 TF/s algorithmic against 188 for the 32-cout layers).  v_mfma_f32_16x16x32_bf16 with the
+// WEIGHTS as the A operand (16 couts x 32 k) and the pixels as B (32 k x 16 pixels): a lane ends up with four consecutive
+// couts of one pixel (16-byte stores, a half-wave writes 16 neighbouring pixels).  K = 32 of one MFMA = 16 channels x TWO
+// taps: lanes 0..31 read tap 2j, lanes 32..63 tap 2j + 1 (the next halo pixel, or the first of the next halo row for the
+// pair (2, 3); tap 9 does not exist: zero weights, its lanes re-read tap 8).  Same haloed tile, LDS planes and chunk
+// pipeline as conv_hs_kernel; wave w owns tile rows 2w, 2w + 1 = four 16-pixel M-tiles (16 accumulator registers);
+// per (chunk, pair): 3 weight loads + 12 ds_read_b128 + 24 MFMAs.
+// ===================================================================================================
+__global__ __launch_bounds__(256, 3) void conv_hs16_kernel(HsParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[3 * HS_PLANE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x;
+  t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int n = t / p.tiles_y;
+  const int y0 = ty * HS_TH, x0 = tx * HS_TW;
+  constexpr unsigned OOB = 0x80000000u;
+
+  const float* img = p.in + (size_t)n * p.H * p.W * p.in_cs + p.in_co;
+  const unsigned long long ib = (unsigned long long)img;
+  const unsigned long long ibu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ib >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)ib);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ibu, 0, 0x80000000, 0x00020000);
+
+  unsigned goff[HS_IPT];
+  int ldst[HS_IPT];
+#pragma unroll
+  for (int it = 0; it < HS_IPT; ++it) {
+    const int item = tid + it * 256;
+    const int px = item >> 2, c4 = item & 3;
+    const int hy = px / HS_HW, hx = px - hy * HS_HW;
+    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+    const bool ok = px < HS_NPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    goff[it] = ok ? (unsigned)(((gy * p.W + gx) * p.in_cs + c4 * 4) * 4) : OOB;
+    ldst[it] = px < HS_NPX ? px * HS_PS + c4 * 4 : -1;
+  }
+  auto load_raw = [&](v4f (&raw)[HS_IPT], int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < HS_IPT; ++it)
+      raw[it] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[it], chunk * 64, 0));
+  };
+  auto produce = [&](const v4f (&raw)[HS_IPT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < HS_IPT; ++it) {
+      u2v h, m, l;
+      kocr_split4(raw[it], h, m, l);
+      if (it + 1 < HS_IPT || ldst[it] >= 0) {
+        unsigned short* dst = As + ldst[it];
+        *reinterpret_cast<u2v*>(dst) = h;
+        *reinterpret_cast<u2v*>(dst + HS_PLANE) = m;
+        *reinterpret_cast<u2v*>(dst + 2 * HS_PLANE) = l;
+      }
+    }
+  };
+
+  v4f acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = v4f{0.f, 0.f, 0.f, 0.f};
+  // B operand of M-tile i = (row 2 wave + (i >> 1), columns 16 (i & 1) ..): lane = pixel l15 x k-group g; g & 1 = channel
+  // half, g >> 1 = tap of the pair
+  const int b_lane = ((2 * wave) * HS_HW + l15) * HS_PS + (g & 1) * 8;
+  const int d_next = (g >> 1) ? HS_PS : 0;                  // second tap of a pair: the next halo pixel ...
+  const int d_cross = (g >> 1) ? (HS_HW - 2) * HS_PS : 0;   // ... or, from kx = 2, the first pixel of the next halo row
+  const unsigned short* w_lane = p.wgt + lane * 8;
+  const int nchunks = p.Cin >> 4;
+
+  v4f raw[HS_IPT];
+  load_raw(raw, 0);
+  produce(raw);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) load_raw(raw, c + 1);
+    const unsigned short* wc = w_lane + (size_t)c * 5 * 3 * 512;
+#pragma unroll
+    for (int pr = 0; pr < 5; ++pr) {
+      const int t0 = 2 * pr, ky = t0 / 3, kx = t0 - ky * 3;
+      const int toff = (ky * HS_HW + kx) * HS_PS + (pr == 4 ? 0 : (kx == 2 ? d_cross : d_next));
+      bf8 wv[3], x[4][3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) wv[s] = *reinterpret_cast<const bf8*>(wc + (pr * 3 + s) * 512);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          x[i][s] = *reinterpret_cast<const bf8*>(As + s * HS_PLANE + b_lane + ((i >> 1) * HS_HW + (i & 1) * 16) * HS_PS + toff);
+      // smallest products first (the order of conv_dsplit.hip)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[0], x[i][2], acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[2], x[i][0], acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[1], x[i][1], acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[0], x[i][1], acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[1], x[i][0], acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[0], x[i][0], acc[i], 0, 0, 0);
+    }
+    if (c + 1 < nchunks) {
+      __syncthreads();  // every wave has read this chunk
+      produce(raw);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: 16x16 C/D map: row (cout) = 4 * (lane >> 4) + r, col (pixel of the M-tile) = lane & 15 --------------------
+  float* oimg = p.out + (size_t)n * p.H * p.W * p.out_cs + p.out_co;
+  const bool has_post = p.post_a != nullptr;
+  const bool vec = p.Cout == 16 && (p.out_cs & 3) == 0 && (p.out_co & 3) == 0 && (((uintptr_t)p.out) & 15) == 0;
+  float pa[4], pb[4], qa[4], qb[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int nc = 4 * g + r < p.Cout ? 4 * g + r : p.Cout - 1;
+    pa[r] = p.pre_a[nc];
+    pb[r] = p.pre_b[nc];
+    qa[r] = has_post ? p.post_a[nc] : 1.f;
+    qb[r] = has_post ? p.post_b[nc] : 0.f;
+  }
+  float mxv = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int y = y0 + 2 * wave + (i >> 1), x = x0 + (i & 1) * 16 + l15;
+    const bool inside = y < p.H && x < p.W;
+    v4f o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = acc[i][r] * pa[r] + pb[r];
+      if (p.relu) v = fmaxf(v, 0.f);
+      if (has_post) v = v * qa[r] + qb[r];
+      o[r] = v;
+    }
+    float* dst = oimg + ((size_t)y * p.W + x) * p.out_cs + 4 * g;
+    if (inside) {
+      if (vec) {
+        *reinterpret_cast<v4f*>(dst) = o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mxv = fmaxf(mxv, fabsf(o[r]));
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * g + r < p.Cout) {
+            dst[r] = o[r];
+            mxv = fmaxf(mxv, fabsf(o[r]));
+          }
+      }
+    }
+  }
+  if (p.amax_out) kocr_amax_update(p.amax_out, mxv);
+}
+
+// ===================================================================================================
 // conv_first_kernel -- CRAFT's first layer (basenet.slice1.0, detection.py:312-322: 3x3, 3 -> 64, BN, ReLU) straight from
 // the uint8 image, on the same bf16x3 split arithmetic.  K = 27 (tap, channel) values per output pixel, padded to 32 =
 // two 16-k MFMA steps: the fp32-MFMA kernel that ran it before spent 48 padded K per pixel on the slow pipe (43 % busy,
@@ -382,6 +538,23 @@ int prepare_hsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) 
   KOCR_TRY(ctx->dev_alloc(&d, u.size() * sizeof(unsigned short)));
   KOCR_HIP(ctx, hipMemcpy(d, u.data(), u.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   L.d_hs = (unsigned short*)d;
+  if (Cout <= 16) {  // conv_hs16_kernel: [Cin/16][5 tap pairs][3 pieces][64 lanes][8]
+    std::vector<unsigned short> v((size_t)(Cin / 16) * 5 * 3 * 512, 0);
+    for (int c = 0; c < Cin; ++c)
+      for (int tap = 0; tap < 9; ++tap)
+        for (int o = 0; o < Cout; ++o) {
+          const float g = w_is_oihw ? w[((size_t)o * Cin + c) * 9 + tap] : w[((size_t)tap * Cin + c) * Cout + o];
+          // MFMA 16x16x32 A operand: lane = (k >> 3) * 16 + row holds k = 8 * (lane >> 4) + j;  k = (tap & 1) * 16 + channel
+          const int k = (tap & 1) * 16 + c % 16, lane = (k >> 3) * 16 + o, j = k & 7;
+          unsigned short pc[3];
+          kocr_split3_host(g, pc);
+          for (int s = 0; s < 3; ++s) v[((((size_t)(c / 16) * 5 + tap / 2) * 3 + s) * 64 + lane) * 8 + j] = pc[s];
+        }
+    void* d16 = nullptr;
+    KOCR_TRY(ctx->dev_alloc(&d16, v.size() * sizeof(unsigned short)));
+    KOCR_HIP(ctx, hipMemcpy(d16, v.data(), v.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    L.d_hs16 = (unsigned short*)d16;
+  }
   return KOCR_OK;
 }
 
@@ -416,16 +589,22 @@ int launch_conv_hsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   p.amax_out = out.amax;
   const size_t M = in.pixels();
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
+  static const bool no16 = getenv("KOCR_HS16") && atoi(getenv("KOCR_HS16")) == 0;
+  const bool use16 = L.d_hs16 && !no16;  // <= 16 couts: the 16-wide product tile
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_hs_256x32:%s", L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_hs_256x%d:%s", use16 ? 16 : 32, L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_hs_256x32");
+    snprintf(nm, sizeof nm, "conv_hs_256x%d", use16 ? 16 : 32);
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   ProfScope ps(ctx, nm, flops, bytes);
   const size_t grid = (size_t)in.N * p.tiles_y * p.tiles_x;
-  hipLaunchKernelGGL(conv_hs_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, p);
+  if (use16) {
+    p.wgt = L.d_hs16;
+    hipLaunchKernelGGL(conv_hs16_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, p);
+  } else
+    hipLaunchKernelGGL(conv_hs_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }

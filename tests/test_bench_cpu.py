@@ -88,4 +88,5 @@ def test_pmc_counter_parsing_and_corrections(tmp_path):
     assert k.pmc.find_kernel(agg.keys(), "conv_w4s_256x128_pool").startswith("void conv_w43_kernel<1")
     assert k.pmc.find_kernel(agg.keys(), "conv_hs_256x32") is None and k.pmc.find_kernel(agg.keys(), "no_such_row") is None
     assert k.perfmodel.issued_per_algorithmic("conv_hs_256x32")["factor"] == 6.0
+    assert abs(k.perfmodel.issued_per_algorithmic("conv_hs_256x16")["factor"] - 60.0 / 9.0) < 1e-12
     assert abs(k.perfmodel.issued_per_algorithmic("conv_k5_352x16:stn_conv_1")["factor"] - 6.24) < 1e-12

@@ -8,6 +8,7 @@ once per process): the fp64-bounded convolution tests and the CRAFT heat-map-vs-
   KOCR_W43V=0    no vertical-reuse arrangement -> wide layers on conv_w43_kernel (round 2's dominant kernel)
   KOCR_LINFOLD=0 KOCR_UPFOLD=0                 -> the layer-by-layer CRAFT schedule (slice5.1, slice5.2, resize + concat)
   KOCR_K5=0      no 5x5 / 16-cout kernel    -> the recogniser's stn_conv_1 on the fp32 MFMA kernel
+  KOCR_HS16=0    no 16-wide product tile    -> conv_cls.4 on conv_hs_kernel's 32-column tile
 
 (these paths were reached by the driver's suite only through the shapes that happen to select
 them.)  Each configuration is one pytest child process over the same test files, same bounds."""
@@ -29,6 +30,7 @@ CONFIGS = [
     {"KOCR_W43V": "0"},
     {"KOCR_LINFOLD": "0", "KOCR_UPFOLD": "0"},
     {"KOCR_K5": "0"},
+    {"KOCR_HS16": "0"},
 ]
 
 

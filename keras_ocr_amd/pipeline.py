@@ -12,12 +12,11 @@ def decode_labels(alphabet, labels):
     labels = np.asarray(labels)
     if labels.size == 0:
         return [""] * len(labels)
-    if any(len(c) != 1 or c == "\0" for c in alphabet):
-        skip = (len(alphabet), -1)
-        return ["".join([alphabet[i] for i in row if i not in skip]) for row in labels.tolist()]
     n = len(alphabet)
-    if labels.min() < -1 or labels.max() > n:
-        raise IndexError("label outside the alphabet")
+    if any(len(c) != 1 or c == "\0" for c in alphabet) or labels.min() < -1 or labels.max() > n:
+        # multi-character entries, or indices the reference's own expression would wrap / reject: evaluate that expression
+        skip = (n, -1)
+        return ["".join([alphabet[i] for i in row if i not in skip]) for row in labels.tolist()]
     table = np.array([ord(c) for c in alphabet] + [0], "<u4")
     text = table[np.where(labels < 0, n, labels)].tobytes().decode("utf-32-le")
     w = labels.shape[1]

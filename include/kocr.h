@@ -179,21 +179,27 @@ int kocr_conv2d_nhwc(kocr_ctx* ctx, const float* in, int N, int H, int W, int Ci
                      const float* post_a, const float* post_b, float* out);
 
 /* ---- arithmetic of the wide convolutions --------------------------------------------- */
-/* The 3x3 / 1x1 / dilated convolutions with Cout > 32 run on the 16-bit matrix cores with fp32
- * operands split into 16-bit pieces and fp32 accumulation:
- *   KOCR_SPLIT_BF16X3 (default): 3 bf16 pieces, exact split, 6 products (dropped terms < 2^-21 |ab| worst case,
- *                                2^-25 |ab| rms);
- *   KOCR_SPLIT_F16X2: 2 fp16 pieces, round-to-nearest split (<= 2^-22 |a| worst case, 2^-24 rms, while the low piece is a
- *                     normal fp16), 3 products, exact power-of-two scaling from the tensor's tracked
- *                     max |x| -- about 1.3x faster end to end, same measured error against fp64.
- * The environment variable KOCR_SPLIT=bf16|f16 sets the initial mode of new contexts.  There is no
- * reference counterpart (the reference computes in TensorFlow fp32). */
+/* The 3x3 / 1x1 / dilated convolutions with Cout > 32 run on the 16-bit matrix cores with fp32 operands split into
+ * 16-bit pieces and fp32 accumulation:
+ *   KOCR_SPLIT_BF16X3: 3 bf16 pieces, exact split, 6 products everywhere (dropped terms < 2^-21 |ab| worst case,
+ *                      2^-25 |ab| rms; no operand bit is dropped);
+ *   KOCR_SPLIT_F16X2:  the Winograd F(4,3) layers whose images tile as 4 x 64 or 8 x 32 pixels (the bulk of CRAFT) run on
+ *                      the fp16 cores instead: 2 fp16 pieces per operand (round to nearest, <= 2^-22 |a| worst case, 2^-24
+ *                      rms, while the low piece is a normal fp16), 3 products, operands scaled by exact powers of two --
+ *                      per IMAGE from the max |x| its producer tracked, per output channel for the weights -- so a result
+ *                      never depends on the rest of the batch.  Same measured error against fp64 as bf16x3; half the
+ *                      matrix-core work of those layers.  Every other layer runs as in KOCR_SPLIT_BF16X3;
+ *   KOCR_SPLIT_F16X1:  REDUCED PRECISION fast mode (opt-in, never a default): the same layers with ONE fp16 piece per
+ *                      operand and one product (relative operand error 2^-12); tolerance stated in DESIGN.md section 3.
+ * The environment variable KOCR_SPLIT=bf16|f16|f16x1 sets the initial mode of new contexts.  There is no reference
+ * counterpart (the reference computes in TensorFlow fp32). */
 #define KOCR_SPLIT_BF16X3 0
 #define KOCR_SPLIT_F16X2 1
+#define KOCR_SPLIT_F16X1 2
 int kocr_set_split_mode(kocr_ctx* ctx, int mode);
 int kocr_get_split_mode(const kocr_ctx* ctx);
 
-/* CRAFT schedule (bf16x3 mode): two chains of convolutions without a non-linearity between them are evaluated in
+/* CRAFT schedule (every arithmetic mode): two chains of convolutions without a non-linearity between them are evaluated in
  * their algebraically identical shorter form ("Folded linear layers"):
  * fold_linear_chain -- slice5.1 -> slice5.2 -> upconv1.conv.0 (detection.py:349-353, :106-108) as one composed
  * dilated 3x3 + a 1x1 over s4; fold_upsample -- conv1x1(concat(resize(y), skip)) (detection.py:106-115, 380-389)

@@ -40,11 +40,13 @@ int kocr_ctx::amax_begin() {
   return KOCR_OK;
 }
 
-// Only the fp16x2 kernels read a tensor's tracked max |x| (their exact power-of-two input scale); in bf16x3 mode no slot is
+// Only the fp16 kernels read a tensor's tracked max |x| (their exact power-of-two input scale); in bf16x3 mode no slot is
 // handed out, so the producers' epilogues skip the reduction and the atomic altogether.
-unsigned* kocr_ctx::amax_slot() {
-  if (split_mode != KOCR_SPLIT_F16X2) return nullptr;
-  return (d_amax && amax_used < AMAX_SLOTS) ? d_amax + amax_used++ : nullptr;
+unsigned* kocr_ctx::amax_slots(int n) {
+  if (split_mode == KOCR_SPLIT_BF16X3 || !d_amax || n <= 0 || amax_used + n > AMAX_SLOTS) return nullptr;
+  unsigned* s = d_amax + amax_used;
+  amax_used += n;
+  return s;
 }
 
 int kocr_ctx::dev_alloc(void** out, size_t bytes) {
@@ -122,7 +124,10 @@ int kocr_create(kocr_ctx** out, int hip_device) {
   if (hipGetDeviceCount(&count) != hipSuccess || hip_device < 0 || hip_device >= count) return KOCR_EHIP;
   if (hipSetDevice(hip_device) != hipSuccess) return KOCR_EHIP;
   kocr_ctx* c = new kocr_ctx();
-  if (const char* e = getenv("KOCR_SPLIT")) c->split_mode = (!strcmp(e, "f16") || !strcmp(e, "fp16")) ? KOCR_SPLIT_F16X2 : KOCR_SPLIT_BF16X3;
+  if (const char* e = getenv("KOCR_SPLIT"))
+    c->split_mode = (!strcmp(e, "f16") || !strcmp(e, "fp16") || !strcmp(e, "f16x2")) ? KOCR_SPLIT_F16X2
+                    : (!strcmp(e, "f16x1") || !strcmp(e, "fast"))                     ? KOCR_SPLIT_F16X1
+                                                                                      : KOCR_SPLIT_BF16X3;
   if (const char* e = getenv("KOCR_LINFOLD")) c->opt_linfold = atoi(e) != 0;
   if (const char* e = getenv("KOCR_UPFOLD")) c->opt_upfold = atoi(e) != 0;
   c->device = hip_device;
@@ -213,9 +218,6 @@ int kocr_craft_forward(kocr_ctx* ctx, const void* img, int dtype, int N, int H, 
   int mb = micro_batch > 0 ? micro_batch : 32;  // Keras predict default batch_size (detection.py:779)
   // keep the per-micro-batch workspace under ~64 GiB of the 288 GB HBM
   while (mb > 1 && craft_workspace_bytes(mb, H, W) > ((size_t)96 << 30)) mb = (mb + 1) / 2;
-  // fp16x2 split: the exact input scale of a convolution follows the max |x| of the tensor it reads, so one IMAGE
-  // per forward makes every image's result independent of what else is in the batch
-  if (ctx->split_mode == KOCR_SPLIT_F16X2) mb = 1;
   mb = std::min(mb, N);
   const size_t esz = dtype == KOCR_U8 ? 1 : 4;
   const size_t in_img = (size_t)H * W * 3 * esz;
@@ -465,7 +467,7 @@ int kocr_conv2d_nhwc(kocr_ctx* ctx, const float* in, int N, int H, int W, int Ci
 
 int kocr_set_split_mode(kocr_ctx* ctx, int mode) {
   if (!ctx) return KOCR_EINVAL;
-  if (mode != KOCR_SPLIT_BF16X3 && mode != KOCR_SPLIT_F16X2) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_set_split_mode: unknown mode");
+  if (mode != KOCR_SPLIT_BF16X3 && mode != KOCR_SPLIT_F16X2 && mode != KOCR_SPLIT_F16X1) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_set_split_mode: unknown mode");
   ctx->split_mode = mode;
   return KOCR_OK;
 }

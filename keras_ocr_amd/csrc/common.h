@@ -43,10 +43,11 @@ struct Tensor {
   int N = 0, H = 0, W = 0, C = 0;
   int cs = 0;  // channel stride of the underlying buffer (floats per pixel)
   int co = 0;  // channel offset of this view inside the buffer
-  // Optional device slot holding (as uint bits of a non-negative float) an UPPER BOUND of max |x| over
-  // everything written into the underlying buffer during this forward; every producer kernel atomicMax-es
-  // into it.  The fp16-split convolutions derive their exact power-of-two input scale from it; a tensor
-  // without a slot is reduced on demand (launch_absmax).  Slices / views share the buffer's slot.
+  // Optional device slots, ONE PER IMAGE (amax[n], n < N), each holding (as uint bits of a non-negative float) an UPPER
+  // BOUND of max |x| over everything written into image n of the underlying buffer during this forward; every producer
+  // kernel atomicMax-es into them.  The fp16 F(4,3) convolutions (conv_w43h.hip) derive the exact power-of-two input scale
+  // of an image from its slot -- per image, so that a result never depends on the rest of the batch; a tensor without
+  // slots is reduced on demand (launch_absmax).  Slices / views share the buffer's slots.
   unsigned* amax = nullptr;
   size_t pixels() const { return (size_t)N * H * W; }
   Tensor slice(int off, int c) const {
@@ -75,15 +76,15 @@ struct ConvLayer {
   int wino_cout_pad = 0;
   unsigned short* d_ws = nullptr;  // Winograd F(2,3) weights, 3-way bf16 split, conv_wsplit.hip order (Cout > 32)
   int ws_cout_pad = 0;
-  unsigned short* d_ws16 = nullptr;  // the same, 2-way fp16 split of U * 2^ws_wexp (fp16x2 mode)
-  int ws_wexp = 0;
-  int ws16_kb = 1;  // 16-channel blocks per K-step of the fp16 Winograd weights' layout (2 when Cin % 32 == 0)
   unsigned short* d_w4 = nullptr;  // Winograd F(4,3) weights, 3-way bf16 split, conv_w43.hip order (Cout > 64, Cin % 32 == 0)
   int w4_cout_pad = 0;
+  // the same weights for the fp16 kernels (conv_w43h.hip): U * 2^wexp[o] split into two fp16 pieces (round to nearest), the
+  // per-cout exponent chosen so that max |U 2^wexp| over the cout's weights lies in [2^14, 2^15); d_pre_a_h[o] =
+  // pre_a[o] * 2^-wexp[o] undoes it in the epilogue
+  unsigned short* d_w4h = nullptr;
+  float* d_pre_a_h = nullptr;
   unsigned short* d_ds = nullptr;  // direct-conv weights, 3-way bf16 split, conv_dsplit.hip order
   int ds_cout_pad = 0;
-  unsigned short* d_ds16 = nullptr;  // 2-way fp16 split of w * 2^ds_wexp
-  int ds_wexp = 0;
   unsigned short* d_first = nullptr;  // 3 -> <= 64 first layer on raw uint8, im2col K = 27 -> 32, conv_hsplit.hip order
   unsigned short* d_hs = nullptr;  // 3x3, <= 32 couts: 3-way bf16 split, conv_hsplit.hip order
   unsigned short* d_hs16 = nullptr;  // the same for <= 16 couts: tap pairs on the 16x16x32 MFMA (conv_hs16_kernel)
@@ -115,7 +116,7 @@ struct kocr_ctx {
   std::string err;
   void set_err(const std::string& s) { err = s; }
 
-  int split_mode = 0;  // KOCR_SPLIT_BF16X3 / KOCR_SPLIT_F16X2
+  int split_mode = 0;  // KOCR_SPLIT_BF16X3 / KOCR_SPLIT_F16X2 / KOCR_SPLIT_F16X1
   // CRAFT schedule options (craft.cpp: folded linear layers); read ONCE from KOCR_LINFOLD / KOCR_UPFOLD when the
   // context is created, changed through kocr_set_schedule
   bool opt_linfold = true, opt_upfold = true;
@@ -123,9 +124,10 @@ struct kocr_ctx {
   // max-|x| slots of the tensors of the current forward (see Tensor::amax): zeroed by amax_begin()
   unsigned* d_amax = nullptr;
   int amax_used = 0;
-  static constexpr int AMAX_SLOTS = 256;
+  static constexpr int AMAX_SLOTS = 1 << 16;
   int amax_begin();            // (re)start slot allocation, zero the slots on the ctx stream
-  unsigned* amax_slot();       // next slot (nullptr when exhausted: the consumer then reduces on demand)
+  unsigned* amax_slots(int n); // the next n slots (one per image; nullptr when exhausted or when the arithmetic in use never
+                               // reads them: the consumer then reduces on demand)
 
   // workspace arenas (bump allocated per call, grown on demand): ws = network activations,
   // pp = post-processing per-pixel scratch, pp2 = post-processing canvases, io = staging,
@@ -217,6 +219,12 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
                        bool need_full);
 // conv_w43.hip: Winograd F(4,3) on the bf16 cores (bf16x3 mode; 3.0 issued FLOPs per algorithmic FLOP instead of 4.0)
 int prepare_w43(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
+// conv_w43h.hip: the same algebra on the fp16 cores, operands scaled by exact powers of two (per image / per cout) and
+// split into two fp16 pieces, three products (KOCR_SPLIT_F16X2: 1.5 issued FLOPs per algorithmic FLOP) or cut to ONE
+// fp16 piece, one product (KOCR_SPLIT_F16X1, the reduced-precision fast mode: 0.5).  launch_conv_w43 dispatches to it.
+struct W4Params;
+int prepare_w43h(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, const float* pre_a);
+int launch_w43vh(kocr_ctx* ctx, W4Params& p, bool fuse, int geo, int pieces);
 bool w43_applicable(const kocr_ctx* ctx, const ConvLayer& L, const Tensor& in);
 int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
                     bool need_full);
@@ -243,9 +251,9 @@ int launch_maxpool2x2(kocr_ctx* ctx, const Tensor& in, const Tensor& out, int ro
 int launch_maxpool3x3s1(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
 int launch_resize_bilinear(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
 int launch_copy_channels(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
-// max |x| of a tensor into a slot (atomicMax; the slot is NOT cleared), and slot-to-slot propagation
-int launch_absmax(kocr_ctx* ctx, const Tensor& t, unsigned* slot);
-int launch_amax_copy(kocr_ctx* ctx, const unsigned* from, unsigned* to);
+// per-image max |x| of a tensor into t.N slots (atomicMax; the slots are NOT cleared), and slot-to-slot propagation
+int launch_absmax(kocr_ctx* ctx, const Tensor& t, unsigned* slots);
+int launch_amax_copy(kocr_ctx* ctx, const unsigned* from, unsigned* to, int n);
 // conv_cls.6 + conv_cls.8 of the CRAFT head in one pass (16 -> 16 ReLU -> 2), heat-map written densely
 int launch_head_tail(kocr_ctx* ctx, const ConvLayer& L6, const ConvLayer& L8, const Tensor& in, float* d_heat);
 

@@ -394,14 +394,41 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
             acc[g][m][r] = o;
           }
       if (p.amax_out) {
-        float mx = 0.f;
+        // per-image max |x| (Tensor::amax[n]): the wave's 256 consecutive pixels lie inside one image unless H W is not a
+        // multiple of 256 -- then every image the wave touches gets the maximum over ITS pixels only (a slot must not
+        // depend on the neighbouring image, nor on the rows past the end of the tensor)
+        const long w0 = pm0 + (long)wm * 256;
+        const long wend = w0 + 256 < (long)p.Mtotal ? w0 + 256 : (long)p.Mtotal;
+        if (wend > w0) {
+          const int hw = p.H * p.W;
+          const int n_lo = __builtin_amdgcn_readfirstlane((int)(w0 / hw)), n_hi = __builtin_amdgcn_readfirstlane((int)((wend - 1) / hw));
+          if (n_lo == n_hi && wend == w0 + 256) {
+            float mx = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int m = 0; m < 2; ++m)
+              for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[g][m][r]));
-        kocr_amax_update(p.amax_out, n < p.Cout ? mx : 0.f);
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[g][m][r]));
+            kocr_amax_update(p.amax_out + n_lo, n < p.Cout ? mx : 0.f);
+          } else {
+            for (int ni = n_lo; ni <= n_hi; ++ni) {
+              const long i0 = (long)ni * hw, i1 = i0 + hw;
+              const int lo = (int)((i0 > w0 ? i0 : w0) - w0), hi = (int)((i1 < wend ? i1 : wend) - w0);
+              float mx = 0.f;
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) {
+                    const int rel = (g * 2 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * l5;
+                    if (rel >= lo && rel < hi) mx = fmaxf(mx, fabsf(acc[g][m][r]));
+                  }
+              kocr_amax_update(p.amax_out + ni, n < p.Cout ? mx : 0.f);
+            }
+          }
+        }
       }
       const int ocs4 = p.out_cs * 4;
       const long rem = ((long)p.Mtotal - pm0) * ocs4;  // stores past the end of the tensor are dropped
@@ -451,35 +478,6 @@ int prepare_dsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) 
   KOCR_HIP(ctx, hipMemcpy(d, u.data(), u.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   L.d_ds = (unsigned short*)d;
 
-  // fp16x2 copy: w * 2^wexp split by round-to-nearest into two fp16, |w 2^wexp| < 2^13
-  float wmax = 0.f;
-  const size_t nw = (size_t)Cout * Cin * ntaps;
-  for (size_t i = 0; i < nw; ++i) wmax = std::max(wmax, std::fabs(w[i]));
-  int wexp = 0;
-  if (wmax > 0.f && std::isfinite(wmax)) {
-    int E;
-    std::frexp(wmax, &E);
-    wexp = 13 - E;
-  }
-  const float wscale = std::ldexp(1.f, wexp);
-  std::vector<unsigned short> v((size_t)(Cin / 16) * ntaps * nt32 * 2 * 64 * 8, 0);
-  for (int c = 0; c < Cin; ++c)
-    for (int tap = 0; tap < ntaps; ++tap)
-      for (int o = 0; o < Cout; ++o) {
-        const float g = (w_is_oihw ? w[((size_t)o * Cin + c) * ntaps + tap] : w[((size_t)tap * Cin + c) * Cout + o]) * wscale;
-        const int k = c % 16, lane = (k >> 3) * 32 + (o & 31), j = k & 7;
-        const size_t step = (size_t)(c / 16) * ntaps + tap;
-        const _Float16 h = (_Float16)g, l = (_Float16)(g - (float)h);
-        unsigned short hb, lb;
-        memcpy(&hb, &h, 2);
-        memcpy(&lb, &l, 2);
-        v[(((step * nt32 + o / 32) * 2 + 0) * 64 + lane) * 8 + j] = hb;
-        v[(((step * nt32 + o / 32) * 2 + 1) * 64 + lane) * 8 + j] = lb;
-      }
-  L.ds_wexp = wexp;
-  KOCR_TRY(ctx->dev_alloc(&d, v.size() * sizeof(unsigned short)));
-  KOCR_HIP(ctx, hipMemcpy(d, v.data(), v.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-  L.d_ds16 = (unsigned short*)d;
   return KOCR_OK;
 }
 
@@ -551,7 +549,7 @@ int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   p.Mtotal = (int)M;
   p.total_tiles = 0;
   p.amax_out = out.amax;
-  const bool half = ctx->split_mode == KOCR_SPLIT_F16X2 && L.d_ds16;
+  const bool half = false;  // round 4: the fp16 arithmetic lives in conv_w43h.hip; the HALF template path is no longer instantiated
   p.up = nullptr;
   p.up_H = p.up_W = 0;
   p.up_sy = p.up_sx = 0.f;
@@ -567,18 +565,6 @@ int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   }
   p.amax_in = nullptr;
   p.w_exp = 0;
-  if (half) {
-    const unsigned* slot = in.amax;
-    if (!slot) {
-      unsigned* tmp = ctx->amax_slot();
-      if (!tmp) KOCR_FAIL(ctx, KOCR_ECAPACITY, "conv " + L.name + ": out of max-|x| slots");
-      KOCR_TRY(launch_absmax(ctx, in, tmp));
-      slot = tmp;
-    }
-    p.amax_in = slot;
-    p.w_exp = L.ds_wexp;
-    p.wgt = L.d_ds16;
-  }
   const int wcls = L.Cout > 64 ? 128 : 64;
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
@@ -596,6 +582,5 @@ int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
       return wcls == 128 ? ds_launch<1, 4, 0, 2>(ctx, p, M) : ds_launch<2, 2, 0, 2>(ctx, p, M);
     return wcls == 128 ? ds_launch<1, 4, 0, 1>(ctx, p, M) : ds_launch<2, 2, 0, 1>(ctx, p, M);
   }
-  if (half) return wcls == 128 ? ds_launch<1, 4, 1>(ctx, p, M) : ds_launch<2, 2, 1>(ctx, p, M);
   return wcls == 128 ? ds_launch<1, 4, 0>(ctx, p, M) : ds_launch<2, 2, 0>(ctx, p, M);
 }

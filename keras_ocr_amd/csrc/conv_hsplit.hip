@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 3) void conv_hs_kernel(HsParams p) {
       if (ok) mxv = fmaxf(mxv, fabsf(acc[m][r]));
     }
   }
-  if (p.amax_out) kocr_amax_update(p.amax_out, mxv);
+  if (p.amax_out) kocr_amax_update(p.amax_out + n, mxv);  // per-image slot (Tensor::amax): the tile lies inside image n
 }
 
 // ===================================================================================================
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256, 3) void conv_hs16_kernel(HsParams p) {
       }
     }
   }
-  if (p.amax_out) kocr_amax_update(p.amax_out, mxv);
+  if (p.amax_out) kocr_amax_update(p.amax_out + n, mxv);  // per-image slot (Tensor::amax): the tile lies inside image n
 }
 
 // ===================================================================================================
@@ -560,7 +560,7 @@ int prepare_hsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) 
 
 bool hsplit_applicable(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in) {
   static const bool off = getenv("KOCR_HSPLIT") && atoi(getenv("KOCR_HSPLIT")) == 0;
-  return !off && ctx->split_mode == KOCR_SPLIT_BF16X3 && L.d_hs && in.cs % 4 == 0 && in.co % 4 == 0 &&
+  return !off && L.d_hs && in.cs % 4 == 0 && in.co % 4 == 0 &&
          ((uintptr_t)in.p & 15) == 0 && in.pixels() >= 4096 && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31) &&
          (size_t)in.H * in.W * 32 * 4 < ((size_t)1 << 31);
 }
@@ -633,7 +633,7 @@ int prepare_first(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
 
 bool first_applicable(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in) {
   static const bool off = getenv("KOCR_FIRST") && atoi(getenv("KOCR_FIRST")) == 0;
-  return !off && ctx->split_mode == KOCR_SPLIT_BF16X3 && L.d_first && (size_t)in.H * in.W * 64 * 4 < ((size_t)1 << 31);
+  return !off && L.d_first && (size_t)in.H * in.W * 64 * 4 < ((size_t)1 << 31);
 }
 
 int launch_conv_first(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8, const float* lut, const Tensor& out) {
@@ -663,5 +663,5 @@ int launch_conv_first(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const
   if (grid > 0x7fffffff) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": too many tiles");
   hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
-  return KOCR_OK;
+  return KOCR_OK;  // (no max-|x| tracking in this kernel: launch_conv_pool reduces the output when it carries slots)
 }

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_k5_kernel(K5Params p) {
       for (int r = 0; r < 4; ++r) mxv = fmaxf(mxv, fabsf(o[r]));
     }
   }
-  if (p.amax_out) kocr_amax_update(p.amax_out, mxv);
+  if (p.amax_out) kocr_amax_update(p.amax_out + n, mxv);  // per-image slot (Tensor::amax)
 }
 
 // ---------------------------------------------------------------------------------------
@@ -198,7 +198,7 @@ int prepare_k5(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
 
 bool k5_applicable(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out) {
   static const bool off = getenv("KOCR_K5") && atoi(getenv("KOCR_K5")) == 0;
-  return !off && ctx->split_mode == KOCR_SPLIT_BF16X3 && L.d_k5 && in.cs % 4 == 0 && in.co % 4 == 0 &&
+  return !off && L.d_k5 && in.cs % 4 == 0 && in.co % 4 == 0 &&
          ((uintptr_t)in.p & 15) == 0 && out.cs % 4 == 0 && out.co % 4 == 0 && ((uintptr_t)out.p & 15) == 0 &&
          in.H * in.W <= K5_MAXM && (in.H + 4) * (in.W + 4) <= K5_MAXHP;
 }

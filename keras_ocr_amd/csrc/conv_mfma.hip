@@ -493,6 +493,7 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
   KOCR_TRY(prepare_wino(ctx, L, w, w_is_oihw));
   KOCR_TRY(prepare_wsplit(ctx, L, w, w_is_oihw));
   KOCR_TRY(prepare_w43(ctx, L, w, w_is_oihw));
+  KOCR_TRY(prepare_w43h(ctx, L, w, w_is_oihw, pre_a));
   KOCR_TRY(prepare_dsplit(ctx, L, w, w_is_oihw));
   KOCR_TRY(prepare_hsplit(ctx, L, w, w_is_oihw));
   KOCR_TRY(prepare_k5(ctx, L, w, w_is_oihw));
@@ -615,8 +616,7 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
   p.nchunks = (L.Kreal + bk - 1) / bk;  // weight rows are zero padded up to Kpad (multiple of 32)
   p.pool_out = nullptr;
   p.tap_inner = L.tap_inner ? 1 : 0;
-  p.amax_out = out.amax;
-  p.amax_pool = pool ? pool->amax : nullptr;
+  p.amax_out = p.amax_pool = nullptr;  // per-image slots (Tensor::amax) are filled by a reduction pass after the launch
   p.ntaps = L.KH * L.KW;
   {
     static const int stg = getenv("KOCR_CONV_STAGGER") ? atoi(getenv("KOCR_CONV_STAGGER")) : 0;
@@ -639,6 +639,7 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
   if (!out.p) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": no output buffer");
   if (in_u8 && lut && conv_variant() == 0 && first_applicable(ctx, L, in)) {  // first layer from raw uint8 on the split path
     KOCR_TRY(launch_conv_first(ctx, L, in, in_u8, lut, out));
+    if (out.amax) KOCR_TRY(launch_absmax(ctx, out, out.amax));
     return pool ? launch_maxpool2x2(ctx, out, *pool) : KOCR_OK;
   }
   if (!in_u8 && !pool && variant == 0 && conv_variant() == 0 && k5_applicable(ctx, L, in, out))  // 5x5, 16 couts, small images
@@ -683,6 +684,7 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
     snprintf(nm, sizeof nm, "conv_%dx%d_m%d%s:%s", BM, L.BN, mode, fuse_pool ? "p" : "", L.name.c_str());
   else
     snprintf(nm, sizeof nm, "conv_mfma_%dx%d_m%d%s", BM, L.BN, mode, fuse_pool ? "_pool" : "");
+  {
   ProfScope ps(ctx, nm, flops, bytes);
   const int mtiles = (int)((M + BM - 1) / BM);
   dim3 grid(mtiles * (L.Cout_pad / L.BN));
@@ -704,5 +706,8 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
   else
     dispatch_variant<256, 32, 4, 1>(variant, mode, grid, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
+  }
+  if (out.amax && (!fuse_pool || need_full)) KOCR_TRY(launch_absmax(ctx, out, out.amax));
+  if (fuse_pool && pool->amax) KOCR_TRY(launch_absmax(ctx, *pool, pool->amax));
   return KOCR_OK;
 }

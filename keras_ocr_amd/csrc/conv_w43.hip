@@ -34,111 +34,8 @@
 // Needs W % 4 == 0 (quads do not straddle rows), Cin % 32 == 0 (even K-step count), Cout > 64; the fused 2x2
 // max-pool (POOL = 1) additionally needs even H and W % 64 == 0 (M-tile = 2 rows x 64 columns, the two rows of a
 // pooling window are accumulator registers r and r + 8 of one lane).  Everything else stays on conv_wsplit.hip.
-#include "split_common.h"
-#include <type_traits>
-#include <cmath>
-#include <algorithm>
-#include <vector>
+#include "w43_common.h"
 
-struct W4Params {
-  const float* in;
-  const unsigned short* wgt;  // [Cin/16][3][Cout_pad/32][6 xi][3 pieces][64 lanes][8] bf16
-  float* out;
-  const float* pre_a;
-  const float* pre_b;
-  const float* post_a;
-  const float* post_b;
-  int H, W, Cin, in_cs, in_co;
-  int Cout, Cout_pad, out_cs, out_co;
-  int relu;
-  int nsteps;  // 3 * Cin / 16 (even)
-  int Mtotal;  // pixels
-  int total_mtiles;  // 32-quad M-tiles
-  float* pool_out;
-  int pool_cs, pool_co, write_full, tiles_per_row;
-  int total_tiles;
-  int n_mpairs;   // pixel tiles (pairs of M-tiles)
-  int dil;        // dilation d (DIL kernels: taps d apart; a quad = 4 outputs d apart in one residue class mod d)
-  int qpr;        // quads per image row = W / 4
-  int m_fastest;  // tile order: 1 = consecutive tiles share the cout block (weights stay in the XCD's L2)
-  unsigned* amax_out;
-  unsigned* amax_pool;
-  // exact division of tile indices (< 2^31) by launch constants without the ~40-instruction integer division sequence:
-  // q = (t + ((n - t) >> 1)) >> sh with t = mulhi(n, mul)  (Granlund-Montgomery); [0] = multiplier, [1] = shift
-  unsigned dv_tpr[2];  // by tiles_per_row
-  unsigned dv_hh[2];   // by H / 2
-  unsigned dv_mp[2];   // by n_mpairs
-  unsigned dv_nb[2];   // by the number of cout blocks
-};
-
-// host: multiplier / shift of the division by d (1 <= d < 2^31)
-static inline void w4_div_magic(unsigned d, unsigned (&out)[2]) {
-  if (d <= 1) {
-    out[0] = 0;
-    out[1] = 0;  // q = (0 + (n >> 1)) >> 0 would be wrong: d == 1 is special-cased on the device through sh == 0 && mul == 0
-    return;
-  }
-  unsigned L = 0;
-  while ((1ull << L) < d) ++L;  // ceil(log2 d), >= 1
-  out[0] = (unsigned)(((1ull << 32) * ((1ull << L) - d)) / d + 1);
-  out[1] = L - 1;
-}
-
-namespace {
-
-__device__ __forceinline__ unsigned w4_fdiv(unsigned n, const unsigned (&dv)[2]) {
-  if (dv[0] == 0 && dv[1] == 0) return n;  // d == 1 (wave-uniform)
-  const unsigned t = __umulhi(n, dv[0]);
-  return (t + ((n - t) >> 1)) >> dv[1];
-}
-
-// interpolation points 0, +-a, +-b, inf (all constants exact in fp32)
-constexpr double W4_PA = 0.625, W4_PB = 1.5;
-constexpr float W4_A = (float)W4_PA, W4_B = (float)W4_PB;
-constexpr float W4_A2 = (float)(W4_PA * W4_PA), W4_B2 = (float)(W4_PB * W4_PB);
-constexpr float W4_A3 = (float)(W4_PA * W4_PA * W4_PA), W4_B3 = (float)(W4_PB * W4_PB * W4_PB);
-constexpr float W4_A2B2 = (float)(W4_PA * W4_PA * W4_PB * W4_PB), W4_A2PB2 = (float)(W4_PA * W4_PA + W4_PB * W4_PB);
-
-constexpr int KH_STRIDE = 256;               // ushorts: 32 rows x 8 channels
-constexpr int PLANE = 2 * 2 * KH_STRIDE;     // one (xi, piece) plane: 2 M-tiles x 2 k halves
-constexpr int BUF = 6 * 3 * PLANE;           // one K-step: 36 KB
-constexpr int LDS_BYTES = 2 * BUF * 2;       // 72 KB
-
-// first pixel of M-tile `mt` (flattened (n, y, x) index); POOL: the M-tile is 2 rows x 64 columns
-template <int POOL>
-__device__ __forceinline__ long w4_mtile_pm0(const W4Params& p, int mt, int& y0, int& x0) {
-  if constexpr (POOL) {
-    const int rp_lin = (int)w4_fdiv((unsigned)mt, p.dv_tpr), cb = mt - rp_lin * p.tiles_per_row;
-    const int hh = p.H >> 1;
-    const int nimg = (int)w4_fdiv((unsigned)rp_lin, p.dv_hh), rp = rp_lin - nimg * hh;
-    y0 = 2 * rp;
-    x0 = cb * 64;
-    return ((long)nimg * p.H + y0) * p.W + x0;
-  } else {
-    y0 = x0 = 0;
-    return (long)mt * 128;
-  }
-}
-
-// tile index -> (pixel tile, cout block)
-__device__ __forceinline__ void w4_decode(const W4Params& p, int tile, int nblk_n, int& mp, int& nt) {
-  if (p.m_fastest) {
-    nt = (int)w4_fdiv((unsigned)tile, p.dv_mp);
-    mp = tile - nt * p.n_mpairs;
-  } else {
-    mp = (int)w4_fdiv((unsigned)tile, p.dv_nb);
-    nt = tile - mp * nblk_n;
-  }
-}
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t w4_rsrc(const float* base, unsigned bytes) {
-  const unsigned long long bb = (unsigned long long)base;
-  const unsigned long long bbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)) << 32) |
-                                 (unsigned)__builtin_amdgcn_readfirstlane((int)bb);
-  return __builtin_amdgcn_make_buffer_rsrc((void*)bbu, 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
-}
-
-}  // namespace
 
 // DBG (developer timing experiments, wrong results; only instantiated with -DKOCR_DEV_SWITCHES): 1 = no input
 // transform / split VALU work, 2 = no weight stream, 4 = no MFMAs, 8 = no LDS operand fetches
@@ -901,18 +798,6 @@ __global__ __launch_bounds__(256) void conv_w43n_kernel(W4Params p) {
 //   just released (two block barriers per tile) and finishes M-tile ph itself.
 // POOL = 1: fused 2x2 max-pool (full-resolution store optional); POOL = 0: full-resolution store only.
 // ===================================================================================================
-// input transform of point xi (fp32, fixed operation order; T = v4f or v2f)
-template <class T>
-__device__ __forceinline__ T w4_transform(const T (&d)[6], int xi) {
-  switch (xi) {
-    case 0: return (W4_A2B2 * d[0] - W4_A2PB2 * d[2]) + d[4];
-    case 1: return (d[4] - W4_B2 * d[2]) + W4_A * (d[3] - W4_B2 * d[1]);
-    case 2: return (d[4] - W4_B2 * d[2]) - W4_A * (d[3] - W4_B2 * d[1]);
-    case 3: return (d[4] - W4_A2 * d[2]) + W4_B * (d[3] - W4_A2 * d[1]);
-    case 4: return (d[4] - W4_A2 * d[2]) - W4_B * (d[3] - W4_A2 * d[1]);
-    default: return (W4_A2B2 * d[1] - W4_A2PB2 * d[3]) + d[5];
-  }
-}
 
 // GEO (round 3): 0 = tile of 2 rows x 128 columns as described above; 1 = tile of 4 rows x 64 columns (H % 4 == 0,
 // W % 64 == 0; the two M-tiles stacked): SIX input rows per FOUR output rows, one full gather item + one HALF item (two
@@ -1259,6 +1144,17 @@ __global__ __launch_bounds__(256) void conv_w43r_kernel(W4Params p) {
       asm volatile("" : "+s"(pcs4));
       int y0, x0;
       const long pm = w4_mtile_pm0<1>(p, tile_mt(mp, ph), y0, x0);
+      if (p.amax_out || p.amax_pool) {  // per-image max |x| (Tensor::amax): the M-tile lies inside one image
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(out[j][r]));
+        mx = live ? mx : 0.f;
+        const unsigned nimg = w4_fdiv((unsigned)pm, p.dv_hw);
+        if (p.amax_out) kocr_amax_update(p.amax_out + nimg, mx);
+        if (p.amax_pool) kocr_amax_update(p.amax_pool + nimg, mx);
+      }
       if (!POOL || p.write_full) {
         const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (pm * p.out_cs + p.out_co), 0x7FFFFFFFu);
         const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
@@ -1664,8 +1560,10 @@ __global__ __launch_bounds__(256) void conv_w43v_kernel(W4Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[j][m][r]));
         mx = live ? mx : 0.f;
-        if (p.amax_out) kocr_amax_update(p.amax_out, mx);
-        if (p.amax_pool) kocr_amax_update(p.amax_pool, mx);
+        int uy, ux;
+        const unsigned nimg = w4_fdiv((unsigned)tile_org(mp, uy, ux), p.dv_hw);  // per-image slots: the tile lies inside one image
+        if (p.amax_out) kocr_amax_update(p.amax_out + nimg, mx);
+        if (p.amax_pool) kocr_amax_update(p.amax_pool + nimg, mx);
       }
       int ty0, tx0;
       const long tpm = tile_org(mp, ty0, tx0);
@@ -1765,7 +1663,7 @@ int prepare_w43(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
 
 bool w43_applicable(const kocr_ctx* ctx, const ConvLayer& L, const Tensor& in) {
   static const bool off = getenv("KOCR_W43") && atoi(getenv("KOCR_W43")) == 0;
-  return !off && ctx->split_mode == KOCR_SPLIT_BF16X3 && L.d_w4 && in.W % (4 * L.dil) == 0 && in.cs % 4 == 0 &&
+  return !off && L.d_w4 && in.W % (4 * L.dil) == 0 && in.cs % 4 == 0 &&
          in.co % 4 == 0 && ((uintptr_t)in.p & 15) == 0 && L.Cin % 32 == 0 && (size_t)in.pixels() < ((size_t)1 << 29);
 }
 
@@ -1885,8 +1783,8 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   p.qpr = in.W / 4;
   p.pool_out = nullptr;
   p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
-  p.amax_out = out.amax;
-  p.amax_pool = fuse ? pool->amax : nullptr;
+  p.amax_out = p.amax_pool = nullptr;  // set below for the arrangements that maintain the per-image slots themselves
+  p.amax_in = nullptr;
   if (fuse) {
     p.pool_out = pool->p;
     p.pool_cs = pool->cs;
@@ -1920,6 +1818,30 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   w4_div_magic((unsigned)p.tiles_per_row, p.dv_tpr);
   w4_div_magic((unsigned)(vgeo == 2 ? in.H / 8 : in.H / 2), p.dv_hh);
   w4_div_magic((unsigned)p.n_mpairs, p.dv_mp);
+  w4_div_magic((unsigned)(in.H * in.W), p.dv_hw);
+  // Per-image max-|x| slots (Tensor::amax): the one-image tiles of the row-reuse / vertical-reuse arrangements maintain
+  // them in their epilogue; the flattened-pixel arrangements leave them to a reduction pass after the launch.
+  const bool tracks = rowreuse || vreuse;
+  if (tracks) {
+    p.amax_out = (!fuse || need_full) ? out.amax : nullptr;
+    p.amax_pool = fuse ? pool->amax : nullptr;
+  }
+  // fp16 arithmetic (conv_w43h.hip) where an fp16 kernel exists for the arrangement; else the exact bf16x3 kernels
+  const int pieces = ctx->split_mode == KOCR_SPLIT_F16X2 ? 2 : ctx->split_mode == KOCR_SPLIT_F16X1 ? 1 : 0;
+  static const bool no_h = getenv("KOCR_W43H") && atoi(getenv("KOCR_W43H")) == 0;
+  const bool use_h = pieces && !no_h && L.d_w4h && vreuse;
+  if (use_h) {
+    const unsigned* slots = in.amax;
+    if (!slots) {  // the producer did not track: reduce the input once, per image
+      unsigned* tmp = ctx->amax_slots(in.N);
+      if (!tmp) KOCR_FAIL(ctx, KOCR_ECAPACITY, "conv " + L.name + ": out of max-|x| slots");
+      KOCR_TRY(launch_absmax(ctx, in, tmp));
+      slots = tmp;
+    }
+    p.amax_in = slots;
+    p.wgt = L.d_w4h;
+    p.pre_a = L.d_pre_a_h;
+  }
   w4_div_magic((unsigned)(p.Cout_pad / (narrow ? 64 : 128)), p.dv_nb);
   // Tile order.  The split weights of one cout block are Cin * 3 * 128 * 36 B; with every cout block of a deep layer in
   // flight on an XCD they overflow its 4 MB L2 and are re-streamed from the Infinity Cache by every round of tiles.
@@ -1929,9 +1851,9 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_w4%s_%s%s:%s", vreuse ? (vgeo == 2 ? "t" : "v") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s:%s", use_h ? (pieces == 2 ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_w4%s_%s%s", vreuse ? (vgeo == 2 ? "t" : "v") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
+    snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s", use_h ? (pieces == 2 ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   {
@@ -1959,7 +1881,9 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
       }
     }
 #endif
-    if (vreuse) {
+    if (use_h) {
+      KOCR_TRY(launch_w43vh(ctx, p, fuse, vgeo, pieces));
+    } else if (vreuse) {
       if (vgeo == 2) {
         KOCR_TRY((w4v_launch<0, 2>(ctx, p)));
       } else {
@@ -1991,6 +1915,10 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
       KOCR_TRY(w4_launch<1>(ctx, p));
     else
       KOCR_TRY(w4_launch<0>(ctx, p));
+  }
+  if (!tracks) {  // flattened-pixel arrangements: per-image max |x| of what was written, for an fp16 consumer
+    if (out.amax && (!fuse || need_full)) KOCR_TRY(launch_absmax(ctx, out, out.amax));
+    if (fuse && pool->amax) KOCR_TRY(launch_absmax(ctx, *pool, pool->amax));
   }
   if (pool && !fuse) return launch_maxpool2x2(ctx, out, *pool);
   return KOCR_OK;

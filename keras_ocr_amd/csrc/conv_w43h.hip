@@ -1,0 +1,624 @@
+// conv_w43h.hip — the Winograd F(4,3) convolutions of conv_w43.hip on the gfx950 FP16 matrix cores (round 4).
+//
+// Why: the bf16x3 kernels issue 3.0 matrix-core FLOPs per algorithmic FLOP (F(4,3): 1/2 of the multiplies x 6 split
+// products) and sit on the chip's power ceiling, so only fewer products per output make them faster.  Two fp16 pieces per
+// operand need three products (a_l b_h + a_h b_l + a_h b_h): 1.5 issued FLOPs per algorithmic FLOP.
+//
+// Arithmetic (KOCR_SPLIT_F16X2, NP = 2; tests/test_split_arith_cpu.py restates it in numpy):
+//   * fp16 has 11 significand bits but only 5 exponent bits, so both operands are first scaled by EXACT powers of two:
+//     the input by 2^e with e = 12 - exponent(max |x| of the image), read from the per-image slot its producer maintains
+//     (Tensor::amax; the F(4,3) input transform grows a value by at most 5.28, so |V 2^e| < 43 300 < 65 504), the weights by
+//     2^wexp[o] per output channel at load time (max |U 2^wexp| in [2^14, 2^15)); the epilogue undoes both in the affine
+//     it applies anyway.  Per IMAGE: a result never depends on what else is in the batch.
+//   * V 2^e = h + l with h = rn_fp16(V 2^e), l = rn_fp16(V 2^e - h): |V 2^e - h - l| <= 2^-22 |V 2^e| (2^-24 rms) while l is
+//     a normal fp16, 2^-25 absolute (scaled units) below -- the second term of the bound tests/test_conv_gpu.py states
+//     (elements more than 2^16 below their image's maximum lose low-piece bits); the same for the weights.
+//   * the three kept products are exact in the fp16 MFMA and accumulate in fp32; the dropped a_l b_l is <= 2^-22 |ab|.
+//   Measured against fp64 (numpy restatement, K = 4608): max 1.3e-7 / rms 2.1e-8 of |x| conv |w| -- the bf16x3 F(4,3)
+//   kernel gives 1.9e-7 / 2.9e-8 on the same data.
+// KOCR_SPLIT_F16X1 (NP = 1) keeps only h (a_h b_h, 0.5 issued FLOPs per algorithmic FLOP): the reduced-precision fast
+// mode, relative error 2^-12 per operand (about 1e-4 of |x| conv |w| on the same probe); never the default.
+//
+// Kernel structure = conv_w43v_kernel (vertical reuse: tile = 4 rows x 64 columns or 8 rows x 32 columns of ONE image x
+// 128 couts, the window's input rows transformed and split once per 16-channel group into LDS, the three vertical taps
+// read them back at a row offset; wave wn owns both M-tiles x 32 couts x six points = 192 accumulators; weights straight
+// from L2 into registers one (channel group, ky) step ahead), with NP operand planes instead of three, PR = 3 (or 1)
+// v_mfma_f32_32x32x16_f16 per point and M-tile instead of six, and the power-of-two scale folded into the constants of the
+// input transform (so it costs two extra multiplies per value and channel group, not one per point).
+#include "w43_common.h"
+
+namespace {
+
+// V_xi * s with the power of two s folded into the (exact) constants of w4_transform: every product with s is exact.
+// The seven scaled constants are plain scalars (kept in registers; a struct of them ended up in scratch memory).
+#define W4H_SCALED_CONSTANTS(sc)                                                                       \
+  const float k_s = (sc), k_sA = (sc) * W4_A, k_sB = (sc) * W4_B, k_sA2 = (sc) * W4_A2, k_sB2 = (sc) * W4_B2, \
+              k_sA2B2 = (sc) * W4_A2B2, k_sA2PB2 = (sc) * W4_A2PB2
+template <class T>
+__device__ __forceinline__ T w4h_transform(const T (&d)[6], int xi, float k_s, float k_sA, float k_sB, float k_sA2, float k_sB2,
+                                           float k_sA2B2, float k_sA2PB2) {
+  switch (xi) {
+    case 0: return (k_sA2B2 * d[0] - k_sA2PB2 * d[2]) + k_s * d[4];
+    case 1: return (k_s * d[4] - k_sB2 * d[2]) + k_sA * (d[3] - W4_B2 * d[1]);
+    case 2: return (k_s * d[4] - k_sB2 * d[2]) - k_sA * (d[3] - W4_B2 * d[1]);
+    case 3: return (k_s * d[4] - k_sA2 * d[2]) + k_sB * (d[3] - W4_A2 * d[1]);
+    case 4: return (k_s * d[4] - k_sA2 * d[2]) - k_sB * (d[3] - W4_A2 * d[1]);
+    default: return (k_sA2B2 * d[1] - k_sA2PB2 * d[3]) + k_s * d[5];
+  }
+}
+
+// two-way fp16 split of two values (one dword per piece)
+__device__ __forceinline__ void kocr_split2_h(const v2f v, unsigned& h, unsigned& l) {
+  const _Float16 h0 = (_Float16)v[0], h1 = (_Float16)v[1];
+  const _Float16 l0 = (_Float16)(v[0] - (float)h0), l1 = (_Float16)(v[1] - (float)h1);
+  h = __builtin_bit_cast(unsigned, hf2{h0, h1});
+  l = __builtin_bit_cast(unsigned, hf2{l0, l1});
+}
+
+constexpr int W4H_TOP = 12;  // scaled inputs lie below 2^13: 5.28 x 2^13 < 65 504
+
+}  // namespace
+
+// DBG (developer timing experiments, WRONG results; only instantiated with -DKOCR_DEV_SWITCHES): 1 = no input transform /
+// split VALU work, 2 = no weight stream, 4 = no MFMAs, 8 = no LDS operand fetches, 16 = no raw input loads, 32 = no block
+// barrier in the K loop
+template <int POOL, int GEO, int NP, int DBG = 0>
+__global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
+  static_assert(GEO == 1 || GEO == 2, "4 x 64 or 8 x 32 tiles");
+  static_assert(!(POOL && GEO == 2), "no fused pooling on 8 x 32 tiles");
+  static_assert(NP == 1 || NP == 2, "one or two fp16 pieces");
+  constexpr int PR = NP == 2 ? 3 : 1;        // products per point and M-tile
+  constexpr int NROWS = GEO == 2 ? 10 : 6;  // input rows of the tile's window
+  constexpr int QPR = GEO == 2 ? 8 : 16;    // quads per tile row
+  constexpr int KHS = QPR * 8;                             // ushorts of one k half of a row: QPR quads x 8 channels
+  constexpr int ROW_STRIDE = 2 * KHS;                      // GEO 1: ushorts per input row of a plane
+  constexpr int PLANE_R = NROWS * 2 * KHS;                 // one (xi, piece) plane
+  constexpr int BUF_R = 6 * NP * PLANE_R;                  // one channel group: 36 / 30 KB (NP = 2)
+  constexpr int TCOLS = QPR * 4;                           // tile columns
+  extern __shared__ __attribute__((aligned(16))) unsigned short As[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = cout sub-tile
+  const int l31 = lane & 31, l5 = lane >> 5;
+  const int nblk_n = p.Cout_pad >> 7;
+  const int total = p.total_tiles;
+  const int ncg = p.Cin >> 4;
+  const int ns = 3 * ncg;
+  const int G = gridDim.x;
+  constexpr unsigned OOB = 0x80000000u;
+
+  // ushort offset of the 16-byte slot (window row w, k half kh, quad q) inside a plane (see conv_w43v_kernel)
+  auto slot = [&](int w, int kh, int q) {
+    if constexpr (GEO == 2)
+      return ((w >> 1) * 2 + kh) * 128 + (w & 1) * 64 + ((q * 8) ^ (kh * 32));
+    else
+      return w * ROW_STRIDE + kh * KHS + ((q * 8) ^ (kh * 32));
+  };
+  // first pixel of pixel tile mp (flattened (n, y, x) index), its row and column
+  auto tile_org = [&](int mp, int& y0, int& x0) -> long {
+    if constexpr (GEO == 2) {
+      const int rq = (int)w4_fdiv((unsigned)mp, p.dv_tpr), cb = mp - rq * p.tiles_per_row;  // (image, row octet), column block
+      const int ho = p.H >> 3;
+      const int nimg = (int)w4_fdiv((unsigned)rq, p.dv_hh), ro = rq - nimg * ho;
+      y0 = 8 * ro;
+      x0 = 32 * cb;
+      return ((long)nimg * p.H + y0) * p.W + x0;
+    } else {
+      const int rq = (int)w4_fdiv((unsigned)mp, p.dv_tpr), cb = mp - rq * p.tiles_per_row;  // rq: (image, row quad)
+      return w4_mtile_pm0<1>(p, 2 * rq * p.tiles_per_row + cb, y0, x0);
+    }
+  };
+
+  // ---- producer state -----------------------------------------------------------------------------------------
+  const int q4 = tid & 3, qd0 = (tid >> 2) & (QPR - 1), r0 = GEO == 2 ? (tid >> 5) : (tid >> 6);
+  const int cp = tid & 7;
+  const int qd1 = GEO == 2 ? ((tid >> 3) & 7) : ((tid >> 3) & 15);
+  const int r1 = GEO == 2 ? 8 + ((tid >> 6) & 1) : 4 + (tid >> 7);
+  int ldst[2];
+  ldst[0] = slot(r0, q4 >> 1, qd0) + (q4 & 1) * 4;
+  ldst[1] = slot(r1, cp >> 2, qd1) + (cp & 3) * 2;
+  struct Geo {
+    unsigned off0[2];  // byte offset of raw pixel d0 of each item
+    unsigned ok;       // bit it: the item's input row lies inside the image (and the tile exists)
+    int e;             // exponent of the image's input scale 2^e
+    const float* base;
+  };
+  auto make_geo = [&](int L, Geo& g, bool& left, bool& right) __attribute__((always_inline)) {
+    int mp, nt_unused;
+    w4_decode(p, kocr_xcd_remap(L < total ? L : 0, total), nblk_n, mp, nt_unused);
+    int y0, x0;
+    const long pm = tile_org(mp, y0, x0);
+    g.base = p.in + (pm * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
+    g.off0[0] = (unsigned)(((r0 * p.W + 4 * qd0) * p.in_cs + q4 * 4) * 4);
+    g.off0[1] = (unsigned)(((r1 * p.W + 4 * qd1) * p.in_cs + cp * 2) * 4);
+    g.ok = ((L < total && (unsigned)(y0 - 1 + r0) < (unsigned)p.H) ? 1u : 0u) |
+           ((L < total && (unsigned)(y0 - 1 + r1) < (unsigned)p.H) ? 2u : 0u);
+    g.e = __builtin_amdgcn_readfirstlane(kocr_scale_exp(p.amax_in + w4_fdiv((unsigned)pm, p.dv_hw), W4H_TOP));
+    // d0 / d5 are column zero padding only at the image edges (W is a multiple of the tile width)
+    left = x0 == 0;
+    right = x0 + TCOLS >= p.W;
+  };
+  Geo gc, gn;
+  bool lc, rc, ln, rn;
+  int ld_cg = 0;  // channel group of the NEXT load inside its tile
+  bool ld_next = false;
+  auto load_item0 = [&](v4f (&raw)[6]) __attribute__((always_inline)) {
+    if constexpr (DBG & 16) return;
+    const int soff = ld_cg * 64;
+    const bool ok = (ld_next ? gn.ok : gc.ok) & 1u;
+    const unsigned off0 = (ld_next ? gn.off0[0] : gc.off0[0]) | (ok ? 0u : OOB);
+    const bool left = (ld_next ? ln : lc) && qd0 == 0, right = (ld_next ? rn : rc) && qd0 == QPR - 1;
+    const unsigned stride = (unsigned)(p.in_cs * 4);
+    const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const unsigned padk = (k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u);
+      if constexpr (DBG & 128)  // the same instructions and bytes, lane-contiguous (1 KB per instruction), cache-resident
+        raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(w4_rsrc(p.in, 0x80000000u), (unsigned)((tid & 63) * 16 + (tid >> 6) * 8192 + k * 1024), soff & 0xFFF, 0));
+      else if constexpr (DBG & 64)  // the same instructions and bytes, but from a 256 KB cache-resident window
+        raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(w4_rsrc(p.in, 0x80000000u), ((off0 + k * stride) | padk) & 0x8003FFF0u, soff & 0xFFF, 0));
+      else
+      raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (off0 + k * stride) | padk, soff, 0));
+    }
+  };
+  auto load_item1 = [&](v2f (&raw)[6]) __attribute__((always_inline)) {
+    if constexpr (DBG & 16) return;
+    const int soff = ld_cg * 64;
+    const bool ok = ((ld_next ? gn.ok : gc.ok) >> 1) & 1u;
+    const unsigned off0 = (ld_next ? gn.off0[1] : gc.off0[1]) | (ok ? 0u : OOB);
+    const bool left = (ld_next ? ln : lc) && qd1 == 0, right = (ld_next ? rn : rc) && qd1 == QPR - 1;
+    const unsigned stride = (unsigned)(p.in_cs * 4);
+    const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const unsigned padk = (k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u);
+      if constexpr (DBG & 128)
+        raw[k] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(w4_rsrc(p.in, 0x80000000u), (unsigned)((tid & 63) * 8 + (tid >> 6) * 8192 + 6144 + k * 512), soff & 0xFFF, 0));
+      else if constexpr (DBG & 64)
+        raw[k] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(w4_rsrc(p.in, 0x80000000u), ((off0 + k * stride) | padk) & 0x8003FFF8u, soff & 0xFFF, 0));
+      else
+      raw[k] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (off0 + k * stride) | padk, soff, 0));
+    }
+  };
+  auto advance = [&]() __attribute__((always_inline)) {
+    const bool wrap = ld_cg == ncg - 1;
+    ld_cg = wrap ? 0 : ld_cg + 1;
+    ld_next = ld_next || wrap;
+  };
+  // sk = 2^e of the channel group being PRODUCED (it may already belong to the next tile's image)
+  auto produce4 = [&](const v4f (&d)[6], unsigned short* bufp, int xi, int it, float sk) __attribute__((always_inline)) {
+    unsigned short* dst = bufp + xi * NP * PLANE_R + ldst[it];
+    if constexpr (DBG & 1) {
+      const u2v r = __builtin_bit_cast(u2v, __builtin_shufflevector(d[xi], d[xi], 0, 1));
+      *reinterpret_cast<u2v*>(dst) = r;
+      if constexpr (NP == 2) *reinterpret_cast<u2v*>(dst + PLANE_R) = r;
+      return;
+    }
+    W4H_SCALED_CONSTANTS(sk);
+    const v4f V = w4h_transform(d, xi, k_s, k_sA, k_sB, k_sA2, k_sB2, k_sA2B2, k_sA2PB2);
+    if constexpr (NP == 2) {
+      u2v h, l;
+      kocr_split4_h(V, h, l);
+      *reinterpret_cast<u2v*>(dst) = h;
+      *reinterpret_cast<u2v*>(dst + PLANE_R) = l;
+    } else {
+      *reinterpret_cast<u2v*>(dst) = u2v{__builtin_bit_cast(unsigned, hf2{(_Float16)V[0], (_Float16)V[1]}),
+                                         __builtin_bit_cast(unsigned, hf2{(_Float16)V[2], (_Float16)V[3]})};
+    }
+  };
+  auto produce2 = [&](const v2f (&d)[6], unsigned short* bufp, int xi, float sk) __attribute__((always_inline)) {
+    unsigned short* dst = bufp + xi * NP * PLANE_R + ldst[1];
+    if constexpr (DBG & 1) {
+      const unsigned r = __float_as_uint(d[xi][0]);
+      *reinterpret_cast<unsigned*>(dst) = r;
+      if constexpr (NP == 2) *reinterpret_cast<unsigned*>(dst + PLANE_R) = r;
+      return;
+    }
+    W4H_SCALED_CONSTANTS(sk);
+    const v2f V = w4h_transform(d, xi, k_s, k_sA, k_sB, k_sA2, k_sB2, k_sA2B2, k_sA2PB2);
+    if constexpr (NP == 2) {
+      unsigned h, l;
+      kocr_split2_h(V, h, l);
+      *reinterpret_cast<unsigned*>(dst) = h;
+      *reinterpret_cast<unsigned*>(dst + PLANE_R) = l;
+    } else {
+      *reinterpret_cast<unsigned*>(dst) = __builtin_bit_cast(unsigned, hf2{(_Float16)V[0], (_Float16)V[1]});
+    }
+  };
+  v4f raw0[6];
+  v2f raw1[6];
+
+  // ---- consumer state ------------------------------------------------------------------------------------------
+  // weights: [16-ch group][ky][32-cout tile][xi][2 pieces][lane][8] fp16 (NP = 1 reads piece 0 only)
+  const int ntiles32 = p.Cout_pad >> 5;
+  const size_t w_step = (size_t)ntiles32 * 12 * 64 * 8;  // ushorts per (channel group, ky) step
+  auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * 4 + wn) * 12 * 64 + lane) * 8; };
+  hf8 bw[6][NP];
+  f16v acc[6][2];
+  const int a_lane = GEO == 2 ? slot(l31 >> 3, l5, l31 & 7) : slot(l31 >> 4, l5, l31 & 15);
+  const int a_lane1 = GEO == 2 ? slot((l31 >> 3) + 1, l5, l31 & 7) : 0;
+  auto load_a = [&](hf8 (&a)[2][NP], const unsigned short* bufp, int ky, int xi) __attribute__((always_inline)) {
+    if constexpr (DBG & 8) return;
+    const unsigned short* plane = bufp + xi * NP * PLANE_R;
+#pragma unroll
+    for (int s = NP - 1; s >= 0; --s)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        int off;
+        if constexpr (GEO == 2) {
+          const int c = ky + 4 * m;
+          off = ((c & 1) ? a_lane1 : a_lane) + (c >> 1) * 256;
+        } else {
+          off = a_lane + (ky + 2 * m) * ROW_STRIDE;
+        }
+        a[m][s] = *reinterpret_cast<const hf8*>(plane + s * PLANE_R + off);
+      }
+  };
+  auto mfma_pt = [&](const hf8 (&a)[2][NP], int xi) __attribute__((always_inline)) {
+    if constexpr (DBG & 4) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int s = 0; s < NP; ++s) acc[xi][m][s] += __builtin_bit_cast(v4f, a[m][s])[0] + __builtin_bit_cast(v4f, bw[xi][s])[0];
+      return;
+    }
+    // smallest terms first; the two M-tiles alternate so consecutive MFMAs are independent
+    if constexpr (NP == 2) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][1], bw[xi][0], acc[xi][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], bw[xi][1], acc[xi][m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], bw[xi][0], acc[xi][m], 0, 0, 0);
+  };
+  // One (channel group, ky) step: consume rows ky .. (+ M-tile offset) of `bufc` (6 points x 2 PR MFMAs); KY = 0 / 1 also
+  // transforms item 0 / 1 of the NEXT channel group into `bufn`, one point per MFMA group.  The weights of the next step
+  // (w_next) replace this step's point by point.  a0 holds point 0 of this step on entry and point 0 of the next step on
+  // exit; for KY = 2 the next step lives in `bufn`, published by the block barrier before the last point's MFMAs.
+  hf8 a0[2][NP], a1[2][NP];
+  auto step = [&](auto ky_c, const unsigned short* bufc, unsigned short* bufn, const unsigned short* w_next, float sk) __attribute__((always_inline)) {
+    constexpr int KY = decltype(ky_c)::value;
+    auto load_b = [&](int xi) __attribute__((always_inline)) {
+      if constexpr (DBG & 2) return;
+#pragma unroll
+      for (int s = 0; s < NP; ++s) bw[xi][s] = *reinterpret_cast<const hf8*>(w_next + (size_t)(xi * 2 + s) * 64 * 8);
+    };
+    auto produce = [&](int xi) __attribute__((always_inline)) {
+      if constexpr (KY == 0) produce4(raw0, bufn, xi, 0, sk);
+      if constexpr (KY == 1) produce2(raw1, bufn, xi, sk);
+    };
+    auto interleave = [&]() __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);  // the LDS fetches of the next point first
+      if constexpr (KY < 2) {
+        constexpr int VPG = (KY == 0 ? 30 : 16) / (2 * PR - 1) + 1;  // VALU per MFMA gap
+#pragma unroll
+        for (int i = 0; i < 2 * PR - 1; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, NP, 0);  // the point's LDS stores
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * PR, 0);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(a1, bufc, KY, 2 * q + 1);
+      produce(2 * q);
+      mfma_pt(a0, 2 * q);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(2 * q);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q < 2) {
+        load_a(a0, bufc, KY, 2 * q + 2);
+        produce(2 * q + 1);
+        mfma_pt(a1, 2 * q + 1);
+        interleave();
+      } else if constexpr (KY < 2) {
+        load_a(a0, bufc, KY + 1, 0);
+        produce(5);
+        mfma_pt(a1, 5);
+        interleave();
+      } else {
+        if constexpr (!(DBG & 32)) __syncthreads();  // the next channel group is complete in bufn, bufc is free
+        load_a(a0, bufn, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pt(a1, 5);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(2 * q + 1);
+    }
+  };
+
+  // ---- prologue ------------------------------------------------------------------------------------------------
+  make_geo(blockIdx.x, gc, lc, rc);
+  make_geo(blockIdx.x + G, gn, ln, rn);
+  load_item0(raw0);
+  load_item1(raw1);
+  advance();  // channel group 0 loaded
+  {
+    int mp0, nt0;
+    w4_decode(p, kocr_xcd_remap(blockIdx.x, total), nblk_n, mp0, nt0);
+    const unsigned short* w0 = w_tile(nt0);
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi)
+#pragma unroll
+      for (int s = 0; s < NP; ++s) bw[xi][s] = *reinterpret_cast<const hf8*>(w0 + (size_t)(xi * 2 + s) * 64 * 8);
+  }
+#pragma unroll
+  for (int xi = 0; xi < 6; ++xi) {
+    produce4(raw0, As, xi, 0, kocr_pow2(gc.e));
+    produce2(raw1, As, xi, kocr_pow2(gc.e));
+  }
+  load_item0(raw0);
+  load_item1(raw1);
+  advance();  // channel group 1 loaded
+  __syncthreads();
+  load_a(a0, As, 0, 0);
+
+  for (int L = blockIdx.x; L < total; L += G) {
+    int mp, nt, mp_n, nt_n;
+    w4_decode(p, kocr_xcd_remap(L, total), nblk_n, mp, nt);
+    w4_decode(p, kocr_xcd_remap(L + G < total ? L + G : L, total), nblk_n, mp_n, nt_n);
+    const unsigned short* w_ptr = w_tile(nt);
+    const unsigned short* w_after = w_tile(nt_n);
+    auto w_at = [&](int s) { return s < ns ? w_ptr + (size_t)s * w_step : w_after; };
+    const float s_cur = kocr_pow2(gc.e), s_nxt = kocr_pow2(gn.e);
+    const float unscale = kocr_pow2(-gc.e);  // this tile's accumulators carry 2^(e + wexp[o]); wexp is folded into pre_a
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][m][r] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int cg = 0; cg < ncg; cg += 2) {
+      // even channel group: consume buffer 0, produce the odd one (this tile's) into buffer 1
+      step(std::integral_constant<int, 0>{}, As, As + BUF_R, w_at(3 * cg + 1), s_cur);
+      load_item0(raw0);
+      step(std::integral_constant<int, 1>{}, As, As + BUF_R, w_at(3 * cg + 2), s_cur);
+      load_item1(raw1);
+      advance();
+      step(std::integral_constant<int, 2>{}, As, As + BUF_R, w_at(3 * cg + 3), s_cur);
+      // odd channel group: consume buffer 1, produce the next even one (the next tile's first after the last pair) into 0
+      const float s_odd = cg + 2 < ncg ? s_cur : s_nxt;
+      step(std::integral_constant<int, 0>{}, As + BUF_R, As, w_at(3 * cg + 4), s_odd);
+      load_item0(raw0);
+      step(std::integral_constant<int, 1>{}, As + BUF_R, As, w_at(3 * cg + 5), s_odd);
+      load_item1(raw1);
+      advance();
+      step(std::integral_constant<int, 2>{}, As + BUF_R, As, w_at(3 * cg + 6), s_odd);
+    }
+    gc = gn;
+    lc = ln;
+    rc = rn;
+    make_geo(L + 2 * G, gn, ln, rn);
+    ld_next = false;
+
+    // ---- epilogue --------------------------------------------------------------------------------------------------
+    {
+      const int n = (nt * 4 + wn) * 32 + l31;
+      const int nc = n < p.Cout ? n : p.Cout - 1;
+      const float pa = p.pre_a[nc] * unscale, pb = p.pre_b[nc];  // pre_a here = pre_a 2^-wexp[o] (ConvLayer::d_pre_a_h)
+      const bool has_post = p.post_a != nullptr;
+      const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
+      const bool live = n < p.Cout;
+      const float lo = p.relu ? 0.f : -INFINITY;
+      auto act = [&](float v) { return fmaxf(v * pa + pb, lo); };
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float m0 = acc[0][m][r], m1 = acc[1][m][r], m2 = acc[2][m][r], m3 = acc[3][m][r], m4 = acc[4][m][r],
+                      m5 = acc[5][m][r];
+          const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+          acc[0][m][r] = act((m0 + s12) + s34);
+          acc[1][m][r] = act(W4_A * d12 + W4_B * d34);
+          acc[2][m][r] = act(W4_A2 * s12 + W4_B2 * s34);
+          acc[3][m][r] = act((W4_A3 * d12 + W4_B3 * d34) + m5);
+        }
+      if (has_post) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][m][r] = acc[j][m][r] * qa + qb;
+      }
+      int ocs4 = p.out_cs * 4;
+      asm volatile("" : "+s"(ocs4));
+      int pcs4 = p.pool_cs * 4;
+      asm volatile("" : "+s"(pcs4));
+      int ty0, tx0;
+      const long tpm = tile_org(mp, ty0, tx0);
+      if (p.amax_out || p.amax_pool) {
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[j][m][r]));
+        mx = live ? mx : 0.f;
+        const unsigned nimg = w4_fdiv((unsigned)tpm, p.dv_hw);  // per-image slots: the tile lies inside one image
+        if (p.amax_out) kocr_amax_update(p.amax_out + nimg, mx);
+        if (p.amax_pool) kocr_amax_update(p.amax_pool + nimg, mx);
+      }
+      if constexpr (GEO == 2) {
+        // M-tile m = rows 4 m .. 4 m + 3 x 8 quads: accumulator register r of lane half l5 is row r >> 2, quad (r & 3) + 4 l5
+        const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (tpm * p.out_cs + p.out_co), 0x7FFFFFFFu);
+        const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int px = (4 * m + (r >> 2)) * p.W + 4 * (r & 3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vo, (px + j) * ocs4, 0);
+          }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          // M-tile m: 2 rows x 64 columns, two rows below M-tile 0
+          const long pm = tpm + (long)2 * m * p.W;
+          const int x0 = tx0;
+          if (!POOL || p.write_full) {
+            const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (pm * p.out_cs + p.out_co), 0x7FFFFFFFu);
+            const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const int px = 4 * ((r & 3) + 8 * (r >> 2));  // quad column (r&3) + 8 (r>>2) [+ 4 l5] of row y
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vo, (px + j) * ocs4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r + 8]), ro, vo, (px + j + p.W) * ocs4, 0);
+              }
+            }
+          }
+          if constexpr (POOL) {
+            // 2x2 max: rows y (r) and y+1 (r+8), columns (0,1) and (2,3) of the quad
+            const long pp0 = ((pm - x0) >> 2) + (x0 >> 1);  // (nimg H/2 + y0/2) W/2 + x0/2: H, W even
+            const __amdgpu_buffer_rsrc_t rp = w4_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
+            const unsigned vp = live ? (unsigned)((8 * l5 * p.pool_cs + n) * 4) : OOB;  // 4 quads = 8 pooled px per l5
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              const int pq = 2 * ((r & 3) + 8 * (r >> 2));
+              const float v0 = fmaxf(fmaxf(acc[0][m][r], acc[1][m][r]), fmaxf(acc[0][m][r + 8], acc[1][m][r + 8]));
+              const float v1 = fmaxf(fmaxf(acc[2][m][r], acc[3][m][r]), fmaxf(acc[2][m][r + 8], acc[3][m][r + 8]));
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * pcs4, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * pcs4, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+// Weights of a layer prepare_w43 accepted (3x3, Cin % 32 == 0, Cout > 32; dilation 1 only here): U = G g in float64,
+// scaled per output channel by 2^wexp[o] (max |U 2^wexp| over the channel's 18 Cin values in [2^14, 2^15)), rounded once to
+// fp32, split into two fp16 pieces by round-to-nearest, packed in conv_w43's B-operand order with two pieces per point.
+int prepare_w43h(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, const float* pre_a) {
+  if (!L.d_w4 || L.dil != 1) return KOCR_OK;
+  const int Cin = L.Cin, Cout = L.Cout;
+  const int cp = L.w4_cout_pad;
+  const int nt32 = cp / 32;
+  const double pa = W4_PA, pb = W4_PB, a2 = pa * pa, b2 = pb * pb;
+  const double na = 2.0 * a2 * (a2 - b2), nb = 2.0 * b2 * (b2 - a2);
+  auto U6 = [&](int c, int ky, int o, double (&U)[6]) {
+    double g[3];
+    for (int kx = 0; kx < 3; ++kx)
+      g[kx] = w_is_oihw ? w[(((size_t)o * Cin + c) * 3 + ky) * 3 + kx] : w[(((size_t)ky * 3 + kx) * Cin + c) * Cout + o];
+    U[0] = g[0] / (a2 * b2);
+    U[1] = (g[0] + pa * g[1] + a2 * g[2]) / na;
+    U[2] = (g[0] - pa * g[1] + a2 * g[2]) / na;
+    U[3] = (g[0] + pb * g[1] + b2 * g[2]) / nb;
+    U[4] = (g[0] - pb * g[1] + b2 * g[2]) / nb;
+    U[5] = g[2];
+  };
+  std::vector<int> wexp(cp, 0);
+  for (int o = 0; o < Cout; ++o) {
+    double umax = 0;
+    for (int c = 0; c < Cin; ++c)
+      for (int ky = 0; ky < 3; ++ky) {
+        double U[6];
+        U6(c, ky, o, U);
+        for (int xi = 0; xi < 6; ++xi) umax = std::max(umax, std::fabs(U[xi]));
+      }
+    if (umax > 0 && std::isfinite(umax)) {
+      int E;
+      std::frexp((float)umax, &E);  // umax = f 2^E, f in [0.5, 1): umax 2^(15 - E) in [2^14, 2^15)
+      wexp[o] = std::max(-100, std::min(100, 15 - E));
+    }
+  }
+  std::vector<unsigned short> u((size_t)(Cin / 16) * 3 * nt32 * 12 * 64 * 8, 0);
+  for (int c = 0; c < Cin; ++c)
+    for (int ky = 0; ky < 3; ++ky)
+      for (int o = 0; o < Cout; ++o) {
+        double U[6];
+        U6(c, ky, o, U);
+        const int k = c % 16, lane = (k >> 3) * 32 + (o & 31), j = k & 7;
+        const size_t step = (size_t)(c / 16) * 3 + ky;
+        for (int xi = 0; xi < 6; ++xi) {
+          const float x = std::ldexp((float)U[xi], wexp[o]);  // the fp32 value the bf16x3 kernels split, times 2^wexp (exact)
+          const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
+          unsigned short hb, lb;
+          memcpy(&hb, &h, 2);
+          memcpy(&lb, &l, 2);
+          u[((((step * nt32 + o / 32) * 6 + xi) * 2 + 0) * 64 + lane) * 8 + j] = hb;
+          u[((((step * nt32 + o / 32) * 6 + xi) * 2 + 1) * 64 + lane) * 8 + j] = lb;
+        }
+      }
+  void* d = nullptr;
+  KOCR_TRY(ctx->dev_alloc(&d, u.size() * sizeof(unsigned short)));
+  KOCR_HIP(ctx, hipMemcpy(d, u.data(), u.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+  L.d_w4h = (unsigned short*)d;
+  std::vector<float> ah(std::max(cp, L.Cout_pad), 1.f);
+  for (int o = 0; o < Cout; ++o) ah[o] = std::ldexp(pre_a ? pre_a[o] : 1.f, -wexp[o]);
+  KOCR_TRY(ctx->upload(&L.d_pre_a_h, ah));
+  return KOCR_OK;
+}
+
+template <int POOL, int GEO, int NP, int DBG = 0>
+static int w4vh_launch(kocr_ctx* ctx, W4Params& p) {
+  constexpr int LDSV = (GEO == 2 ? 2 * 6 * 10 * 128 * 2 : 2 * 6 * 6 * 256 * 2) * NP;  // 2 x 30 / 36 KB (NP = 2)
+  static std::atomic<bool> attr_done[64];
+  const int dev = ctx->device & 63;
+  if (!attr_done[dev]) {
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43vh_kernel<POOL, GEO, NP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSV));
+    attr_done[dev] = true;
+  }
+  static std::atomic<int> n_cus[64];
+  if (!n_cus[dev]) {
+    hipDeviceProp_t prop;
+    KOCR_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    n_cus[dev] = prop.multiProcessorCount;
+  }
+  const int n_cu = n_cus[dev];
+  const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;  // persistent: one block per CU
+  hipLaunchKernelGGL((conv_w43vh_kernel<POOL, GEO, NP, DBG>), dim3(grid), dim3(256), LDSV, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
+// the vertical-reuse arrangement in fp16 arithmetic: p as launch_conv_w43 filled it for conv_w43v_kernel, with wgt =
+// ConvLayer::d_w4h, pre_a = d_pre_a_h and amax_in set.  geo 1 / 2, pieces 2 / 1.
+int launch_w43vh(kocr_ctx* ctx, W4Params& p, bool fuse, int geo, int pieces) {
+#ifdef KOCR_DEV_SWITCHES
+  static const int dbg = getenv("KOCR_W43H_DBG") ? atoi(getenv("KOCR_W43H_DBG")) : 0;
+  if (dbg && !fuse && geo == 1 && pieces == 2) {
+    switch (dbg) {
+      case 1: return w4vh_launch<0, 1, 2, 1>(ctx, p);
+      case 2: return w4vh_launch<0, 1, 2, 2>(ctx, p);
+      case 4: return w4vh_launch<0, 1, 2, 4>(ctx, p);
+      case 8: return w4vh_launch<0, 1, 2, 8>(ctx, p);
+      case 16: return w4vh_launch<0, 1, 2, 16>(ctx, p);
+      case 32: return w4vh_launch<0, 1, 2, 32>(ctx, p);
+      case 3: return w4vh_launch<0, 1, 2, 3>(ctx, p);
+      case 18: return w4vh_launch<0, 1, 2, 18>(ctx, p);
+      case 19: return w4vh_launch<0, 1, 2, 19>(ctx, p);
+      case 27: return w4vh_launch<0, 1, 2, 27>(ctx, p);
+      case 59: return w4vh_launch<0, 1, 2, 59>(ctx, p);
+      case 12: return w4vh_launch<0, 1, 2, 12>(ctx, p);
+      case 17: return w4vh_launch<0, 1, 2, 17>(ctx, p);
+      case 64: return w4vh_launch<0, 1, 2, 64>(ctx, p);
+      case 128: return w4vh_launch<0, 1, 2, 128>(ctx, p);
+      case 66: return w4vh_launch<0, 1, 2, 66>(ctx, p);
+      default: break;
+    }
+  }
+#endif
+  if (pieces == 2) {
+    if (geo == 2) return w4vh_launch<0, 2, 2>(ctx, p);
+    return fuse ? w4vh_launch<1, 1, 2>(ctx, p) : w4vh_launch<0, 1, 2>(ctx, p);
+  }
+  if (geo == 2) return w4vh_launch<0, 2, 1>(ctx, p);
+  return fuse ? w4vh_launch<1, 1, 1>(ctx, p) : w4vh_launch<0, 1, 1>(ctx, p);
+}

@@ -355,8 +355,7 @@ int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
   p.Mtotal = (int)M;
   p.pool_out = nullptr;
   p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
-  p.amax_out = out.amax;
-  p.amax_pool = (fuse && pool) ? pool->amax : nullptr;
+  p.amax_out = p.amax_pool = nullptr;  // per-image slots (Tensor::amax) are filled by a reduction pass after the launch
   if (fuse) {
     p.pool_out = pool->p;
     p.pool_cs = pool->cs;
@@ -405,6 +404,8 @@ int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
     }
     KOCR_HIP(ctx, hipGetLastError());
   }
+  if (out.amax && (!fuse || need_full)) KOCR_TRY(launch_absmax(ctx, out, out.amax));
+  if (fuse && pool->amax) KOCR_TRY(launch_absmax(ctx, *pool, pool->amax));
   if (pool && !fuse) return launch_maxpool2x2(ctx, out, *pool);
   return KOCR_OK;
 }

@@ -534,53 +534,6 @@ int prepare_wsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) 
   KOCR_HIP(ctx, hipMemcpy(d, u.data(), u.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   L.d_ws = (unsigned short*)d;
 
-  // fp16x2 copy: U * 2^wexp split by round-to-nearest into two fp16, |U 2^wexp| < 2^13
-  float umax = 0.f;
-  for (int c = 0; c < Cin; ++c)
-    for (int ky = 0; ky < 3; ++ky)
-      for (int o = 0; o < Cout; ++o) {
-        float g[3];
-        for (int kx = 0; kx < 3; ++kx)
-          g[kx] = w_is_oihw ? w[(((size_t)o * Cin + c) * 3 + ky) * 3 + kx] : w[(((size_t)ky * 3 + kx) * Cin + c) * Cout + o];
-        const float U[4] = {g[0], 0.5f * ((g[0] + g[1]) + g[2]), 0.5f * ((g[0] - g[1]) + g[2]), g[2]};
-        for (int xi = 0; xi < 4; ++xi) umax = std::max(umax, std::fabs(U[xi]));
-      }
-  int wexp = 0;
-  if (umax > 0.f && std::isfinite(umax)) {
-    int E;
-    std::frexp(umax, &E);  // umax = f * 2^E, f in [0.5, 1)
-    wexp = 13 - E;
-  }
-  const float wscale = std::ldexp(1.f, wexp);
-  // K-step of the fp16 kernel: 32 channels (two 16-channel blocks) when Cin allows, else 16
-  const int KB = (Cin % 32 == 0) ? 2 : 1;
-  L.ws16_kb = KB;
-  std::vector<unsigned short> v((size_t)(Cin / 16) * 3 * nt32 * 8 * 64 * 8, 0);
-  for (int c = 0; c < Cin; ++c)
-    for (int ky = 0; ky < 3; ++ky)
-      for (int o = 0; o < Cout; ++o) {
-        float g[3];
-        for (int kx = 0; kx < 3; ++kx)
-          g[kx] = w_is_oihw ? w[(((size_t)o * Cin + c) * 3 + ky) * 3 + kx] : w[(((size_t)ky * 3 + kx) * Cin + c) * Cout + o];
-        const float U[4] = {g[0], 0.5f * ((g[0] + g[1]) + g[2]), 0.5f * ((g[0] - g[1]) + g[2]), g[2]};
-        const int k = c % 16, lane = (k >> 3) * 32 + (o & 31), j = k & 7;
-        const int kblk = (c / 16) % KB;
-        const size_t step = (size_t)(c / (16 * KB)) * 3 + ky;
-        for (int xi = 0; xi < 4; ++xi) {
-          const float x = U[xi] * wscale;
-          const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
-          unsigned short hb, lb;
-          memcpy(&hb, &h, 2);
-          memcpy(&lb, &l, 2);
-          const size_t ph = (size_t)xi * KB + kblk;  // [step][ntile32][phase][piece][lane][8]
-          v[((((step * nt32 + o / 32) * 4 * KB + ph) * 2 + 0) * 64 + lane) * 8 + j] = hb;
-          v[((((step * nt32 + o / 32) * 4 * KB + ph) * 2 + 1) * 64 + lane) * 8 + j] = lb;
-        }
-      }
-  L.ws_wexp = wexp;
-  KOCR_TRY(ctx->dev_alloc(&d, v.size() * sizeof(unsigned short)));
-  KOCR_HIP(ctx, hipMemcpy(d, v.data(), v.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-  L.d_ws16 = (unsigned short*)d;
   return KOCR_OK;
 }
 
@@ -644,31 +597,15 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   p.pool_out = nullptr;
   p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
   p.total_tiles = 0;
-  p.amax_out = out.amax;
-  p.amax_pool = (fuse && pool) ? pool->amax : nullptr;
+  p.amax_out = p.amax_pool = nullptr;  // per-image slots (Tensor::amax) are filled by a reduction pass after the launch
 #ifdef KOCR_DEV_SWITCHES
   static const int dbg = getenv("KOCR_WS_DBG") ? atoi(getenv("KOCR_WS_DBG")) : 0;
   p.dbg = dbg;
 #endif
-  // fp16x2 mode needs the input's max |x| on the device: tracked by the producer (Tensor::amax) or reduced here
-  // the 32-channel-step fp16 kernel pairs two adjacent pairs per producer thread: needs W % 4 == 0 (else bf16x3)
-  const bool half = ctx->split_mode == KOCR_SPLIT_F16X2 && L.d_ws16 && (L.ws16_kb == 1 || in.W % 4 == 0);
-  const int kb = half ? L.ws16_kb : 1;
+  // (round 4: the fp16 arithmetic lives in conv_w43h.hip; the HALF / KB template paths of this kernel are no longer instantiated)
+  const bool half = false;
   p.amax_in = nullptr;
   p.w_exp = 0;
-  if (half) {
-    const unsigned* slot = in.amax;
-    if (!slot) {
-      unsigned* tmp = ctx->amax_slot();
-      if (!tmp) KOCR_FAIL(ctx, KOCR_ECAPACITY, "conv " + L.name + ": out of max-|x| slots");
-      KOCR_TRY(launch_absmax(ctx, in, tmp));
-      slot = tmp;
-    }
-    p.amax_in = slot;
-    p.w_exp = L.ws_wexp;
-    p.wgt = L.d_ws16;
-    p.nsteps /= kb;
-  }
   if (fuse) {
     p.pool_out = pool->p;
     p.pool_cs = pool->cs;
@@ -686,31 +623,7 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   {
     ProfScope ps(ctx, nm, flops, bytes);
-    if (half && kb == 2) {
-      if (wcls == 128) {
-        if (fuse)
-          KOCR_TRY((ws_launch<1, 1, 4, 1, 2>(ctx, p, M)));
-        else
-          KOCR_TRY((ws_launch<0, 1, 4, 1, 2>(ctx, p, M)));
-      } else {
-        if (fuse)
-          KOCR_TRY((ws_launch<1, 2, 2, 1, 2>(ctx, p, M)));
-        else
-          KOCR_TRY((ws_launch<0, 2, 2, 1, 2>(ctx, p, M)));
-      }
-    } else if (half) {
-      if (wcls == 128) {
-        if (fuse)
-          KOCR_TRY((ws_launch<1, 1, 4, 1, 1>(ctx, p, M)));
-        else
-          KOCR_TRY((ws_launch<0, 1, 4, 1, 1>(ctx, p, M)));
-      } else {
-        if (fuse)
-          KOCR_TRY((ws_launch<1, 2, 2, 1, 1>(ctx, p, M)));
-        else
-          KOCR_TRY((ws_launch<0, 2, 2, 1, 1>(ctx, p, M)));
-      }
-    } else if (wcls == 128) {
+    if (wcls == 128) {
       if (fuse)
         KOCR_TRY((ws_launch<1, 1, 4, 0, 1>(ctx, p, M)));
       else
@@ -722,6 +635,8 @@ int launch_conv_wsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
         KOCR_TRY((ws_launch<0, 2, 2, 0, 1>(ctx, p, M)));
     }
   }
+  if (out.amax && (!fuse || need_full)) KOCR_TRY(launch_absmax(ctx, out, out.amax));
+  if (fuse && pool->amax) KOCR_TRY(launch_absmax(ctx, *pool, pool->amax));
   if (pool && !fuse) return launch_maxpool2x2(ctx, out, *pool);
   return KOCR_OK;
 }

@@ -309,10 +309,11 @@ int craft_run(kocr_ctx* ctx, CraftNet* net, const void* d_img, int dtype, int N,
     room = ctx->ws.cap > o ? ctx->ws.cap - o : 0;
     KOCR_TRY(ctx->amax_begin());
   }
-  // every tensor produced by a convolution / pooling / up-sampling kernel carries a max-|x| slot
-  // (Tensor::amax) so that an fp16-split consumer can pick its exact power-of-two input scale
+  // track = true: the tensor feeds a 3x3 convolution that may run in fp16 arithmetic (conv_w43h.hip); it carries one
+  // max-|x| slot per image (Tensor::amax) which its producer maintains, so that the consumer can pick the exact
+  // power-of-two input scale of every image.  (A consumer whose input has no slots reduces it on demand.)
   std::map<const float*, std::pair<size_t, size_t>> live;  // tensor base -> (offset, bytes)
-  auto mk = [&](int h, int w, int c, Tensor* t) -> int {
+  auto mk = [&](int h, int w, int c, Tensor* t, bool track = false) -> int {
     const size_t bytes = (size_t)N * h * w * c * sizeof(float);
     const size_t off = pool.alloc(bytes);
     t->N = N;
@@ -325,7 +326,7 @@ int craft_run(kocr_ctx* ctx, CraftNet* net, const void* d_img, int dtype, int N,
       t->amax = nullptr;
       t->p = reinterpret_cast<float*>(off + 256);  // a distinct non-null key; never dereferenced
     } else {
-      t->amax = ctx->amax_slot();
+      t->amax = track ? ctx->amax_slots(N) : nullptr;
       if (off + al(bytes) > room) KOCR_FAIL(ctx, KOCR_ENOMEM, "kocr_craft_forward: workspace exhausted");
       t->p = reinterpret_cast<float*>(base + off);
     }
@@ -360,59 +361,59 @@ int craft_run(kocr_ctx* ctx, CraftNet* net, const void* d_img, int dtype, int N,
   // conv + 2x2 max-pool: fused epilogue when the shape tiles, else two kernels; need_full: the pre-pool tensor is
   // consumed elsewhere (skip connection).  The full-resolution buffer of an un-needed tensor is returned at once.
   Tensor a1, a2, p1, b1, cat4, p2, c1, cat3, c3, p3, e1, cat2, f1, p4, g1, cat1, h0, h1;
-  KOCR_TRY(mk(d.H, d.W, 64, &a1));
+  KOCR_TRY(mk(d.H, d.W, 64, &a1));  // (feeds slice1.3: 64 couts, bf16x3 row-reuse kernel -- no slots needed)
   RUN(launch_conv(ctx, L("basenet.slice1.0"), x0, u8, lut, a1));
   KOCR_TRY(mk(d.H, d.W, 64, &a2));
-  KOCR_TRY(mk(d.H2, d.W2, 64, &p1));
+  KOCR_TRY(mk(d.H2, d.W2, 64, &p1, true));
   RUN(launch_conv_pool(ctx, L("basenet.slice1.3"), a1, nullptr, nullptr, a2, &p1, /*need_full=*/false));
   done(a1);
   done(a2);
-  KOCR_TRY(mk(d.H2, d.W2, 128, &b1));
+  KOCR_TRY(mk(d.H2, d.W2, 128, &b1, true));
   RUN(launch_conv(ctx, L("basenet.slice1.7"), p1, nullptr, nullptr, b1));
   done(p1);
   KOCR_TRY(mk(d.H2, d.W2, 192, &cat4));
-  KOCR_TRY(mk(d.H4, d.W4, 128, &p2));
+  KOCR_TRY(mk(d.H4, d.W4, 128, &p2, true));
   const Tensor s1 = cat4.slice(64, 128);
   RUN(launch_conv_pool(ctx, L("basenet.slice1.10"), b1, nullptr, nullptr, s1, &p2, /*need_full=*/true));  // s1: skip tensor
   done(b1);
-  KOCR_TRY(mk(d.H4, d.W4, 256, &c1));
+  KOCR_TRY(mk(d.H4, d.W4, 256, &c1, true));
   RUN(launch_conv(ctx, L("basenet.slice2.14"), p2, nullptr, nullptr, c1));
   done(p2);
-  KOCR_TRY(mk(d.H4, d.W4, 384, &cat3));
+  KOCR_TRY(mk(d.H4, d.W4, 384, &cat3, true));
   const Tensor s2 = cat3.slice(128, 256);
   RUN(launch_conv(ctx, L("basenet.slice2.17"), c1, nullptr, nullptr, s2));
   done(c1);
   KOCR_TRY(mk(d.H4, d.W4, 256, &c3));
-  KOCR_TRY(mk(d.H8, d.W8, 256, &p3));
+  KOCR_TRY(mk(d.H8, d.W8, 256, &p3, true));
   RUN(launch_conv_pool(ctx, L("basenet.slice3.20"), s2, nullptr, nullptr, c3, &p3, false));
   done(c3);
-  KOCR_TRY(mk(d.H8, d.W8, 512, &e1));
+  KOCR_TRY(mk(d.H8, d.W8, 512, &e1, true));
   RUN(launch_conv(ctx, L("basenet.slice3.24"), p3, nullptr, nullptr, e1));
   done(p3);
-  KOCR_TRY(mk(d.H8, d.W8, 768, &cat2));
+  KOCR_TRY(mk(d.H8, d.W8, 768, &cat2, true));
   const Tensor s3 = cat2.slice(256, 512);
   RUN(launch_conv(ctx, L("basenet.slice3.27"), e1, nullptr, nullptr, s3));
   done(e1);
   KOCR_TRY(mk(d.H8, d.W8, 512, &f1));
-  KOCR_TRY(mk(d.H16, d.W16, 512, &p4));
+  KOCR_TRY(mk(d.H16, d.W16, 512, &p4, true));
   RUN(launch_conv_pool(ctx, L("basenet.slice4.30"), s3, nullptr, nullptr, f1, &p4, false));
   done(f1);
-  KOCR_TRY(mk(d.H16, d.W16, 512, &g1));
+  KOCR_TRY(mk(d.H16, d.W16, 512, &g1, true));
   RUN(launch_conv(ctx, L("basenet.slice4.34"), p4, nullptr, nullptr, g1));
   done(p4);
-  KOCR_TRY(mk(d.H16, d.W16, 1536, &cat1));
+  KOCR_TRY(mk(d.H16, d.W16, 1536, &cat1, true));
   const Tensor s4 = cat1.slice(1024, 512);
   RUN(launch_conv(ctx, L("basenet.slice4.37"), g1, nullptr, nullptr, s4));
   done(g1);
   // ---- slice5 (detection.py:365-378) ----------------------------------------------------
-  KOCR_TRY(mk(d.H16, d.W16, 512, &h0));
+  KOCR_TRY(mk(d.H16, d.W16, 512, &h0, true));
   RUN(launch_maxpool3x3s1(ctx, s4, h0));
   KOCR_TRY(mk(d.H16, d.W16, 1024, &h1));
   Tensor u1a;
-  KOCR_TRY(mk(d.H16, d.W16, 512, &u1a));
+  KOCR_TRY(mk(d.H16, d.W16, 512, &u1a, true));
   bool lin_fold = false;
   if constexpr (!DRY) {
-    lin_fold = ctx->opt_linfold && ctx->split_mode == KOCR_SPLIT_BF16X3 && dsplit_usable(L("upconv1.conv.0#skip"), s4) &&
+    lin_fold = ctx->opt_linfold && dsplit_usable(L("upconv1.conv.0#skip"), s4) &&
                2 * (size_t)h0.H * h0.W * 512 * 4 < ((size_t)1 << 31);
     if (lin_fold) {  // see craft_load: slice5.1 -> slice5.2 -> upconv1.conv.0 as one dilated 3x3 plus a 1x1 over s4
       Tensor t = h1;  // the first half of h1's buffer, as a contiguous 512-channel tensor
@@ -443,7 +444,7 @@ int craft_run(kocr_ctx* ctx, CraftNet* net, const void* d_img, int dtype, int N,
     if constexpr (!DRY) {
       const ConvLayer& Ls = L((std::string(name) + "#skip").c_str());
       const Tensor skip = cat.slice(c_y, cat.C - c_y);
-      const bool fold = ctx->opt_upfold && ctx->split_mode == KOCR_SPLIT_BF16X3 && dsplit_usable(Ls, skip) &&
+      const bool fold = ctx->opt_upfold && dsplit_usable(Ls, skip) &&
                         2 * (size_t)t.H * t.W * t.C * 4 < ((size_t)1 << 31);  // two images of t within 32-bit offsets
       if (fold) {
         KOCR_TRY(launch_conv(ctx, L((std::string(name) + "#y").c_str()), y, nullptr, nullptr, t));
@@ -462,12 +463,12 @@ int craft_run(kocr_ctx* ctx, CraftNet* net, const void* d_img, int dtype, int N,
   KOCR_TRY(mk(d.H16, d.W16, 256, &u1b));
   RUN(launch_conv(ctx, L("upconv1.conv.3"), u1a, nullptr, nullptr, u1b));
   done(u1a);
-  KOCR_TRY(mk(d.H8, d.W8, 256, &u2a));
+  KOCR_TRY(mk(d.H8, d.W8, 256, &u2a, true));
   KOCR_TRY(up_conv("upconv2.conv.0", u1b, cat2, u2a));
   KOCR_TRY(mk(d.H8, d.W8, 128, &u2b));
   RUN(launch_conv(ctx, L("upconv2.conv.3"), u2a, nullptr, nullptr, u2b));
   done(u2a);
-  KOCR_TRY(mk(d.H4, d.W4, 128, &u3a));
+  KOCR_TRY(mk(d.H4, d.W4, 128, &u3a, true));
   KOCR_TRY(up_conv("upconv3.conv.0", u2b, cat3, u3a));
   KOCR_TRY(mk(d.H4, d.W4, 64, &u3b));
   RUN(launch_conv(ctx, L("upconv3.conv.3"), u3a, nullptr, nullptr, u3b));

@@ -185,8 +185,8 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
   if (!net || !net->loaded) KOCR_FAIL(ctx, KOCR_ENOWEIGHTS, "kocr_crnn_forward: call kocr_load_crnn first");
   if (M <= 0) return KOCR_OK;
   KOCR_TRY(ctx->amax_begin());
-  // The recogniser always runs the exact bf16x3 split: its batch is a mix of crops of many images, and the fp16x2
-  // scale (max |x| of the whole tensor) would make a crop's result depend on its neighbours in the batch.
+  // The recogniser always runs the exact bf16x3 split (its conv stack has no fp16 F(4,3) arrangement yet: 31 x 200 and
+  // 15 x 100 crops tile neither as 4 x 64 nor as 8 x 32).
   struct ModeGuard {
     kocr_ctx* c;
     int old;
@@ -194,7 +194,7 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
     ~ModeGuard() { c->split_mode = old; }
   } mode_guard(ctx);
   auto mk = [&](int n, int h, int w, int c, Tensor* t) -> int {
-    t->amax = nullptr;  // assigned below for the conv stack only (its producers all maintain the slot)
+    t->amax = nullptr;
     t->N = n;
     t->H = h;
     t->W = w;
@@ -227,31 +227,22 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
   x0.co = 0;
   x0.p = const_cast<float*>(d_crops);
   KOCR_TRY(mk(M, HC, WC, 64, &c1));
-  c1.amax = ctx->amax_slot();
   KOCR_TRY(conv("conv_1", x0, c1));
   KOCR_TRY(mk(M, HC, WC, 128, &c2));
-  c2.amax = ctx->amax_slot();
   KOCR_TRY(conv("conv_2", c1, c2));
   KOCR_TRY(mk(M, HC, WC, 256, &c3));
-  c3.amax = ctx->amax_slot();
   KOCR_TRY(conv("conv_3", c2, c3));  // ReLU then bn_3
   KOCR_TRY(mk(M, HC / 2, WC / 2, 256, &p3));
-  p3.amax = ctx->amax_slot();
   KOCR_TRY(launch_maxpool2x2(ctx, c3, p3, /*row_off=*/1));
   KOCR_TRY(mk(M, HC / 2, WC / 2, 256, &c4));
-  c4.amax = ctx->amax_slot();
   KOCR_TRY(conv("conv_4", p3, c4));
   KOCR_TRY(mk(M, HC / 2, WC / 2, 512, &c5));
-  c5.amax = ctx->amax_slot();
   KOCR_TRY(conv("conv_5", c4, c5));
   KOCR_TRY(mk(M, HC / 4, WC / 4, 512, &p5));
-  p5.amax = ctx->amax_slot();
   KOCR_TRY(launch_maxpool2x2(ctx, c5, p5, /*row_off=*/1));
   KOCR_TRY(mk(M, HC / 4, WC / 4, 512, &c6));
-  c6.amax = ctx->amax_slot();
   KOCR_TRY(conv("conv_6", p5, c6));
   KOCR_TRY(mk(M, HC / 4, WC / 4, 512, &c7n));
-  c7n.amax = ctx->amax_slot();
   KOCR_TRY(conv("conv_7", c6, c7n));
   // back to the Keras layout (M, 50, 7, 512) for the STN and everything after it
   KOCR_TRY(mk(M, WC / 4, HC / 4, 512, &c7));

@@ -176,7 +176,7 @@ int launch_maxpool2x2(kocr_ctx* ctx, const Tensor& in, const Tensor& out, int ro
     KOCR_HIP(ctx, hipGetLastError());
   }
   if (out.amax) {  // |out| <= max |in|
-    if (in.amax) return launch_amax_copy(ctx, in.amax, out.amax);
+    if (in.amax) return launch_amax_copy(ctx, in.amax, out.amax, out.N);
     return launch_absmax(ctx, out, out.amax);
   }
   return KOCR_OK;
@@ -194,7 +194,7 @@ int launch_maxpool3x3s1(kocr_ctx* ctx, const Tensor& in, const Tensor& out) {
     KOCR_HIP(ctx, hipGetLastError());
   }
   if (out.amax) {  // |out| <= max |in|
-    if (in.amax) return launch_amax_copy(ctx, in.amax, out.amax);
+    if (in.amax) return launch_amax_copy(ctx, in.amax, out.amax, out.N);
     return launch_absmax(ctx, out, out.amax);
   }
   return KOCR_OK;
@@ -213,7 +213,7 @@ int launch_resize_bilinear(kocr_ctx* ctx, const Tensor& in, const Tensor& out) {
     KOCR_HIP(ctx, hipGetLastError());
   }
   if (out.amax) {  // |out| <= max |in|
-    if (in.amax) return launch_amax_copy(ctx, in.amax, out.amax);
+    if (in.amax) return launch_amax_copy(ctx, in.amax, out.amax, out.N);
     return launch_absmax(ctx, out, out.amax);
   }
   return KOCR_OK;
@@ -324,36 +324,40 @@ int launch_head_tail(kocr_ctx* ctx, const ConvLayer& L6, const ConvLayer& L8, co
 // ---------------------------------------------------------------------------------------
 // max |x| bookkeeping for the fp16-split convolutions (Tensor::amax)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void absmax_kernel(const float* in, size_t pixels, int C4, int cs, int co, unsigned* slot) {
+__global__ __launch_bounds__(256) void absmax_kernel(const float* in, size_t img_pixels, int C4, int cs, int co, unsigned* slots) {
   typedef float v4f __attribute__((ext_vector_type(4)));
   float m = 0.f;
-  const size_t total = pixels * C4;
+  const size_t total = img_pixels * C4;
+  const float* base = in + (size_t)blockIdx.y * img_pixels * cs;  // image blockIdx.y
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t px = i / C4;
     const int c4 = (int)(i - px * C4);
-    const v4f v = *reinterpret_cast<const v4f*>(in + px * cs + co + 4 * c4);
+    const v4f v = *reinterpret_cast<const v4f*>(base + px * cs + co + 4 * c4);
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > *(volatile const unsigned*)slot) atomicMax(slot, __float_as_uint(m));
+  kocr_amax_update(slots + blockIdx.y, m);
 }
 
-__global__ void amax_copy_kernel(const unsigned* from, unsigned* to) { atomicMax(to, *from); }
+__global__ void amax_copy_kernel(const unsigned* from, unsigned* to, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicMax(to + i, from[i]);
+}
 
-int launch_absmax(kocr_ctx* ctx, const Tensor& t, unsigned* slot) {
+int launch_absmax(kocr_ctx* ctx, const Tensor& t, unsigned* slots) {
   if (t.C % 4 || t.cs % 4 || t.co % 4 || ((uintptr_t)t.p & 15)) KOCR_FAIL(ctx, KOCR_EINVAL, "absmax: unaligned tensor");
-  const size_t total = t.pixels() * (t.C / 4);
-  if (!total) return KOCR_OK;
+  const size_t total = (size_t)t.H * t.W * (t.C / 4);
+  if (!total || !t.N) return KOCR_OK;
   ProfScope ps(ctx, "absmax", 0, 4.0 * t.pixels() * t.C);
-  hipLaunchKernelGGL(absmax_kernel, ew_grid(total), dim3(256), 0, ctx->stream, t.p, t.pixels(), t.C / 4, t.cs, t.co, slot);
+  size_t b = (total + 255) / 256;
+  if (b > 1024) b = 1024;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)b, (unsigned)t.N), dim3(256), 0, ctx->stream, t.p, (size_t)t.H * t.W, t.C / 4, t.cs, t.co, slots);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }
 
-int launch_amax_copy(kocr_ctx* ctx, const unsigned* from, unsigned* to) {
-  if (!from || !to || from == to) return KOCR_OK;
-  hipLaunchKernelGGL(amax_copy_kernel, dim3(1), dim3(1), 0, ctx->stream, from, to);
+int launch_amax_copy(kocr_ctx* ctx, const unsigned* from, unsigned* to, int n) {
+  if (!from || !to || from == to || n <= 0) return KOCR_OK;
+  hipLaunchKernelGGL(amax_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, from, to, n);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }

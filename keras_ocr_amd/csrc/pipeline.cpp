@@ -61,9 +61,6 @@ extern "C" int kocr_detect(kocr_ctx* ctx, const void* img, int dtype, int N, int
   if (!d_heat || !d_boxes) KOCR_FAIL(ctx, KOCR_ENOMEM, "kocr_detect: arena exhausted");
   int mb = micro_batch > 0 ? micro_batch : 32;
   while (mb > 1 && craft_workspace_bytes(mb, H, W) > ((size_t)96 << 30)) mb = (mb + 1) / 2;
-  // fp16x2 split: the exact input scale of a convolution follows the max |x| of the tensor it reads, so one IMAGE
-  // per forward makes every image's result independent of what else is in the batch
-  if (ctx->split_mode == KOCR_SPLIT_F16X2) mb = 1;
   mb = std::min(mb, N);
   KOCR_TRY(ctx->ws_reserve(craft_workspace_bytes(mb, H, W)));
   for (int s = 0; s < N; s += mb) {
@@ -188,9 +185,6 @@ extern "C" int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, c
   // ---- detector forward (micro-batched) ----
   int mb = micro_batch > 0 ? micro_batch : 32;
   while (mb > 1 && craft_workspace_bytes(mb, Hmax, Wmax) > ((size_t)96 << 30)) mb = (mb + 1) / 2;
-  // fp16x2 split: the exact input scale of a convolution follows the max |x| of the tensor it reads, so one IMAGE
-  // per forward makes every image's result independent of what else is in the batch
-  if (ctx->split_mode == KOCR_SPLIT_F16X2) mb = 1;
   mb = std::min(mb, N);
   KOCR_TRY(ctx->ws_reserve(craft_workspace_bytes(mb, Hmax, Wmax)));
   for (int s = 0; s < N; s += mb) {

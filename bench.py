@@ -191,11 +191,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--split", choices=["bf16x3", "f16x2"], default="bf16x3",
+    ap.add_argument("--split", choices=["bf16x3", "f16x2"], default="f16x2",
                     help="arithmetic of the wide convolutions for the headline number (include/kocr.h KOCR_SPLIT_*)")
     ap.add_argument("--alt-mode", action="store_true",
-                    help="also time the other split mode (fp16x2: an independent arithmetic kept as a tested numerical "
-                         "cross-check; since round 3 it is slower than the default bf16x3 path and no longer a default leg)")
+                    help="also time the other fp32-class split mode (bf16x3 everywhere: the round-3 default) on the same workload")
     ap.add_argument("--no-alt-mode", action="store_true", help="(default; kept for old command lines)")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] / configs[4]-share / host-array legs")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -323,9 +322,10 @@ def main():
         alt = {"mode": alt_mode, "value": world * args.batch * args.steps / dt_alt, "unit": "images/s",
                "ms_per_step": dt_alt / args.steps * 1e3,
                "words": sum(len(g) for g in out_alt), "identical_strings_vs_headline_mode": same,
-               "note": "f16x2 = 2 round-to-nearest fp16 pieces per fp32 operand, 3 products, exact power-of-two "
-                       "scaling; bf16x3 = 3 exact bf16 pieces, 6 products; both within fp32 round-off of an fp64 "
-                       "reference (tests/test_split_modes_gpu.py); the whole GPU suite passes in either mode"}
+               "note": "f16x2 = the Winograd F(4,3) layers on the fp16 cores: 2 round-to-nearest fp16 pieces per fp32 operand, "
+                       "3 products, exact per-image / per-cout power-of-two scaling (everything else bf16x3); bf16x3 = 3 exact "
+                       "bf16 pieces, 6 products everywhere; both within fp32 round-off of an fp64 reference "
+                       "(tests/test_conv_gpu.py, tests/test_split_modes_gpu.py); the whole GPU suite passes in either mode"}
         ctx.set_split_mode(args.split)
 
     extra = {}
@@ -455,7 +455,9 @@ def main():
             "dtype": ("f32 (wide 3x3 / 1x1 convolutions: fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMA products, "
                       "fp32 accumulation -- fp32-class accuracy, tests/test_conv_gpu.py; everything else fp32 MFMA/VALU)")
             if args.split == "bf16x3" else
-            "f32 (wide convolutions: 2 round-to-nearest fp16 pieces per operand, 3 fp16 MFMA products, fp32 accumulation)",
+            ("f32 (Winograd F(4,3) convolutions: fp32 operands scaled by exact powers of two and split into 2 round-to-nearest fp16 "
+             "pieces, 3 fp16 MFMA products, fp32 accumulation; other wide convolutions: 3 exact bf16 pieces, 6 bf16 MFMA products -- "
+             "fp32-class accuracy against fp64, tests/test_conv_gpu.py; everything else fp32 MFMA/VALU)"),
             "data": "synthetic (seeded rendered-text pages; random-init weights of the reference "
                     "architectures, detector head calibrated to emit word boxes)",
             "config": {"workload": f"Pipeline.recognize full pipeline, batch {args.batch} x {SIDE}x{SIDE} RGB u8 per GPU, "

@@ -376,11 +376,11 @@ class Context:
         return out
 
     # -- arithmetic of the wide convolutions (include/kocr.h: KOCR_SPLIT_*) ---------------
-    SPLIT_BF16X3, SPLIT_F16X2 = 0, 1
+    SPLIT_BF16X3, SPLIT_F16X2, SPLIT_F16X1 = 0, 1, 2
 
     def set_split_mode(self, mode):
         if isinstance(mode, str):
-            mode = {"bf16": 0, "bf16x3": 0, "f16": 1, "fp16": 1, "f16x2": 1}[mode]
+            mode = {"bf16": 0, "bf16x3": 0, "f16": 1, "fp16": 1, "f16x2": 1, "f16x1": 2, "fast": 2}[mode]
         self._check(self._lib.kocr_set_split_mode(self._h, int(mode)))
 
     def get_split_mode(self):

@@ -116,7 +116,7 @@ struct kocr_ctx {
   std::string err;
   void set_err(const std::string& s) { err = s; }
 
-  int split_mode = 0;  // KOCR_SPLIT_BF16X3 / KOCR_SPLIT_F16X2 / KOCR_SPLIT_F16X1
+  int split_mode = KOCR_SPLIT_F16X2;  // KOCR_SPLIT_BF16X3 / KOCR_SPLIT_F16X2 (default since round 4) / KOCR_SPLIT_F16X1
   // CRAFT schedule options (craft.cpp: folded linear layers); read ONCE from KOCR_LINFOLD / KOCR_UPFOLD when the
   // context is created, changed through kocr_set_schedule
   bool opt_linfold = true, opt_upfold = true;

@@ -41,7 +41,8 @@ SCALE = 2
 WORDS_PER_PAGE = 20       # SURVEY.md 8(d) cfg 4: "~20 words each"
 FP32_MFMA_PEAK_TF = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 / fp16 MFMA peak, same table
-PARITY_PAGES = (0, 9, 18, 31)  # pages of the timed batch compared with the CPU oracle (as tests/test_baseline_sizes_gpu.py)
+PARITY_PAGES = (0, 4, 9, 13, 18, 22, 27, 31)  # pages of the timed batch compared with the CPU oracle
+HEAT_TOL = 2e-4  # north_star's "stated fp32 tolerance on heatmaps", ABSOLUTE: the calibrated head keeps the maps O(1)
 
 
 def make_pages(n, side, seed, words=WORDS_PER_PAGE):
@@ -124,8 +125,9 @@ def parity_of(gpu_page, oracle_page, flipped=None, page=0):
     return res
 
 
-def parity_pages(ctx, craft_w, crnn_w, pages, gpu_out, page0_oracle, page0_heat):
-    """`parity` object of the bench line: pages PARITY_PAGES of the timed batch against the CPU oracle."""
+def parity_pages(ctx, craft_w, crnn_w, pages, gpu_out, page0_oracle, page0_heat, oracle_cache):
+    """`parity` object of the bench line: pages PARITY_PAGES of the timed batch against the CPU oracle.  The oracle's
+    result of every page (words, heat-map) is kept in `oracle_cache` for the fast-mode leg."""
     from oracle import pipeline as opipe
     from oracle.parity import flips
 
@@ -137,17 +139,22 @@ def parity_pages(ctx, craft_w, crnn_w, pages, gpu_out, page0_oracle, page0_heat)
             heat = []
             want = opipe.recognize(craft_w, crnn_w, [pages[i]], scale=SCALE, heat_out=heat)[0]
             h_ref = heat[0][0]
+        oracle_cache[i] = (want, h_ref)
         big = ctx.resize_pad(pages[i][None], (pages[i].shape[1] * SCALE, pages[i].shape[0] * SCALE))
         h_gpu = ctx.craft_forward(big)[0]
         r = parity_of(gpu_out[i], want, flips(h_gpu, h_ref), page=i)
-        # the calibrated random-init head scales its two output channels by ~1e4-1e6 (weights.calibrate_craft_head), so the
-        # heat-map error is judged relative to the map's magnitude: 2e-4 absolute on maps of magnitude <= ~3 in the tests
-        r["heat_max_abs_err"] = float(np.abs(h_gpu - h_ref).max())
+        # ABSOLUTE heat-map error against north_star's fp32 tolerance: the head is calibrated so that the maps stay O(1)
+        # (weights.calibrate_craft_head(top_q=0.9999)), as real CRAFT score maps are
+        d = np.abs(h_gpu - h_ref)
+        r["heat_max_abs_err"] = float(d.max())
+        r["heat_rms_err"] = float(np.sqrt((d.astype(np.float64) ** 2).mean()))
         r["heat_max_abs"] = float(np.abs(h_ref).max())
-        r["heat_rel_err"] = r["heat_max_abs_err"] / max(1.0, r["heat_max_abs"])
+        near = (np.abs(h_ref - np.float32(0.4)) <= 1.0) | (np.abs(h_ref[..., :1] - np.float32(0.7)) <= 1.0)
+        r["heat_max_abs_err_within_1_of_a_threshold"] = float(d[near].max()) if near.any() else 0.0
+        r["pixels_within_1_of_a_threshold"] = int(near.sum())
         r.pop("note")
         per_page.append(r)
-        ok = ok and r["ok"] and r["heat_rel_err"] <= 5e-5
+        ok = ok and r["ok"] and r["heat_max_abs_err"] <= HEAT_TOL
     return {"pages": [r["page"] for r in per_page], "ok": bool(ok),
             "words_gpu": sum(r["words_gpu"] for r in per_page), "words_oracle": sum(r["words_oracle"] for r in per_page),
             "strings_equal": all(r["strings_equal"] for r in per_page),
@@ -155,13 +162,66 @@ def parity_pages(ctx, craft_w, crnn_w, pages, gpu_out, page0_oracle, page0_heat)
                                          default=None),
             "heat_max_abs_err": max(r["heat_max_abs_err"] for r in per_page),
             "heat_max_abs": max(r["heat_max_abs"] for r in per_page),
-            "heat_rel_err": max(r["heat_rel_err"] for r in per_page),
+            "heat_rms_err": max(r["heat_rms_err"] for r in per_page),
+            "heat_tolerance_abs": HEAT_TOL,
+            "heat_max_abs_err_within_1_of_a_threshold": max(r["heat_max_abs_err_within_1_of_a_threshold"] for r in per_page),
             "flipped_threshold_pixels": sum(r["flipped_threshold_pixels"] for r in per_page),
             "per_page": per_page,
             "note": "oracle = oracle/ (CPU restatement of the reference path); strings exact, boxes to 1e-3 px, heat-maps to "
-                    "5e-5 of their magnitude (the calibrated random-init head scales them by ~1e5; the tests hold 2e-4 absolute "
-                    "on maps of magnitude ~3); a missing / extra box is accepted only next to a heat-map pixel that lies on the other side of a "
-                    "getBoxes threshold (counted: flipped_threshold_pixels)"}
+                    f"{HEAT_TOL} ABSOLUTE (maps of magnitude heat_max_abs); a missing / extra box is accepted only next to a "
+                    "heat-map pixel that lies on the other side of a getBoxes threshold (counted: flipped_threshold_pixels)"}
+
+
+def fast_mode_leg(ctx, pipe, step, timed, args, world, out_default, pages, oracle_cache):
+    """SURVEY 8(f).4 / VERDICT r03 item 2: the opt-in REDUCED-PRECISION mode (KOCR_SPLIT_F16X1: one fp16 piece per operand in
+    the Winograd F(4,3) layers) on the same workload -- its throughput and what it costs in accuracy, against the oracle
+    pages of the parity leg.  Never `value`."""
+    from oracle.parity import flips
+    from keras_ocr_amd import evaluation
+
+    ctx.set_split_mode("f16x1")
+    try:
+        step()
+        dt_f, out_f = timed(step, args.steps)
+        heat_err, heat_rms, n_flip, n_same, n_oracle, n_fast, same_str = 0.0, 0.0, 0, 0, 0, 0, 0
+        true, pred = {}, {}
+        for i, (want, h_ref) in sorted(oracle_cache.items()):
+            big = ctx.resize_pad(pages[i][None], (pages[i].shape[1] * SCALE, pages[i].shape[0] * SCALE))
+            h = ctx.craft_forward(big)[0]
+            d = np.abs(h - h_ref)
+            heat_err = max(heat_err, float(d.max()))
+            heat_rms = max(heat_rms, float(np.sqrt((d.astype(np.float64) ** 2).mean())))
+            n_flip += int(len(flips(h, h_ref)))
+            got = out_f[i]
+            n_oracle += len(want)
+            n_fast += len(got)
+            for t, b in want:
+                dd = [float(np.abs(np.asarray(b, np.float64) - np.asarray(gb, np.float64)).max()) for _, gb in got]
+                if dd and min(dd) <= 1e-3:
+                    n_same += 1
+                    same_str += int(got[int(np.argmin(dd))][0] == t)
+            true[i] = [{"text": t, "vertices": np.asarray(b, np.float64)} for t, b in want]
+            pred[i] = [{"text": t, "vertices": np.asarray(b, np.float64)} for t, b in got]
+        prec = rec_ = None
+        if n_oracle and n_fast:
+            _, (prec, rec_) = evaluation.score(true, pred)
+        same_default = sum(1 for ga, gb in zip(out_default, out_f) for (ta, _), (tb, _) in zip(ga, gb) if ta == tb)
+        return {"mode": "f16x1", "value": world * args.batch * args.steps / dt_f, "unit": "images/s",
+                "ms_per_step": dt_f / args.steps * 1e3, "words": sum(len(g) for g in out_f),
+                "vs_oracle_on_parity_pages": {
+                    "heat_max_abs_err": heat_err, "heat_rms_err": heat_rms, "flipped_threshold_pixels": n_flip,
+                    "oracle_boxes": n_oracle, "fast_boxes": n_fast, "boxes_identical_to_1e-3_px": n_same,
+                    "of_those_strings_identical": same_str,
+                    "precision_recall_vs_oracle_iou0.5_similarity0.5": [prec, rec_]},
+                "strings_identical_to_default_mode_by_position": same_default,
+                "stated_tolerance": "heat-maps within 2e-2 absolute (2e-3 rms) of the oracle on full-size pages with maps of "
+                                    "magnitude ~4 -- 500x the fp32-class modes; 5e-3 on the small images of "
+                                    "tests/test_split_modes_gpu.py::test_fast_mode_heatmaps_and_boxes; per layer "
+                                    "|err| <= 1e-3 |x| conv |w| (same file)",
+                "note": "REDUCED PRECISION (relative operand error 2^-12 in the F(4,3) layers): opt-in via "
+                        "kocr_set_split_mode(KOCR_SPLIT_F16X1) / KOCR_SPLIT=f16x1, never the default, never `value`"}
+    finally:
+        ctx.set_split_mode(args.split)
 
 
 def respawn_under_torchrun(args):
@@ -256,12 +316,13 @@ def main():
     crnn_w = k.weights.synthetic_crnn_weights(4321)
     # calibrate the random-init head (same on every rank) so that the detector emits ~20 boxes per page
     ctx.load_craft(craft_w)
-    cal_pages = make_pages(4, SIDE, seed=1004)
+    cal_pages = make_pages(8, SIDE, seed=4)  # = the first 8 pages of rank 0's timed batch (the same on every rank)
     sample = ctx.resize_pad(cal_pages, (SIDE * SCALE, SIDE * SCALE))
     raw = ctx.craft_forward(sample)
     best = None
-    for frac in (0.03, 0.016, 0.008, 0.005, 0.0035, 0.0025, 0.0018, 0.0013, 0.0009, 0.0006, 0.0004):
-        cand = k.weights.calibrate_craft_head(craft_w, raw, text_frac=frac, link_frac=frac / 3)
+    for frac in (0.012, 0.0095, 0.008, 0.007, 0.0062, 0.0055, 0.0049, 0.0044, 0.0039, 0.0034, 0.003, 0.0025):
+        # top_q = 0.9999 keeps the gain (and with it the maps) O(1) -- see weights.calibrate_craft_head
+        cand = k.weights.calibrate_craft_head(craft_w, raw, text_frac=frac, link_frac=frac / 3, top_q=0.9999)
         a = cand["conv_cls.8.weight"].reshape(2, -1)[:, :1] / craft_w["conv_cls.8.weight"].reshape(2, -1)[:, :1]
         heat = (raw - craft_w["conv_cls.8.bias"]) * a.ravel() + cand["conv_cls.8.bias"]
         nb = np.mean([len(b) for b in ctx.get_boxes(heat.astype(np.float32))])
@@ -295,6 +356,16 @@ def main():
         tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         return float(tt.item()), res
+
+    def timed_local(fn, steps):
+        """rank-local timing for the rank-0-only legs (no collective: the other ranks sit in the final barrier)"""
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = None
+        for _ in range(steps):
+            res = fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, res
 
     out = None
     for _ in range(args.warmup):
@@ -493,7 +564,11 @@ def main():
             res["alt_split_mode"] = alt
         if not args.no_cpu_baseline:
             res["cpu_baseline"], oracle_page, oracle_heat = cpu_baseline(craft_w, crnn_w, pages[0])
-            res["parity"] = parity_pages(ctx, craft_w, crnn_w, pages, out, oracle_page, oracle_heat)
+            oracle_cache = {}
+            res["parity"] = parity_pages(ctx, craft_w, crnn_w, pages, out, oracle_page, oracle_heat, oracle_cache)
+            if not args.no_extra:
+                fold_process_profile()
+                res["fast_mode"] = fast_mode_leg(ctx, pipe, step, timed_local, args, world, out, pages, oracle_cache)
         fold_process_profile()  # the parity leg's single-page detector forwards are launches of this process too
         if args.profile_all and name in prof_process:
             pr = prof_process[name]

@@ -200,12 +200,14 @@ def read_keras_h5(path, kind):
     return out
 
 
-def calibrate_craft_head(weights, heat_sample, text_frac=0.08, link_frac=0.03, peak=0.95):
+def calibrate_craft_head(weights, heat_sample, text_frac=0.08, link_frac=0.03, peak=0.95, top_q=0.998):
     """Rescale the last (linear) CRAFT layer of random-init weights so that its two output
     channels behave like score maps: ``text_frac`` / ``link_frac`` of the pixels of
     ``heat_sample`` (the head's output under ``weights``) end up above the reference's 0.4
-    thresholds (detection.py:749-750) and the 99.8th percentile lands at ``peak`` (> the 0.7
-    detection threshold).  Random weights otherwise never produce a box, which would leave the
+    thresholds (detection.py:749-750) and the ``top_q`` quantile (99.8th percentile by default) lands at
+    ``peak`` (> the 0.7 detection threshold).  ``top_q`` must lie well above ``1 - text_frac``: the gain is
+    ``(peak - 0.4) / (quantile(top_q) - quantile(1 - frac))``, so close quantiles turn the maps into step functions of
+    magnitude 1e5 (bench.py uses 0.9999 to keep them O(1), as real CRAFT maps are).  Random weights otherwise never produce a box, which would leave the
     crop + recognition stages of the synthetic benchmark idle.  Returns a new weight dict."""
     out = dict(weights)
     w = np.array(weights["conv_cls.8.weight"], dtype=np.float32, copy=True)
@@ -213,7 +215,7 @@ def calibrate_craft_head(weights, heat_sample, text_frac=0.08, link_frac=0.03, p
     for c, frac in enumerate((text_frac, link_frac)):
         v = np.asarray(heat_sample[..., c], dtype=np.float64).ravel()
         q = np.quantile(v, 1.0 - frac)
-        top = np.quantile(v, 0.998)
+        top = np.quantile(v, top_q)
         a = (peak - 0.4) / max(top - q, 1e-6)
         w[c] *= np.float32(a)
         b[c] = np.float32(a * (b[c] - q) + 0.4)

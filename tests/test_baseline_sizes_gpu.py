@@ -4,7 +4,7 @@ The oracle costs ~1 s per 768x768 CRAFT forward and ~3 s per full 768x768 page (
 host cores, so full-size comparisons are affordable on a handful of pages:
 
   cfg2  CRAFT only, the whole 8 x 768x768 batch: heat-maps vs oracle (max-abs / rms reported)
-  cfg3  all 512 crops of 31x200: probabilities <= 2e-4, labels exact wherever the oracle's margin > 1e-3
+  cfg3  all 512 crops of 31x200: probabilities <= 1e-4, labels exact wherever the oracle's margin > 1e-3
   cfg4  32 pages of 768x768 at scale 2 in ONE call; four of them against the full CPU oracle
   cfg5  one 1536x1536 page at scale 3 (capped: detector input 2048x2048) against the full CPU oracle
 
@@ -24,8 +24,8 @@ from tests.parity import flips as _flips, compare_page as _compare_page
 
 pytestmark = pytest.mark.gpu
 
-HEAT_TOL = 2e-4     # stated fp32 tolerance on heat-maps (the reference's Keras-vs-PyTorch bar is 1.5e-4)
-PROB_TOL = 2e-4
+HEAT_TOL = 5e-5     # stated fp32 tolerance on heat-maps (measured ~2e-5; the reference's own Keras-vs-PyTorch bar is 1.5e-4)
+PROB_TOL = 1e-4  # measured ~4e-5
 MARGIN = 1e-3
 FLIP_BUDGET = 2e-5  # fraction of heat-map pixels allowed to sit on the other side of a threshold
 

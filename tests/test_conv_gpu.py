@@ -104,59 +104,76 @@ def test_conv_transpose_detecting(ctx):
 # persistent blocks walk over several tiles each and both tile shapes (128 px x 128 couts, 256 px x 64
 # couts) and odd/even K-step counts are hit.
 # ---------------------------------------------------------------------------------------------------
+# Every case names the kernel family it must run on in the DEFAULT arithmetic (fp16x2 F(4,3) where an fp16 arrangement
+# exists, else the exact bf16x3 kernels); under KOCR_SPLIT=bf16 "conv_w4h" reads "conv_w4".  The profiler row of the
+# launch is asserted (a dispatch regression must not pass silently), unless a KOCR_* developer switch
+# reroutes the layer (tests/test_fallback_paths_gpu.py).
 SPLIT_CASES = [
-    # N, H, W, Cin, Cout
-    (1, 96, 192, 256, 256),   # 288 tiles of 128x128 > 256 CUs: blocks take a second tile
-    (2, 64, 128, 64, 64),     # 256x64 tiles
-    (1, 40, 64, 48, 96),      # 9 K-steps (odd)
-    (1, 30, 50, 512, 130),    # ragged couts, tiles crossing image rows
-    # conv_w43.hip (Winograd F(4,3): Cin % 32 == 0, Cout > 64, W % 4 == 0) -- the first case above takes it too
-    (1, 30, 52, 512, 130),    # ragged couts, 256-pixel tiles crossing image rows, last tile partly outside
-    (2, 17, 36, 64, 128),     # 12 K-steps, two images, odd height
-    (1, 64, 128, 128, 256),   # two cout tiles per pixel tile
-    (3, 8, 4, 32, 96),        # a single quad per row: both column paddings in one quad
-    # 32 < Cout <= 64: the 64-cout arrangement of conv_w43.hip (512-pixel tiles, two gather items per thread);
-    # (2, 64, 128, 64, 64) above takes it too
-    (1, 17, 36, 32, 48),      # ragged couts, odd height, last tile mostly outside
-    (2, 40, 128, 128, 64),    # upconv3.conv.3 class
+    # N, H, W, Cin, Cout, family
+    (1, 96, 192, 256, 256, "conv_w4hv_256x128"),   # 288 tiles > 256 CUs: blocks take a second tile; vertical reuse, 4 x 64
+    (2, 64, 128, 64, 64, "conv_w4s_256x64"),       # 64 couts: row-reuse arrangement, 4 x 64
+    (1, 40, 64, 48, 96, "conv_ws_128x128"),        # Cin % 32 != 0: F(2,3) kernel, 9 K-steps (odd)
+    (1, 30, 50, 512, 130, "conv_ws_128x128"),      # W % 4 != 0: F(2,3), ragged couts, tiles crossing image rows
+    # conv_w43.hip (Winograd F(4,3): Cin % 32 == 0, Cout > 64, W % 4 == 0)
+    (1, 30, 52, 512, 130, "conv_w4s_256x128"),     # H % 4 != 0: flattened-pixel tiles, ragged couts, last tile partly outside
+    (2, 17, 36, 64, 128, "conv_w4s_256x128"),      # 12 K-steps, two images, odd height
+    (1, 64, 128, 128, 256, "conv_w4hv_256x128"),   # two cout tiles per pixel tile
+    (3, 8, 4, 32, 96, "conv_w4s_256x128"),         # a single quad per row: both column paddings in one quad
+    # 32 < Cout <= 64: the 64-cout arrangement of conv_w43.hip (512-pixel tiles, two gather items per thread)
+    (1, 17, 36, 32, 48, "conv_w4s_512x64"),        # ragged couts, odd height, last tile mostly outside
+    (2, 40, 128, 128, 64, "conv_w4s_256x64"),      # upconv3.conv.3 class (row reuse, 4 x 64)
     # 32 < Cout <= 64 on images that tile as 4 rows x 64 columns / 2 rows x 128 columns: the row-reuse arrangement
-    # (conv_w43r_kernel, both geometries; (2, 64, 128, 64, 64) and (2, 40, 128, 128, 64) above take 4 x 64)
-    (1, 6, 128, 32, 48),      # 2 x 128 (H % 4 != 0): two channel groups, one tile per row pair, ragged couts
-    (2, 8, 256, 64, 64),      # 4 x 64: slice1.3 class, four channel groups, four tiles per row quad, two images
-    (1, 4, 384, 96, 40),      # 4 x 64: six channel groups, one row quad
-    (2, 10, 256, 64, 64),     # 2 x 128: two tiles per row pair, two images
-    (3, 12, 64, 32, 33),      # 4 x 64: one tile per row quad, one live column in the second cout half
+    (1, 6, 128, 32, 48, "conv_w4s_256x64"),        # 2 x 128 (H % 4 != 0): two channel groups, one tile per row pair, ragged couts
+    (2, 8, 256, 64, 64, "conv_w4s_256x64"),        # 4 x 64: slice1.3 class, four channel groups, four tiles per row quad, two images
+    (1, 4, 384, 96, 40, "conv_w4s_256x64"),        # 4 x 64: six channel groups, one row quad
+    (2, 10, 256, 64, 64, "conv_w4s_256x64"),       # 2 x 128: two tiles per row pair, two images
+    (3, 12, 64, 32, 33, "conv_w4s_256x64"),        # 4 x 64: one tile per row quad, one live column in the second cout half
     # Cout > 64 on images that tile as 4 rows x 64 columns or 8 rows x 32 columns: the vertical-reuse arrangement
-    # (conv_w43v_kernel); (1, 96, 192, 256, 256) and (1, 64, 128, 128, 256) above take it too (4 x 64)
-    (2, 8, 256, 64, 128),     # 4 x 64: slice1.7 class, four channel groups, four tiles per row quad, two images
-    (1, 4, 192, 32, 130),     # 4 x 64: one row quad (both vertical paddings in every tile), two cout blocks, ragged couts
-    (3, 12, 64, 96, 96),      # 4 x 64: one tile per row quad (both column paddings in every tile), six channel groups
-    (2, 16, 96, 64, 128),     # 8 x 32: slice4.34 class geometry (96 wide), two row octets, three column blocks, two images
-    (1, 8, 32, 32, 130),      # 8 x 32: a single tile per image (all four paddings), two cout blocks, ragged couts
-    (3, 24, 160, 96, 96),     # 8 x 32: five column blocks, three row octets, six channel groups, three images
-    (1, 6, 128, 32, 130),     # H % 4 != 0: stays on conv_w43_kernel (flattened-pixel tiles)
+    (2, 8, 256, 64, 128, "conv_w4hv_256x128"),     # 4 x 64: slice1.7 class, four channel groups, four tiles per row quad, two images
+    (1, 4, 192, 32, 130, "conv_w4hv_256x128"),     # 4 x 64: one row quad (both vertical paddings in every tile), ragged couts
+    (3, 12, 64, 96, 96, "conv_w4hv_256x128"),      # 4 x 64: one tile per row quad (both column paddings in every tile)
+    (2, 16, 96, 64, 128, "conv_w4ht_256x128"),     # 8 x 32: slice4.34 class geometry (96 wide), two images
+    (1, 8, 32, 32, 130, "conv_w4ht_256x128"),      # 8 x 32: a single tile per image (all four paddings), ragged couts
+    (3, 24, 160, 96, 96, "conv_w4ht_256x128"),     # 8 x 32: five column blocks, three row octets, three images
+    (1, 6, 128, 32, 130, "conv_w4s_256x128"),      # H % 4 != 0: stays on conv_w43_kernel (flattened-pixel tiles)
     # Cout <= 32 (conv_hsplit.hip: haloed 8x32 tile split once into LDS; needs >= 4096 pixels)
-    (1, 64, 64, 32, 32),      # conv_cls.0 / .2 class, tiles exact
-    (2, 70, 45, 64, 32),      # upconv4.conv.3 class: 4 chunks, ragged tiles in both directions, two images
-    (1, 67, 100, 32, 16),     # conv_cls.4 class: 16 of 32 columns used
-    (1, 130, 33, 16, 7),      # one chunk, a single used column in the second tile column
+    (1, 64, 64, 32, 32, "conv_hs_256x32"),         # conv_cls.0 / .2 class, tiles exact
+    (2, 70, 45, 64, 32, "conv_hs_256x32"),         # upconv4.conv.3 class: 4 chunks, ragged tiles in both directions, two images
+    (1, 67, 100, 32, 16, "conv_hs_256x16"),        # conv_cls.4 class: the 16-wide product tile
+    (1, 130, 33, 16, 7, "conv_hs_256x16"),         # one chunk, a single used column in the second tile column
 ]
+
+
+def _expect_family(ctx, rows, family):
+    """The profiler must show the launch on `family` (name of the default arithmetic; KOCR_SPLIT=bf16 maps the fp16 rows
+    back to their bf16x3 kernels).  Skipped when a KOCR_* developer switch other than KOCR_SPLIT is set."""
+    if any(k.startswith("KOCR_") and k not in ("KOCR_SPLIT",) for k in os.environ):
+        return
+    if ctx.get_split_mode() == 0:
+        family = family.replace("conv_w4h", "conv_w4")
+    conv = sorted(k for k in rows if k.startswith("conv"))
+    assert conv == [family], f"expected the launch on {family}, profiler rows: {sorted(rows)}"
 
 
 @pytest.mark.parametrize("case", SPLIT_CASES, ids=[str(c) for c in SPLIT_CASES])
 def test_split_kernel_is_fp32_class_against_fp64(ctx, case):
-    n, h, w, cin, cout = case
-    rng = np.random.default_rng(_seed(case))
+    n, h, w, cin, cout, family = case
+    rng = np.random.default_rng(_seed(case[:5]))
     x = np.maximum(rng.standard_normal((n, h, w, cin)), 0).astype(np.float32)  # post-ReLU-like, half zeros
     wt = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
     got = ctx.conv2d_nhwc(x, wt).astype(np.float64)
+    rows = ctx.profile_report()
+    ctx.profile_enable(False)
+    _expect_family(ctx, rows, family)
     xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
     wtt = torch.from_numpy(wt).double().permute(3, 2, 0, 1)
     want = F.conv2d(xt, wtt, None, padding=1).permute(0, 2, 3, 1).numpy()
     bound = F.conv2d(xt.abs(), wtt.abs(), None, padding=1).permute(0, 2, 3, 1).numpy()
     ratio = np.abs(got - want) / np.maximum(bound, 1e-30)
     rms = float(np.sqrt((ratio ** 2).mean()))
-    print(f"split conv {case}: max err / (|x| conv |w|) = {ratio.max():.3e}, rms = {rms:.3e}")
+    print(f"split conv {case[:5]} on {family}: max err / (|x| conv |w|) = {ratio.max():.3e}, rms = {rms:.3e}")
     assert float(ratio.max()) <= 1e-6, f"max err / (|x| conv |w|) = {ratio.max():.3e}"
     assert rms <= 1.5e-7, f"rms = {rms:.3e}"
 
@@ -200,29 +217,32 @@ def test_k5_kernel_is_fp32_class_against_fp64(ctx, case):
 
 # conv_dsplit.hip: the same bf16x3 arithmetic for 1x1 / dilated / larger kernels (>= 4096 pixels)
 DSPLIT_CASES = [
-    # N, H, W, Cin, Cout, k, dil
-    (1, 96, 96, 512, 256, 3, 6),    # slice5.1 class (dilated), 256x128 tiles
-    (2, 64, 72, 1024, 128, 1, 1),   # slice5.2 class
-    (1, 192, 192, 192, 64, 1, 1),   # upconv4.conv.0 class: 512x64 tiles
-    (1, 70, 61, 48, 100, 1, 1),     # ragged pixels / couts, 3 K-steps
-    (1, 65, 67, 32, 40, 5, 1),      # 5x5, tiles crossing rows, odd sizes
-    (2, 50, 90, 64, 70, 3, 2),      # dilation 2, two images
-    # dilated layers with W % (4 dil) == 0, Cin % 32 == 0, Cout > 64 take conv_w43.hip (Winograd F(4,3) on the comb
-    # of pixels dil apart) -- the first case above does too
-    (2, 48, 48, 64, 128, 3, 6),     # slice5.1 geometry at 768x768 input
-    (1, 33, 40, 32, 96, 3, 2),      # dilation 2, odd height, ragged couts, tile ends inside a row
+    # N, H, W, Cin, Cout, k, dil, family
+    (1, 96, 96, 512, 256, 3, 6, "conv_w4s_256x128_dil"),   # slice5.1 class: dilated, W % (4 dil) == 0 -> F(4,3) on the comb of pixels
+    (2, 64, 72, 1024, 128, 1, 1, "conv_ds_256x128"),       # slice5.2 class
+    (1, 192, 192, 192, 64, 1, 1, "conv_ds_512x64"),        # upconv4.conv.0 class: 512x64 tiles
+    (1, 70, 61, 48, 100, 1, 1, "conv_ds_256x128"),         # ragged pixels / couts, 3 K-steps
+    (1, 65, 67, 32, 40, 5, 1, "conv_ds_512x64"),           # 5x5, tiles crossing rows, odd sizes
+    (2, 50, 90, 64, 70, 3, 2, "conv_ds_256x128"),          # dilation 2, W % 8 != 0: direct split kernel, two images
+    (2, 48, 48, 64, 128, 3, 6, "conv_w4s_256x128_dil"),    # slice5.1 geometry at 768x768 input
+    (1, 33, 40, 32, 96, 3, 2, "conv_w4s_256x128_dil"),     # dilation 2, odd height, ragged couts, tile ends inside a row
 ]
 
 
 @pytest.mark.parametrize("case", DSPLIT_CASES, ids=[str(c) for c in DSPLIT_CASES])
 def test_direct_split_kernel_is_fp32_class_against_fp64(ctx, case):
-    n, h, w, cin, cout, k, dil = case
-    rng = np.random.default_rng(_seed(case))
+    n, h, w, cin, cout, k, dil, family = case
+    rng = np.random.default_rng(_seed(case[:7]))
     x = np.maximum(rng.standard_normal((n, h, w, cin)), 0).astype(np.float32)
     wt = (rng.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32)
     pre_a = rng.uniform(0.5, 1.5, cout).astype(np.float32)
     pre_b = rng.uniform(-0.3, 0.3, cout).astype(np.float32)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
     got = ctx.conv2d_nhwc(x, wt, dilation=dil, pre_a=pre_a, pre_b=pre_b, relu=True).astype(np.float64)
+    rows = ctx.profile_report()
+    ctx.profile_enable(False)
+    _expect_family(ctx, rows, family)
     xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
     wtt = torch.from_numpy(wt).double().permute(3, 2, 0, 1)
     pad = dil * (k // 2)

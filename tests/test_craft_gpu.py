@@ -1,6 +1,6 @@
 """CRAFT forward on the GPU (HIP path, through the C-ABI) vs the CPU oracle.
 
-Tolerance (stated, fp32): max |heat_gpu - heat_oracle| <= 2e-4 — the reference's own
+Tolerance (stated, fp32): max |heat_gpu - heat_oracle| <= 5e-5 — the reference's own
 cross-framework bar is decimal=4, i.e. 1.5e-4 (tests/test_pytorch_keras.py:49) on
 real weights; seeded weights keep activations O(1) so the same scale applies.
 """
@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-HEAT_TOL = 2e-4
+HEAT_TOL = 5e-5  # measured ~2e-5 (was 2e-4, 10x looser than measured)
 
 
 @pytest.fixture(scope="module")

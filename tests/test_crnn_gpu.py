@@ -1,7 +1,7 @@
 """CRNN recogniser on the GPU (conv/GEMM on MFMA, STN sampler, LSTM recurrence, CTC wave
 decoder — through kocr_crnn_forward) vs the CPU oracle (oracle/crnn.py, recognition.py:187-333).
 
-Tolerance (stated, fp32): softmax probabilities |dp| <= 2e-4; label rows must be EXACTLY equal
+Tolerance (stated, fp32): softmax probabilities |dp| <= 1e-4; label rows must be EXACTLY equal
 wherever the oracle's per-step top-2 probability margin exceeds 1e-3 on every step of the row
  — a smaller margin can legitimately flip an argmax under fp32 reordering."""
 import numpy as np
@@ -11,7 +11,7 @@ from tests import synth
 
 pytestmark = pytest.mark.gpu
 
-PROB_TOL = 2e-4
+PROB_TOL = 1e-4  # measured ~4e-5 (was 2e-4)
 MARGIN = 1e-3
 
 

@@ -9,6 +9,8 @@ once per process): the fp64-bounded convolution tests and the CRAFT heat-map-vs-
   KOCR_LINFOLD=0 KOCR_UPFOLD=0                 -> the layer-by-layer CRAFT schedule (slice5.1, slice5.2, resize + concat)
   KOCR_K5=0      no 5x5 / 16-cout kernel    -> the recogniser's stn_conv_1 on the fp32 MFMA kernel
   KOCR_HS16=0    no 16-wide product tile    -> conv_cls.4 on conv_hs_kernel's 32-column tile
+  KOCR_SPLIT=bf16  the exact bf16x3 split everywhere (round 3's default arithmetic)
+  KOCR_W43H=0    no fp16 F(4,3) kernels     -> the default mode's fp16 layers on their bf16x3 kernels
 
 (these paths were reached by the driver's suite only through the shapes that happen to select
 them.)  Each configuration is one pytest child process over the same test files, same bounds."""
@@ -31,6 +33,8 @@ CONFIGS = [
     {"KOCR_LINFOLD": "0", "KOCR_UPFOLD": "0"},
     {"KOCR_K5": "0"},
     {"KOCR_HS16": "0"},
+    {"KOCR_SPLIT": "bf16"},
+    {"KOCR_W43H": "0"},
 ]
 
 

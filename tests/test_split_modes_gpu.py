@@ -1,16 +1,24 @@
-"""Both arithmetic modes of the wide convolutions (include/kocr.h KOCR_SPLIT_*) against fp64.
+"""The arithmetic modes of the wide convolutions (include/kocr.h KOCR_SPLIT_*) against fp64.
 
-bf16x3 (default): exact 3-way bf16 split, 6 products.  f16x2: round-to-nearest 2-way fp16 split, 3
-products, exact power-of-two scaling of inputs (from the tensor's tracked max |x|) and weights.  Stated
-bounds, elementwise, S = |x| conv |w| in fp64:
+bf16x3: exact 3-way bf16 split, 6 products, every wide layer.  f16x2 (the default since round 4): the Winograd F(4,3)
+layers whose images tile as 4 x 64 / 8 x 32 pixels run on the fp16 cores (csrc/conv_w43h.hip): round-to-nearest 2-way
+fp16 split, 3 products, inputs scaled by an exact power of two PER IMAGE (from the max |x| slot the producer tracked or a
+reduction on demand), weights per output channel; every other layer runs the bf16x3 kernels.  Stated bounds, elementwise,
+S = |x| conv |w| in fp64, max|x| taken per image:
 
     bf16x3:  |err| <= 1e-6 * S
     f16x2 :  |err| <= 1e-6 * S + 2^-36 * max|x| * (1 conv |w|)
 
-The second term is the fp16 low piece going subnormal for elements more than 2^16 below the tensor's
-maximum (their absolute error stays <= 2^-39 max|x|); on tensors of ordinary dynamic range it is far
-below the first.  The rest of the GPU suite runs in the context's default mode; this module pins both.
+The second term is the fp16 low piece going subnormal for elements more than 2^16 below their image's maximum (their
+absolute error stays <= 2^-38 max|x|); on tensors of ordinary dynamic range it is far below the first.
+
+f16x1 (KOCR_SPLIT_F16X1, opt-in REDUCED PRECISION fast mode): one fp16 piece per operand, one product -- relative operand
+error 2^-12.  Stated tolerance (SURVEY 8(f).4 "re-stated tolerance"):  |err| <= 1e-3 * S + 2^-24 * max|x| * (1 conv |w|)
+elementwise and rms(err / S) <= 1e-4 on the F(4,3) layers (measured 1.3-2.8e-4 / 1.8-3.8e-5); CRAFT heat-maps within 5e-3 of the
+oracle on maps of magnitude ~3 (measured 1e-3), i.e. 100x the fp32-class modes -- and therefore never a default and never `value` in bench.py.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -42,31 +50,50 @@ def _ref64(x, w, dil):
 def _check(got, x, w, dil, mode):
     want, s, ones = _ref64(x, w, dil)
     bound = 1e-6 * s
-    if mode == "f16x2":
-        bound = bound + 2.0 ** -36 * float(np.abs(x).max()) * ones
+    if mode == "f16x2":  # per-image max |x|
+        amax = np.abs(x).reshape(x.shape[0], -1).max(axis=1).astype(np.float64).reshape(-1, 1, 1, 1)
+        bound = bound + 2.0 ** -36 * amax * ones
     err = np.abs(got.astype(np.float64) - want)
     worst = float((err / np.maximum(bound, 1e-300)).max())
     assert np.isfinite(got).all()
     assert worst <= 1.0, f"{mode}: max err / bound = {worst:.3f}"
 
 
+def _conv_rows(ctx, x, wt, **kw):
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    got = ctx.conv2d_nhwc(x, wt, **kw)
+    rows = sorted(k for k in ctx.profile_report() if k.startswith("conv"))
+    ctx.profile_enable(False)
+    return got, rows
+
+
+def _plain_env():
+    return not any(k.startswith("KOCR_") and k != "KOCR_SPLIT" for k in os.environ)
+
+
 CASES = [
-    # N, H, W, Cin, Cout, k, dil
-    (1, 48, 96, 256, 256, 3, 1),   # Winograd split kernel, 128x128 tiles
-    (1, 32, 128, 64, 64, 3, 1),    # 256x64 tiles
-    (1, 96, 96, 128, 192, 1, 1),   # direct split kernel, 1x1
-    (1, 80, 64, 64, 128, 3, 6),    # direct split kernel, dilated
+    # N, H, W, Cin, Cout, k, dil, kernel family in f16x2 mode
+    (1, 48, 192, 256, 256, 3, 1, "conv_w4hv_256x128"),   # fp16 F(4,3), 4 x 64 tiles
+    (2, 16, 96, 128, 128, 3, 1, "conv_w4ht_256x128"),    # fp16 F(4,3), 8 x 32 tiles, two images
+    (1, 32, 128, 64, 64, 3, 1, "conv_w4s_256x64"),       # 64 couts: bf16x3 row-reuse kernel in both modes
+    (1, 96, 96, 128, 192, 1, 1, "conv_ds_256x128"),      # direct split kernel, 1x1 (bf16x3 in both modes)
+    (1, 80, 64, 64, 128, 3, 6, "conv_ds_256x128"),       # direct split kernel, dilated, W % 24 != 0
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
 def test_fp32_class_on_ordinary_data(mode_ctx, case):
     ctx, mode = mode_ctx
-    n, h, w, cin, cout, k, dil = case
-    rng = np.random.default_rng(hash(case) % 2 ** 32)
+    n, h, w, cin, cout, k, dil, family = case
+    rng = np.random.default_rng(abs(hash(case[:7])) % 2 ** 32)
     x = np.maximum(rng.standard_normal((n, h, w, cin)), 0).astype(np.float32)
     wt = (rng.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32)
-    _check(ctx.conv2d_nhwc(x, wt, dilation=dil), x, wt, dil, mode)
+    got, rows = _conv_rows(ctx, x, wt, dilation=dil)
+    if _plain_env():
+        want_row = family if mode == "f16x2" else family.replace("conv_w4h", "conv_w4")
+        assert rows == [want_row], f"{mode}: expected {want_row}, profiler rows {rows}"
+    _check(got, x, wt, dil, mode)
 
 
 @pytest.mark.parametrize("scale_x,scale_w", [(1e-20, 1.0), (1e20, 1e-3), (3e-7, 5e4), (1.0, 1e-25)])
@@ -76,6 +103,20 @@ def test_extreme_magnitudes_are_rescaled_exactly(mode_ctx, scale_x, scale_w):
     rng = np.random.default_rng(11)
     x = (np.maximum(rng.standard_normal((1, 40, 64, 64)), 0) * scale_x).astype(np.float32)
     wt = (rng.standard_normal((3, 3, 64, 96)) * 0.05 * scale_w).astype(np.float32)
+    got, rows = _conv_rows(ctx, x, wt)
+    if _plain_env() and mode == "f16x2":
+        assert rows == ["conv_w4hv_256x128"], rows
+    _check(got, x, wt, 1, mode)
+
+
+def test_weights_of_very_different_channels_are_scaled_per_cout(mode_ctx):
+    """Output channels whose weights differ by 1e8 in magnitude: the per-cout weight exponent keeps each inside fp16."""
+    ctx, mode = mode_ctx
+    rng = np.random.default_rng(13)
+    x = np.maximum(rng.standard_normal((1, 16, 64, 32)), 0).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, 32, 96)) * 0.05).astype(np.float32)
+    wt[..., ::3] *= 1e-4
+    wt[..., 1::3] *= 1e4
     _check(ctx.conv2d_nhwc(x, wt), x, wt, 1, mode)
 
 
@@ -95,22 +136,42 @@ def test_wide_dynamic_range_inside_one_tensor(mode_ctx):
     assert float(rel.max()) <= (1e-6 if mode == "bf16x3" else 2e-4)
 
 
-def test_all_zero_input(mode_ctx):
+def test_every_image_has_its_own_scale(mode_ctx):
+    """Images of very different magnitude in one batch: each result is BIT-IDENTICAL to the image convolved alone (the
+    input scale is per image: nothing depends on what else is in the batch), and the weak image keeps fp32-class
+    accuracy relative to itself."""
+    ctx, mode = mode_ctx
+    rng = np.random.default_rng(14)
+    x = np.maximum(rng.standard_normal((3, 16, 128, 64)), 0).astype(np.float32)
+    x[1] *= 1e-6
+    x[2] *= 1e5
+    wt = (rng.standard_normal((3, 3, 64, 128)) * 0.05).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, 128).astype(np.float32)
+    got = ctx.conv2d_nhwc(x, wt, pre_b=b, relu=True)
+    for i in range(3):
+        alone = ctx.conv2d_nhwc(x[i:i + 1], wt, pre_b=b, relu=True)
+        assert np.array_equal(got[i:i + 1], alone), f"{mode}: image {i} depends on its batch"
+    _check(ctx.conv2d_nhwc(x, wt), x, wt, 1, mode)
+
+
+@pytest.mark.parametrize("cout", [64, 128])
+def test_all_zero_input(mode_ctx, cout):
     ctx, mode = mode_ctx
     x = np.zeros((1, 32, 64, 64), np.float32)
-    wt = np.ones((3, 3, 64, 64), np.float32)
-    b = np.linspace(-1, 1, 64).astype(np.float32)
+    wt = np.ones((3, 3, 64, cout), np.float32)
+    b = np.linspace(-1, 1, cout).astype(np.float32)
     got = ctx.conv2d_nhwc(x, wt, pre_b=b)
     assert np.array_equal(got, np.broadcast_to(b, got.shape))
 
 
 def test_heatmaps_agree_between_modes(ctx, craft_weights):
-    """Whole CRAFT forward (tracked max|x| slots through convs, pools, up-sampling, concat buffers)."""
+    """Whole CRAFT forward (per-image max|x| slots through convs, pools, the folded decoder, concat buffers)."""
     from oracle import craft as ocraft
 
     ctx.load_craft(craft_weights)
     rng = np.random.default_rng(5)
     img = rng.integers(0, 256, (2, 128, 192, 3), dtype=np.uint8)
+    img[1] //= 6  # a dark page next to a bright one: the two images get different input scales
     want = ocraft.detector_predict(craft_weights, img)
     old = ctx.get_split_mode()
     try:
@@ -118,8 +179,11 @@ def test_heatmaps_agree_between_modes(ctx, craft_weights):
         for mode in MODES:
             ctx.set_split_mode(mode)
             out[mode] = ctx.craft_forward(img)
-            assert float(np.abs(out[mode] - want).max()) <= 2e-4, mode
+            assert float(np.abs(out[mode] - want).max()) <= 5e-5, mode
         assert float(np.abs(out["bf16x3"] - out["f16x2"]).max()) <= 5e-5
+        ctx.set_split_mode("f16x2")  # batch invariance of the whole detector in the default mode, bit for bit
+        for i in range(2):
+            assert np.array_equal(ctx.craft_forward(img[i:i + 1]), out["f16x2"][i:i + 1])
     finally:
         ctx.set_split_mode(old)
 
@@ -136,7 +200,7 @@ def test_crnn_labels_agree_between_modes(ctx, crnn_weights):
             res[mode] = ctx.crnn_forward(crops, return_probs=True)
         la, pa = res["bf16x3"]
         lb, pb = res["f16x2"]
-        # the CRNN parity bar against the oracle is 2e-4 on the softmax (tests/test_crnn_gpu.py); two
+        # the CRNN parity bar against the oracle is 1e-4 on the softmax (tests/test_crnn_gpu.py); two
         # fp32-class evaluations of the same graph differ by round-off amplified through the two BiLSTMs
         assert float(np.abs(pa - pb).max()) <= 1e-4
         top2 = np.sort(pa, axis=-1)[..., -2:]
@@ -144,3 +208,59 @@ def test_crnn_labels_agree_between_modes(ctx, crnn_weights):
         assert np.array_equal(la[safe], lb[safe])
     finally:
         ctx.set_split_mode(old)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# KOCR_SPLIT_F16X1: the reduced-precision fast mode and its stated tolerance
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def fast_ctx(ctx):
+    old = ctx.get_split_mode()
+    ctx.set_split_mode("f16x1")
+    yield ctx
+    ctx.set_split_mode(old)
+
+
+FAST_CASES = [
+    (1, 48, 192, 256, 256, "conv_w4qv_256x128"),
+    (2, 16, 96, 128, 128, "conv_w4qt_256x128"),
+    (1, 96, 192, 512, 130, "conv_w4qv_256x128"),
+]
+
+
+@pytest.mark.parametrize("case", FAST_CASES, ids=[str(c) for c in FAST_CASES])
+def test_fast_mode_holds_its_stated_tolerance(fast_ctx, case):
+    n, h, w, cin, cout, family = case
+    rng = np.random.default_rng(abs(hash(case[:5])) % 2 ** 32)
+    x = np.maximum(rng.standard_normal((n, h, w, cin)), 0).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32)
+    got, rows = _conv_rows(fast_ctx, x, wt)
+    if _plain_env():
+        assert rows == [family], rows
+    want, s, ones = _ref64(x, wt, 1)
+    amax = np.abs(x).reshape(n, -1).max(axis=1).astype(np.float64).reshape(-1, 1, 1, 1)
+    err = np.abs(got.astype(np.float64) - want)
+    ratio = err / np.maximum(s, 1e-300)
+    rms = float(np.sqrt((ratio ** 2).mean()))
+    print(f"fast conv {case[:5]}: max err / S = {ratio.max():.3e}, rms = {rms:.3e}")
+    assert float((err / (1e-3 * s + 2.0 ** -24 * amax * ones)).max()) <= 1.0
+    assert rms <= 1e-4
+    # ... and it is NOT an fp32-class mode: the test would be vacuous if the full-precision kernel had run
+    assert float(ratio.max()) > 5e-6
+
+
+def test_fast_mode_heatmaps_and_boxes(fast_ctx, craft_weights):
+    """CRAFT in the fast mode: heat-maps within the stated 5e-3 of the oracle (maps of magnitude ~3), and the per-image
+    scale still makes every image independent of its batch, bit for bit."""
+    from oracle import craft as ocraft
+
+    fast_ctx.load_craft(craft_weights)
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (2, 128, 192, 3), dtype=np.uint8)
+    want = ocraft.detector_predict(craft_weights, img)
+    got = fast_ctx.craft_forward(img)
+    err = float(np.abs(got - want).max())
+    print(f"fast mode heat-map error {err:.3e} on maps of magnitude {np.abs(want).max():.2f}")
+    assert err <= 5e-3
+    for i in range(2):
+        assert np.array_equal(fast_ctx.craft_forward(img[i:i + 1]), got[i:i + 1])

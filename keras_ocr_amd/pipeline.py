@@ -69,17 +69,17 @@ class Pipeline:
         crosses ranks in ``dist.ShardedPipeline``."""
         if not isinstance(images, np.ndarray):
             images = [tools.read(image) for image in images]
-        images = list(images)
-        for im in images:
-            if getattr(im, "dtype", None) != np.uint8:
-                raise TypeError("Pipeline.recognize expects uint8 RGB images (what tools.read returns); "
-                                f"got {getattr(im, 'dtype', type(im))}")
         images = [np.ascontiguousarray(im) for im in images]
         if not images:
             return [], np.zeros((0, 48), np.int32)
         detection_kwargs = dict(detection_kwargs or {})
         del recognition_kwargs  # Keras predict kwargs: no effect on results
         ctx = getattr(self.detector, "_ctx", None)
+        if any(im.dtype != np.uint8 for im in images):
+            # float (or any non-uint8) images: the reference's cv2 calls interpolate them in float (tools.py:394, :107);
+            # the stage-wise path does the same on the host (tools.resize_linear_float / warp_box_float) -- off the fused
+            # fixed-point GPU path, which is defined for uint8 pixels only
+            return self._recognize_stagewise([im.astype(np.float32) for im in images], detection_kwargs, hmax, wmax)
         if ctx is None or getattr(self.recognizer, "_ctx", None) is not ctx:
             # duck-typed / separately-placed stages: the reference's stage-wise path (pipeline.py:44-75)
             return self._recognize_stagewise(images, detection_kwargs, hmax, wmax)

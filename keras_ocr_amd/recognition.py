@@ -127,6 +127,16 @@ class Recognizer:
             start = 0 if not start_end else start_end[-1][1]
             start_end.append((start, start + len(boxes)))
         images = [np.asarray(image) for image in images]
+        if any(im.dtype != np.uint8 for im in images):
+            # float images (recognition.py:507-526 works in the image's own type): gray conversion and the crop warp in
+            # float on the host (tools.rgb2gray_float / warp_box_float), the recogniser itself on the GPU
+            crops = []
+            for image, boxes in zip(images, box_groups):
+                gray = tools.rgb2gray_float(image) if image.ndim == 3 and image.shape[-1] == 3 else np.asarray(image, np.float32)
+                crops += [tools.warp_box_float(gray, box, 31, 200) for box in boxes]
+            labels = self._ctx.crnn_forward(np.stack(crops) / np.float32(255))
+            predictions = self._decode(labels)
+            return [predictions[start:end] for start, end in start_end]
         if len({im.shape for im in images}) == 1:
             # one size (what Pipeline / Detector hand over): crops never leave HBM
             labels = self._ctx.recognize_boxes(np.stack(images), box_groups)

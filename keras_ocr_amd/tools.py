@@ -12,21 +12,139 @@ import numpy as np
 from . import _lib
 
 
+def _decoded_to_array(img, as_imread):
+    """PIL image -> what cv2 hands back for it (before the BGR->RGB swap of tools.py:38).  ``as_imread``: cv2.imread's
+    default IMREAD_COLOR (always 8-bit, 3 channels: 16-bit samples keep their high byte, alpha is dropped, gray is
+    replicated); otherwise cv2.imdecode(IMREAD_UNCHANGED) (depth and channel count as stored)."""
+    mode = img.mode
+    if mode in ("I;16", "I;16B", "I;16L", "I"):  # 16-bit gray (PIL reads 16-bit PNG / TIFF gray as one of these)
+        arr = np.asarray(img).astype(np.uint16)
+        if as_imread:
+            g = (arr >> 8).astype(np.uint8)
+            return np.stack([g, g, g], -1)
+        return arr  # 2-D uint16: the reference's cvtColor(BGR2RGB) rejects it, see read()
+    if mode in ("1", "L"):
+        g = np.asarray(img.convert("L"))
+        return np.stack([g, g, g], -1) if as_imread else g
+    if mode == "LA":
+        if as_imread:
+            g = np.asarray(img.convert("L"))
+            return np.stack([g, g, g], -1)
+        return np.asarray(img)  # 2 channels: rejected like the reference
+    if mode == "P":
+        img = img.convert("RGBA" if "transparency" in img.info else "RGB")
+        mode = img.mode
+    if mode in ("RGBA", "RGBa", "RGBX"):
+        return np.asarray(img.convert("RGBA"))[..., :3]  # imread drops alpha; BGR2RGB of 4 channels drops it as well
+    return np.asarray(img.convert("RGB"))
+
+
 def read(filepath_or_buffer: typing.Union[str, io.BytesIO, np.ndarray]):
-    """tools.read (tools.py:19-38): ndarray passthrough; files / buffers / URLs are decoded to
-    RGB with PIL (OpenCV is not a dependency of this package)."""
+    """tools.read (tools.py:19-38): ndarray passthrough; files / buffers / URLs are decoded to RGB with PIL (OpenCV is
+    not a dependency of this package), following what the reference's two cv2 calls do:
+
+    * a PATH goes through ``cv2.imread`` (tools.py:36): 8-bit, 3 channels, and the EXIF orientation of the file is
+      APPLIED (imread's default) -- a JPEG a phone stored rotated comes out upright;
+    * a BUFFER / file object / URL goes through ``cv2.imdecode(IMREAD_UNCHANGED)`` (tools.py:30-31): stored depth and
+      channels, EXIF orientation NOT applied; an alpha channel is dropped by the BGR->RGB conversion that follows, a
+      gray or gray+alpha image makes that conversion fail (cv2.error in the reference, ValueError here)."""
     if isinstance(filepath_or_buffer, np.ndarray):
         return filepath_or_buffer
-    from PIL import Image  # local import: only needed for file inputs
+    from PIL import Image, ImageOps  # local import: only needed for file inputs
 
     if hasattr(filepath_or_buffer, "read"):
-        return np.array(Image.open(io.BytesIO(filepath_or_buffer.read())).convert("RGB"))
+        image = _decoded_to_array(Image.open(io.BytesIO(filepath_or_buffer.read())), as_imread=False)
+        if image.ndim != 3 or image.shape[2] not in (3, 4):
+            raise ValueError("tools.read: a gray image read from a buffer cannot be converted BGR->RGB "
+                             "(the reference's cv2.cvtColor raises here, tools.py:38); pass a path or an array")
+        return image[..., :3]
     if isinstance(filepath_or_buffer, str):
         if urllib.parse.urlparse(filepath_or_buffer).scheme in ("http", "https"):
             return read(urllib.request.urlopen(filepath_or_buffer))  # pylint: disable=consider-using-with
         assert os.path.isfile(filepath_or_buffer), "Could not find image at path: " + filepath_or_buffer
-        return np.array(Image.open(filepath_or_buffer).convert("RGB"))
+        return _decoded_to_array(ImageOps.exif_transpose(Image.open(filepath_or_buffer)), as_imread=True)
     raise TypeError(f"Unsupported image source: {type(filepath_or_buffer)}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# float images (any dtype but uint8): the reference's cv2 calls work in the image's own type -- cv2.resize interpolates in
+# float (tools.py:394), cvtColor / warpPerspective likewise (recognition.py:510, tools.py:107).  The uint8 path runs in
+# fixed point on the GPU; this is the float restatement, on the host in numpy (off the benchmarked path; NOT checked
+# against OpenCV, which is absent from this image -- INTEGRATION.md section 4b).
+# ---------------------------------------------------------------------------------------------------------------------
+def resize_linear_float(image, dsize):
+    """cv2.resize(image, dsize=(width, height)) for a float image, INTER_LINEAR: source coordinate
+    (d + 0.5) * (src / dst) - 0.5, taps clamped to the image (replicated border), horizontal pass then vertical
+    pass, float32 coefficients."""
+    src = np.asarray(image, dtype=np.float32)
+    dw, dh = int(dsize[0]), int(dsize[1])
+    sh, sw = src.shape[:2]
+    if (dw, dh) == (sw, sh):
+        return src.copy()
+
+    def taps(dst_n, src_n):
+        f = (np.arange(dst_n, dtype=np.float64) + 0.5) * (src_n / dst_n) - 0.5
+        i0 = np.floor(f).astype(np.int64)
+        a = (f - i0).astype(np.float32)
+        a[i0 < 0] = 0
+        i0 = np.clip(i0, 0, src_n - 1)
+        i1 = np.clip(i0 + 1, 0, src_n - 1)
+        return i0, i1, a
+
+    x0, x1, ax = taps(dw, sw)
+    y0, y1, ay = taps(dh, sh)
+    ax = ax.reshape((1, dw) + (1,) * (src.ndim - 2))
+    ay = ay.reshape((dh, 1) + (1,) * (src.ndim - 2))
+    rows = src[:, x0] * (np.float32(1) - ax) + src[:, x1] * ax
+    return (rows[y0] * (np.float32(1) - ay) + rows[y1] * ay).astype(np.float32)
+
+
+def rgb2gray_float(image):
+    """cv2.cvtColor(float image, COLOR_RGB2GRAY): 0.299 R + 0.587 G + 0.114 B in float32."""
+    im = np.asarray(image, dtype=np.float32)
+    return im[..., 0] * np.float32(0.299) + im[..., 1] * np.float32(0.587) + im[..., 2] * np.float32(0.114)
+
+
+def warp_box_float(gray, box, target_height=31, target_width=200):
+    """tools.warpBox (tools.py:61-117, margin 0, cval 0) of a 2-D float image: get_rotated_box, integer width / height,
+    homography box -> [[0,0],[s w,0],[s w,s h],[0,s h]], cv2.warpPerspective with INTER_LINEAR (source coordinates rounded
+    to 1/32 pixel as OpenCV's remap does, float weights, constant-0 border), pasted top-left into target_height x
+    target_width zeros."""
+    box, _ = get_rotated_box(box)
+    w, h = get_rotated_width_height(box)
+    scale = min(target_width / w, target_height / h)  # ZeroDivisionError for an empty box, as in the reference
+    dst = np.array([[0, 0], [scale * w, 0], [scale * w, scale * h], [0, scale * h]], np.float32).astype(np.float64)
+    srcq = np.asarray(box, np.float32).astype(np.float64)
+    a, b = [], []
+    for (x, y), (u, v) in zip(srcq, dst):  # getPerspectiveTransform: 8 x 8 system for M (src -> dst)
+        a.append([x, y, 1, 0, 0, 0, -x * u, -y * u])
+        a.append([0, 0, 0, x, y, 1, -x * v, -y * v])
+        b += [u, v]
+    m = np.append(np.linalg.solve(np.array(a), np.array(b)), 1.0).reshape(3, 3)
+    mi = np.linalg.inv(m)
+    cw, ch = int(scale * w), int(scale * h)
+    out = np.zeros((target_height, target_width), np.float32)
+    cw, ch = min(cw, target_width), min(ch, target_height)
+    if cw <= 0 or ch <= 0:
+        return out
+    xs, ys = np.meshgrid(np.arange(cw, dtype=np.float64), np.arange(ch, dtype=np.float64))
+    den = mi[2, 0] * xs + mi[2, 1] * ys + mi[2, 2]
+    den = np.where(den != 0, 1.0 / den, 0.0)
+    fx = np.rint((mi[0, 0] * xs + mi[0, 1] * ys + mi[0, 2]) * den * 32).astype(np.int64)
+    fy = np.rint((mi[1, 0] * xs + mi[1, 1] * ys + mi[1, 2]) * den * 32).astype(np.int64)
+    x0, y0 = fx >> 5, fy >> 5
+    ax, ay = ((fx & 31) / 32.0).astype(np.float32), ((fy & 31) / 32.0).astype(np.float32)
+    g = np.asarray(gray, np.float32)
+    hh, ww = g.shape
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < hh) & (xx >= 0) & (xx < ww)
+        return np.where(ok, g[np.clip(yy, 0, hh - 1), np.clip(xx, 0, ww - 1)], np.float32(0))
+
+    one = np.float32(1)
+    out[:ch, :cw] = (tap(y0, x0) * ((one - ax) * (one - ay)) + tap(y0, x0 + 1) * (ax * (one - ay))
+                     + tap(y0 + 1, x0) * ((one - ax) * ay) + tap(y0 + 1, x0 + 1) * (ax * ay))
+    return out
 
 
 def resize_scale(shape, max_scale, max_size):
@@ -39,6 +157,8 @@ def resize_scale(shape, max_scale, max_size):
 def resize_image(image, max_scale, max_size, ctx=None):
     """tools.resize_image (tools.py:378-398) -> (image, scale); cv2.resize runs on the GPU."""
     scale = resize_scale(image.shape, max_scale, max_size)
+    if np.asarray(image).dtype != np.uint8:  # cv2.resize interpolates a float image in float (host restatement)
+        return resize_linear_float(image, (int(image.shape[1] * scale), int(image.shape[0] * scale))), scale
     ctx = ctx or _lib.default_context()
     out = ctx.resize_pad(image[np.newaxis], (int(image.shape[1] * scale), int(image.shape[0] * scale)))[0]
     return out, scale

@@ -224,12 +224,11 @@ def fast_mode_leg(ctx, pipe, step, timed, args, world, out_default, pages, oracl
         ctx.set_split_mode(args.split)
 
 
-def respawn_under_torchrun(args):
+def respawn_under_torchrun(args, env):
     """`python bench.py --gpus N` outside torchrun: launch N ranks of this script on this node."""
     import socket
-    import torch
 
-    have = torch.cuda.device_count()
+    have = env.device_count()
     if have < args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node; refusing to "
                          "report a multi-GPU number from fewer devices")
@@ -244,12 +243,70 @@ def respawn_under_torchrun(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def main():
+class GpuEnv:
+    """The device plumbing of the bench: torch-ROCm tensors in HBM, torch.distributed over RCCL (backend "nccl").
+    tests/test_bench_cpu.py replaces it by a host double (gloo, mocked libkocr context) to execute main() at world
+    size 2 without a GPU -- everything else in main() is the code the driver runs."""
+    backend = "nccl"
+
+    def check(self, local_rank):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an AMD GPU (no CPU fallback)")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
+        torch.cuda.set_device(local_rank)
+
+    def device_count(self):
+        import torch
+
+        return torch.cuda.device_count()
+
+    def context(self, k, local_rank):
+        import torch
+
+        ctx = k.Context(local_rank)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        return ctx
+
+    def sync(self):
+        import torch
+
+        torch.cuda.synchronize()
+
+    def to_dev(self, arr):
+        import torch
+
+        return torch.from_numpy(arr).cuda()
+
+    def empty(self, shape, dtype):
+        import torch
+
+        return torch.empty(shape, dtype=dtype, device="cuda")
+
+    def rand(self, shape):
+        import torch
+
+        return torch.rand(shape, dtype=torch.float32, device="cuda")
+
+    def scalar(self, v):
+        import torch
+
+        return torch.tensor([v], dtype=torch.float64, device="cuda")
+
+    def cpu_baseline_ok(self):
+        return True
+
+
+def main(argv=None, env=None):
+    env = env or GpuEnv()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--side5", type=int, default=1536, help="page side of the configs[4] legs (1536; smaller only in tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split", choices=["bf16x3", "f16x2"], default="f16x2",
                     help="arithmetic of the wide convolutions for the headline number (include/kocr.h KOCR_SPLIT_*)")
@@ -264,10 +321,10 @@ def main():
                     help="keep the HIP-event profiler on for the WHOLE process (headline loop included) and report the "
                          "per-launch averages over every launch: the numbers a rocprofv3 --stats / --pmc run of the "
                          "same command must agree with (scripts/profile_final.sh)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        respawn_under_torchrun(args)
+        respawn_under_torchrun(args, env)
     if "WORLD_SIZE" not in os.environ and "MASTER_PORT" not in os.environ:
         import socket  # single process: rendezvous on a free local port (a fixed one may still be in TIME_WAIT)
 
@@ -282,20 +339,15 @@ def main():
     import torch
     import keras_ocr_amd as k
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an AMD GPU (no CPU fallback)")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
-    torch.cuda.set_device(local_rank)
-    rank, world = k.dist.init_from_env(backend="nccl", force=True)  # RCCL, also at N = 1
+    env.check(local_rank)
+    rank, world = k.dist.init_from_env(backend=env.backend, force=True)  # RCCL, also at N = 1
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but the process group has {world} rank(s)")
     seen = k.dist.ranks_seen()  # all-reduce of 1 over RCCL
     if seen != world:
         raise SystemExit(f"bench.py: all-reduce saw {seen} ranks, expected {world}")
-    ctx = k.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx = env.context(k, local_rank)
     ctx.set_split_mode(args.split)
     ctx.profile_reset()
     ctx.profile_enable(bool(args.profile_all))
@@ -335,7 +387,7 @@ def main():
     rec = k.recognition.Recognizer(weights=crnn_w, ctx=ctx)
     pipe = k.pipeline.Pipeline(detector=det, recognizer=rec, scale=SCALE)
 
-    d_pages = torch.from_numpy(pages).cuda()
+    d_pages = env.to_dev(pages)
     n, h, w = args.batch, SIDE, SIDE
 
     def step():
@@ -343,7 +395,7 @@ def main():
 
     def barrier():
         torch.distributed.barrier()
-        torch.cuda.synchronize()
+        env.sync()
 
     def timed(fn, steps):
         """barrier + synchronize on both sides, max over ranks"""
@@ -353,18 +405,18 @@ def main():
         for _ in range(steps):
             res = fn()
         barrier()
-        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        tt = env.scalar(time.perf_counter() - t0)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         return float(tt.item()), res
 
     def timed_local(fn, steps):
         """rank-local timing for the rank-0-only legs (no collective: the other ranks sit in the final barrier)"""
-        torch.cuda.synchronize()
+        env.sync()
         t0 = time.perf_counter()
         res = None
         for _ in range(steps):
             res = fn()
-        torch.cuda.synchronize()
+        env.sync()
         return time.perf_counter() - t0, res
 
     out = None
@@ -412,13 +464,15 @@ def main():
         # BASELINE configs[4] as ONE batch over the whole job: 32 x N pages of 1536x1536 (256 at N = 8), scale 3 (capped:
         # detector input 2048x2048), each rank's contiguous block of 32 already in its HBM; dist.ShardedPipeline runs the
         # local chain and the three RCCL all-gathers of the packed results -- all inside the timed region
-        p5s = torch.from_numpy(make_pages(args.batch, 1536, seed=5 + rank, words=80)).cuda()
+        side5 = args.side5
+        p5s_host = make_pages(args.batch, side5, seed=5 + rank, words=80)
+        p5s = env.to_dev(p5s_host)
         sp = k.dist.ShardedPipeline(k.pipeline.Pipeline(detector=det, recognizer=rec, scale=3))
         n_tot = args.batch * world
-        sp.recognize_device(p5s.data_ptr(), n_tot, 1536, 1536)
+        sp.recognize_device(p5s.data_ptr(), n_tot, side5, side5)
         tm = {}
         reps = 2
-        dt5, o5s = timed(lambda: sp.recognize_device(p5s.data_ptr(), n_tot, 1536, 1536, timing=tm), reps)
+        dt5, o5s = timed(lambda: sp.recognize_device(p5s.data_ptr(), n_tot, side5, side5, timing=tm), reps)
         extra["cfg5_sharded"] = {
             "workload": f"BASELINE configs[4]: ONE batch of {n_tot} pages 1536x1536 (scale 3 -> 2048x2048) sharded over {world} "
                         "rank(s) by dist.ShardedPipeline, contiguous blocks resident in each rank's HBM; result all-gathers "
@@ -427,45 +481,74 @@ def main():
             "gather_ms": tm.get("gather_s", 0.0) / reps * 1e3, "pages_returned_on_every_rank": len(o5s),
             "words": sum(len(g) for g in o5s), "gather_payload_bytes_per_rank": tm.get("gather_payload_bytes_per_rank"),
             "backend": torch.distributed.get_backend()}
-        del p5s
+        # the same batch when it STARTS on rank 0 -- the raw uint8 pages are scattered over RCCL (one
+        # torch.distributed.scatter of equal blocks) before the local chains; scatter + chains + gathers inside the timed region
+        if world > 1:
+            full = torch.cat([torch.empty_like(p5s) for _ in range(world)]) if rank == 0 else None
+            if rank == 0:
+                full[:args.batch] = p5s   # the other ranks' pages are rank 0's to invent: only the traffic matters here
+                for r in range(1, world):
+                    full[r * args.batch:(r + 1) * args.batch] = env.to_dev(make_pages(args.batch, side5, seed=5 + r, words=80))
+        else:
+            full = p5s
+        tms = {}
+        sp.recognize_scattered(full, n_tot, side5, side5, src_rank=0)
+        dt5s, o5c = timed(lambda: sp.recognize_scattered(full, n_tot, side5, side5, src_rank=0, timing=tms), reps)
+        extra["cfg5_scattered"] = {
+            "workload": f"the same batch of {n_tot} pages starting in rank 0's HBM: torch.distributed.scatter (RCCL send/recv over "
+                        "xGMI) of the raw uint8 pages before the resize, then the local chains and the result all-gathers",
+            "value": n_tot * reps / dt5s, "unit": "images/s (whole job)", "ms_per_batch": dt5s / reps * 1e3,
+            "scatter_ms": tms.get("scatter_s", 0.0) / reps * 1e3, "gather_ms": tms.get("gather_s", 0.0) / reps * 1e3,
+            "scatter_bytes_sent_by_rank0": tms.get("scatter_bytes_sent"),
+            "same_strings_as_resident_blocks": [[t for t, _ in g] for g in o5c] == [[t for t, _ in g] for g in o5s]}
+        del p5s, full
+    # Every leg that involves a collective is over.  The other ranks leave NOW (one last barrier, then they destroy their
+    # side of the group and return): rank 0's solo legs below -- CRNN / CRAFT only, the configs[4] share, the PMC child
+    # runs, the CPU oracle (tens of seconds) -- must not run while peers sit in a collective waiting for a timeout.
+    fold_process_profile()
+    torch.distributed.barrier()
+    if rank != 0:
+        torch.distributed.destroy_process_group()
+        ctx.close()
+        return None
     crnn_us_per_crop = None
     if rank == 0:
         # secondary BASELINE metric: ms/crop of the CRNN alone (configs[2]: 512 pre-cropped 31x200 strips)
         m = 512
-        crops = torch.rand((m, 31, 200), dtype=torch.float32, device="cuda")
-        labels = torch.empty((m, 48), dtype=torch.int32, device="cuda")
+        crops = env.rand((m, 31, 200))
+        labels = env.empty((m, 48), torch.int32)
         ctx.crnn_forward_device(crops.data_ptr(), m, labels.data_ptr())
-        torch.cuda.synchronize()
+        env.sync()
         t1 = time.perf_counter()
         for _ in range(3):
             ctx.crnn_forward_device(crops.data_ptr(), m, labels.data_ptr())
-        torch.cuda.synchronize()
+        env.sync()
         crnn_us_per_crop = (time.perf_counter() - t1) / 3 / m * 1e6
         del crops, labels
     if rank == 0 and not args.no_extra:
         # configs[1]: CRAFT detector only, batch 8 x 768x768 (no resize), heat-maps stay in HBM
-        x8 = torch.from_numpy(make_pages(8, SIDE, seed=2)).cuda()
-        heat8 = torch.empty((8, SIDE // 2, SIDE // 2, 2), dtype=torch.float32, device="cuda")
+        x8 = env.to_dev(make_pages(8, SIDE, seed=2))
+        heat8 = env.empty((8, SIDE // 2, SIDE // 2, 2), torch.float32)
         ctx.craft_forward_device(x8.data_ptr(), 0, 8, SIDE, SIDE, heat8.data_ptr())
-        torch.cuda.synchronize()
+        env.sync()
         t1 = time.perf_counter()
         for _ in range(5):
             ctx.craft_forward_device(x8.data_ptr(), 0, 8, SIDE, SIDE, heat8.data_ptr())
-        torch.cuda.synchronize()
+        env.sync()
         d2 = (time.perf_counter() - t1) / 5
         extra["cfg2_craft_only"] = {"workload": "BASELINE configs[1]: CRAFT forward only, 8 x 768x768 u8, input and heat-maps in HBM",
                                     "value": 8 / d2, "unit": "images/s", "ms_per_batch": d2 * 1e3,
                                     "algorithmic_tflops": 8 * 419.624e9 / d2 / 1e12}
         del x8, heat8
         # configs[4], one rank's share: 32 x 1536x1536 pages, scale=3 -> capped to 2048x2048 (one micro-batch)
-        p5 = torch.from_numpy(make_pages(32, 1536, seed=5, words=80)).cuda()
+        p5 = env.to_dev(make_pages(32, args.side5, seed=5, words=80))
         pipe3 = k.pipeline.Pipeline(detector=det, recognizer=rec, scale=3)
-        pipe3.recognize_device(p5.data_ptr(), 32, 1536, 1536)
-        torch.cuda.synchronize()
+        pipe3.recognize_device(p5.data_ptr(), 32, args.side5, args.side5)
+        env.sync()
         t1 = time.perf_counter()
         for _ in range(2):
-            o5 = pipe3.recognize_device(p5.data_ptr(), 32, 1536, 1536)
-        torch.cuda.synchronize()
+            o5 = pipe3.recognize_device(p5.data_ptr(), 32, args.side5, args.side5)
+        env.sync()
         d5 = (time.perf_counter() - t1) / 2
         extra["cfg5_share"] = {"workload": "BASELINE configs[4] per-GPU share: 32 pages 1536x1536, scale=3 "
                                            "(internally 2048x2048), full pipeline, single rank",
@@ -562,7 +645,7 @@ def main():
         res.update(extra)
         if alt is not None:
             res["alt_split_mode"] = alt
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and env.cpu_baseline_ok():
             res["cpu_baseline"], oracle_page, oracle_heat = cpu_baseline(craft_w, crnn_w, pages[0])
             oracle_cache = {}
             res["parity"] = parity_pages(ctx, craft_w, crnn_w, pages, out, oracle_page, oracle_heat, oracle_cache)
@@ -581,9 +664,9 @@ def main():
                 "algorithmic_fp32_tflops": pr["flops"] / (pr["ms"] * 1e-3) / 1e12}
         json_out.write(json.dumps(res) + "\n")
         json_out.flush()
-    torch.distributed.barrier()
     torch.distributed.destroy_process_group()
     ctx.close()
+    return res if rank == 0 else None
 
 
 if __name__ == "__main__":

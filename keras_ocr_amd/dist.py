@@ -76,8 +76,28 @@ def packed_payload_bytes(per_rank_images, cap):
 
 
 class ShardError(RuntimeError):
-    """Raised on EVERY rank when the local chain of at least one rank failed (its message names the rank and the
-    original exception); the failing rank chains its own exception as __cause__."""
+    """Raised on EVERY rank when the local chain of at least one rank failed.  The message names the failing rank(s) and
+    the KIND of exception each raised (exchanged as a small code in the status slot of the counts all-gather: the
+    reference's IndexError at detection.py:272 / ZeroDivisionError at tools.py:95, an AssertionError, a libkocr error, or
+    "Exception"), also available as ``failed_ranks`` / ``kinds`` ({rank: name}); the failing rank chains its own
+    exception as ``__cause__``.  A sharded caller therefore sees ShardError where the single-process call raises the
+    reference's own exception type."""
+    failed_ranks = ()
+    kinds = {}
+
+
+_STATUS_NAMES = {1: "Exception", 2: "IndexError", 3: "ZeroDivisionError", 4: "AssertionError", 5: "KocrError", 6: "ValueError",
+                 7: "TypeError"}
+
+
+def _status_of(error):
+    """0 = ok, else a code naming the exception type (anything unlisted travels as 1 = "Exception")."""
+    if error is None:
+        return 0
+    for code, name in _STATUS_NAMES.items():
+        if code != 1 and any(c.__name__ == name for c in type(error).__mro__):
+            return code
+    return 1
 
 
 def gather_packed(box_groups, labels, per_rank_images, group=None, error=None, timing=None):
@@ -115,17 +135,21 @@ def gather_packed(box_groups, labels, per_rank_images, group=None, error=None, t
     c = torch.zeros(per_rank_images + 2, dtype=torch.int32)
     c[:len(counts_local)] = torch.tensor(counts_local, dtype=torch.int32)
     c[-2] = len(counts_local)
-    c[-1] = 0 if error is None else 1
+    c[-1] = _status_of(error)
     c = c.to(dev)
     all_c = torch.empty(world * (per_rank_images + 2), dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(all_c, c, group=group)
     all_c = all_c.cpu().numpy().reshape(world, per_rank_images + 2)
     failed = [r for r in range(world) if all_c[r, -1] != 0]
     if failed:
-        msg = f"sharded recognize failed on rank(s) {failed}"
+        kinds = sorted({_STATUS_NAMES.get(int(all_c[r, -1]), "Exception") for r in failed})
+        msg = f"sharded recognize failed on rank(s) {failed} ({', '.join(kinds)})"
+        exc = ShardError(f"{msg}: {type(error).__name__}: {error}" if error is not None else msg)
+        exc.failed_ranks = failed
+        exc.kinds = {r: _STATUS_NAMES.get(int(all_c[r, -1]), "Exception") for r in failed}
         if error is not None:
-            raise ShardError(f"{msg}: {type(error).__name__}: {error}") from error
-        raise ShardError(msg)
+            raise exc from error
+        raise exc
     cap = max(int(all_c[:, :-2].sum(axis=1).max()), 1)
     # 2. + 3. packed boxes and label rows, capacity = the busiest rank's crop count
     b = torch.zeros((cap, 8), dtype=torch.float32)
@@ -193,12 +217,69 @@ class ShardedPipeline:
         return self._run_shard(lambda: self.pipeline.recognize_device_raw(d_ptr, end - start, h, w, detection_kwargs),
                                end > start, -(-n_total // world), timing)
 
+    def recognize_scattered(self, batch, n_total, h, w, src_rank=0, detection_kwargs=None, timing=None):
+        """the WHOLE (n_total, h, w, 3) uint8 batch starts on ONE rank -- ``batch`` is a torch tensor
+        in ``src_rank``'s HBM (a host tensor under gloo) and is ignored (may be None) on the other ranks.  The raw pages
+        are scattered BEFORE the resize (the smallest form of the data: 1.81 GB for BASELINE configs[4], 7/8 of it leaves
+        rank 0 over its seven xGMI links) with one ``torch.distributed.scatter`` of equal ceil(n/world) blocks (RCCL
+        implements it as grouped send/recv; the last block is zero padded), then every rank runs the local chain on its
+        block and the results are all-gathered as in ``recognize_device``.  ``timing`` receives ``scatter_s`` (the
+        collective plus the wait for it) and ``scatter_bytes_sent`` next to ``gather_s``."""
+        import time
+        import torch
+        import torch.distributed as dist
+
+        rank, world = self._rank_world()
+        per = -(-n_total // world) if n_total else 0
+        start, end = shard_bounds(n_total, world, rank)
+        distributed = dist.is_available() and dist.is_initialized()
+        t0 = time.perf_counter()
+        if not distributed:
+            mine = batch
+            dev = None
+        else:
+            dev = _comm_device(self.group)
+            mine = torch.empty((per, h, w, 3), dtype=torch.uint8, device=dev)
+            chunks = None
+            if rank == src_rank:
+                if batch is None or tuple(batch.shape) != (n_total, h, w, 3) or batch.dtype != torch.uint8:
+                    raise ValueError("recognize_scattered: the source rank needs the (n_total, h, w, 3) uint8 batch")
+                batch = batch.to(dev)
+                chunks = []
+                for r in range(world):
+                    c = batch[r * per:min((r + 1) * per, n_total)]
+                    if c.shape[0] < per:  # equal blocks for the collective: the tail is zero padded (and never processed)
+                        c = torch.cat([c, torch.zeros((per - c.shape[0], h, w, 3), dtype=torch.uint8, device=dev)])
+                    chunks.append(c.contiguous())
+            dist.scatter(mine, scatter_list=chunks, src=src_rank, group=self.group)
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+        if timing is not None:
+            timing["scatter_s"] = timing.get("scatter_s", 0.0) + (time.perf_counter() - t0)
+            timing["scatter_bytes_sent"] = (per * (world - 1) * h * w * 3) if (distributed and rank == src_rank) else 0
+        n_mine = end - start
+
+        def run():
+            if mine.device.type == "cuda":
+                return self.pipeline.recognize_device_raw(mine.data_ptr(), n_mine, h, w, detection_kwargs)
+            # host tensors (gloo): the same call as recognize(); every image has the batch's size
+            _, _, _, hmax, wmax = self.pipeline._plan([(h, w, 3)] * n_total)  # pylint: disable=protected-access
+            return self.pipeline.recognize_raw(mine[:n_mine].numpy(), hmax, wmax, detection_kwargs, None)
+
+        return self._run_shard(run, n_mine > 0, per, timing)
+
     def _run_shard(self, run, has_work, per, timing):
         box_groups, labels, err = [], np.zeros((0, LABEL_WIDTH), np.int32), None
-        if has_work:
-            try:
+        try:
+            if has_work:
                 box_groups, labels = run()
-            except Exception as e:  # noqa: BLE001 -- exchanged as a status flag so that no rank is left in a collective
-                err = e
+                # the packing of gather_packed's preamble, done here so that a malformed local result is exchanged as a
+                # status too instead of raising on one rank before the first collective (ADVICE r03)
+                np.asarray(labels, np.int32).reshape(sum(len(b) for b in box_groups), LABEL_WIDTH)
+                for b in box_groups:
+                    if len(b):
+                        np.asarray(b, np.float32).reshape(-1, 8)
+        except Exception as e:  # noqa: BLE001 -- exchanged as a status flag so that no rank is left in a collective
+            box_groups, labels, err = [], np.zeros((0, LABEL_WIDTH), np.int32), e
         box_groups, labels = gather_packed(box_groups, labels, per, self.group, error=err, timing=timing)
         return self.pipeline.assemble(box_groups, labels)

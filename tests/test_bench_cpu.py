@@ -92,3 +92,154 @@ def test_pmc_counter_parsing_and_corrections(tmp_path):
     assert k.perfmodel.issued_per_algorithmic("conv_hs_256x32")["factor"] == 6.0
     assert abs(k.perfmodel.issued_per_algorithmic("conv_hs_256x16")["factor"] - 60.0 / 9.0) < 1e-12
     assert abs(k.perfmodel.issued_per_algorithmic("conv_k5_352x16:stn_conv_1")["factor"] - 6.24) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.main() executed at WORLD SIZE 2 without a GPU: torch.distributed over gloo, libkocr replaced
+# at the ctypes seam by a double (the real Pipeline / Detector / Recognizer / ShardedPipeline classes run), device
+# plumbing replaced by bench.GpuEnv's host double.  Checks what a first 8-GPU run would otherwise be the first to
+# execute: ONE JSON line from rank 0 only, whole-job accounting (n_gpus, global batch, the sharded batch carries
+# world x batch pages on every rank, rank 0 alone sends in the scatter leg), and that no rank sits in a collective while
+# rank 0 runs its solo legs (the other rank returns BEFORE rank 0 finishes them).
+# ---------------------------------------------------------------------------------------------------------------------
+class _BenchMockContext:
+    def __init__(self):
+        self.mode = 1
+        self.prof = False
+
+    def set_split_mode(self, m):
+        self.mode = m
+
+    def get_split_mode(self):
+        return self.mode
+
+    def profile_reset(self):
+        pass
+
+    def profile_enable(self, on=True):
+        self.prof = bool(on)
+
+    def profile_report(self):
+        return {"conv_w4hv_256x128": {"launches": 6, "ms": 12.0, "flops": 6.0e12, "bytes": 3.0e9},
+                "maxpool2x2": {"launches": 2, "ms": 0.5, "flops": 0.0, "bytes": 1.0e9}}
+
+    def load_craft(self, state):
+        assert "conv_cls.8.weight" in state
+
+    def load_crnn(self, state):
+        assert "fc_12/bias" in state
+
+    def resize_pad(self, images, dsize, out_hw=None, cval=255):
+        return np.zeros((len(images), 8, 8, 3), np.uint8)
+
+    def craft_forward(self, images, micro_batch=0):
+        return np.random.default_rng(0).standard_normal((len(images), 16, 16, 2)).astype(np.float32)
+
+    def get_boxes(self, heat, **kw):
+        return [np.zeros((2, 4, 2), np.float32) for _ in range(len(heat))]
+
+    def pipeline(self, images, hs, ws, dhs, dws, hmax, wmax, micro_batch=0, on_device=False, **kw):
+        groups, rows = [], []
+        for i, (h, dh, dw) in enumerate(zip(hs, dhs, dws)):
+            n = 1 + i % 2
+            groups.append(np.tile(np.array([[0, 0], [dw, 0], [dw, dh], [0, dh]], np.float32), (n, 1, 1)))
+            for j in range(n):
+                row = np.full(48, -1, np.int32)
+                row[:2] = [int(h) % 36, j]
+                rows.append(row)
+        return groups, np.array(rows, np.int32)
+
+    def crnn_forward_device(self, d_crops, m, d_labels, d_probs=None):
+        import time as _t
+
+        _t.sleep(0.5)   # rank 0's solo legs take a while: the other rank must be gone by then
+
+    def craft_forward_device(self, *a, **kw):
+        pass
+
+    def close(self):
+        pass
+
+
+class _HostEnv:
+    backend = "gloo"
+
+    def check(self, local_rank):
+        pass
+
+    def device_count(self):
+        return 2
+
+    def context(self, k, local_rank):
+        return _BenchMockContext()
+
+    def sync(self):
+        pass
+
+    def to_dev(self, arr):
+        import torch
+
+        return torch.from_numpy(np.ascontiguousarray(arr))
+
+    def empty(self, shape, dtype):
+        import torch
+
+        return torch.empty(shape, dtype=dtype)
+
+    def rand(self, shape):
+        import torch
+
+        return torch.rand(shape)
+
+    def scalar(self, v):
+        import torch
+
+        return torch.tensor([v], dtype=torch.float64)
+
+    def cpu_baseline_ok(self):
+        return False
+
+
+def _bench_worker(rank, world, port, q):
+    import time as _t
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import bench
+
+    res = bench.main(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch", "4", "--side5", "64", "--no-live-traffic"],
+                     env=_HostEnv())
+    q.put((rank, _t.time(), res))
+
+
+def test_bench_main_runs_at_world_2_over_gloo_with_a_mocked_library(capfd):
+    import socket
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, t0, res), (_, t1, none) = got
+    assert none is None and isinstance(res, dict)                      # one result, from rank 0
+    assert t1 < t0 - 1.0                                               # rank 1 left before rank 0's solo legs were over
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["steps"] == 2 and res["warmup"] == 1
+    assert res["config"]["global_batch"] == 8 and res["scaling"] == "weak" and res["higher_is_better"] is True
+    assert abs(res["value"] - 8 * 2 / (res["ms_per_step"] * 2 / 1e3)) < 1e-6 * res["value"]   # whole job: world x batch x K / time
+    sh, sc = res["cfg5_sharded"], res["cfg5_scattered"]
+    assert sh["pages_returned_on_every_rank"] == 8 and sh["backend"] == "gloo" and sh["gather_ms"] > 0
+    assert sc["scatter_bytes_sent_by_rank0"] == 4 * 64 * 64 * 3 and sc["scatter_ms"] > 0 and sc["same_strings_as_resident_blocks"]
+    assert res["roofline"]["kernel"] == "conv_w4hv_256x128" and res["roofline"]["peak"] == 2500.0
+    assert abs(res["roofline"]["issued_tflops"] - 1.5 * res["roofline"]["achieved"]) < 1e-9
+    assert "cpu_baseline" not in res and res["crnn_only"]["value"] > 0
+    out = capfd.readouterr().out
+    assert sum(ln.startswith('{"metric"') for ln in out.splitlines()) == 1   # exactly one JSON line on stdout

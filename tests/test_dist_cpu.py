@@ -224,6 +224,7 @@ def test_failure_on_one_rank_raises_on_every_rank_gloo_world2():
         assert p.exitcode == 0
     errs = {r: (m, c) for r, m, c in res if m != "after"}
     assert "rank(s) [1]" in errs[0][0] and errs[0][1] is None            # rank 0 learns of it through the status slot
+    assert "IndexError" in errs[0][0]                                    # ... including WHAT was raised (status code)
     assert "rank(s) [1]" in errs[1][0] and "IndexError" in errs[1][0] and errs[1][1] == "IndexError"
     assert [(r, n) for r, m, n in res if m == "after"] == [(0, 3), (1, 3)]
 
@@ -254,3 +255,55 @@ def test_stagewise_path_pads_to_the_imposed_size(monkeypatch):
     assert seen["shape"] == (1, 64, 80, 3)
     pipe.recognize_raw([np.zeros((10, 12, 3), np.uint8)])
     assert seen["shape"] == (1, 20, 24, 3)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the batch starts on ONE rank and is scattered before the local chains (recognize_scattered)
+# ---------------------------------------------------------------------------------------------------
+def _worker_scatter(rank, world, port, n_images, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    import keras_ocr_amd
+
+    keras_ocr_amd.dist.init_from_env(backend="gloo")
+    h, w = 13, 24
+    batch = None
+    if rank == 1:   # the source is NOT rank 0: nothing may depend on that
+        arr = np.zeros((n_images, h, w, 3), np.uint8)
+        for i in range(n_images):
+            arr[i] = i + 1
+        batch = torch.from_numpy(arr)
+    timing = {}
+    seen = []
+
+    class Spy(_FakePipeline):
+        def recognize_raw(self, images, hmax, wmax, detection_kwargs=None, recognition_kwargs=None):
+            seen.extend(int(im[0, 0, 0]) for im in images)   # which pages reached this rank (their fill value)
+            return super().recognize_raw(images, hmax, wmax, detection_kwargs, recognition_kwargs)
+
+    out = keras_ocr_amd.dist.ShardedPipeline(Spy()).recognize_scattered(batch, n_images, h, w, src_rank=1, timing=timing)
+    q.put((rank, seen, len(out), timing.get("scatter_bytes_sent"), timing.get("scatter_s", 0) > 0, "gather_s" in timing))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_images", [5, 4, 1])
+def test_scatter_from_one_rank_gloo_world2(n_images):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_scatter, args=(r, 2, port, n_images, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    per = -(-n_images // 2)
+    assert res[0][1] == list(range(1, min(per, n_images) + 1))                 # rank 0 got pages 1..per from rank 1
+    assert res[1][1] == list(range(per + 1, n_images + 1))                     # rank 1 kept the tail (zero padding unused)
+    assert res[0][2] == n_images and res[1][2] == n_images                     # everybody ends with the whole result
+    assert res[0][3] == 0 and res[1][3] == per * 13 * 24 * 3                   # only the source sends: one block per peer
+    assert all(r[4] and r[5] for r in res)

@@ -85,3 +85,20 @@ def test_gather_packed_on_hbm_tensors_empty_rank(nccl_group):
 
     boxes, labels = kd.gather_packed([np.array([]), np.array([])], np.zeros((0, 48), np.int32), 2)
     assert len(boxes) == 2 and all(len(b) == 0 for b in boxes) and labels.shape == (0, 48)
+
+
+def test_scattered_batch_over_rccl(nccl_group, pipe):
+    """the batch starts in ONE rank's HBM and goes through torch.distributed.scatter (RCCL) before the local
+    chains; at world 1 the collective degenerates to a device copy but runs through the same code path."""
+    import torch
+    import keras_ocr_amd
+
+    pages = np.stack([synth.text_page(96, 128, 5, seed=s) for s in (41, 42, 43)])
+    want = pipe.recognize(pages)
+    timing = {}
+    got = keras_ocr_amd.dist.ShardedPipeline(pipe).recognize_scattered(torch.from_numpy(pages).cuda(), 3, 96, 128, src_rank=0,
+                                                                       timing=timing)
+    _same(got, want)
+    assert timing["scatter_s"] > 0 and timing["scatter_bytes_sent"] == 0 and timing["gather_s"] > 0
+    with pytest.raises(ValueError, match="source rank needs"):
+        keras_ocr_amd.dist.ShardedPipeline(pipe).recognize_scattered(None, 3, 96, 128, src_rank=0)

@@ -128,6 +128,18 @@ int kocr_create(kocr_ctx** out, int hip_device) {
     c->split_mode = (!strcmp(e, "f16") || !strcmp(e, "fp16") || !strcmp(e, "f16x2")) ? KOCR_SPLIT_F16X2
                     : (!strcmp(e, "f16x1") || !strcmp(e, "fast"))                     ? KOCR_SPLIT_F16X1
                                                                                       : KOCR_SPLIT_BF16X3;
+  {
+    auto on = [](const char* name, bool dflt) {
+      const char* e = getenv(name);
+      return e ? atoi(e) != 0 : dflt;
+    };
+    c->sw.dense_splitk = on("KOCR_DENSE_SPLITK", true);
+    c->sw.lstm16 = on("KOCR_LSTM16", true);
+    c->sw.hs16 = on("KOCR_HS16", true);
+    c->sw.k5 = on("KOCR_K5", true);
+    c->sw.up2x = on("KOCR_UP2X", true);
+    c->sw.w43h = on("KOCR_W43H", true);
+  }
   if (const char* e = getenv("KOCR_LINFOLD")) c->opt_linfold = atoi(e) != 0;
   if (const char* e = getenv("KOCR_UPFOLD")) c->opt_upfold = atoi(e) != 0;
   c->device = hip_device;

@@ -120,6 +120,17 @@ struct kocr_ctx {
   // CRAFT schedule options (craft.cpp: folded linear layers); read ONCE from KOCR_LINFOLD / KOCR_UPFOLD when the
   // context is created, changed through kocr_set_schedule
   bool opt_linfold = true, opt_upfold = true;
+  // kernel selection switches, read ONCE per context in kocr_create from the environment variable of the same name in
+  // upper case with the KOCR_ prefix (KOCR_LSTM16=0 ...): the fallback kernels can be exercised per context, inside
+  // one process (the older switches of the convolution dispatch are still process-wide)
+  struct Switches {
+    bool dense_splitk = true;  // stn_dense_1 on the split-K kernel
+    bool lstm16 = true;        // round-3 LSTM kernel (16 crops per workgroup, U resident in registers)
+    bool hs16 = true;          // <= 16-cout 3x3 layers on the 16x16x32 MFMA
+    bool k5 = true;            // 5x5 / 16-cout kernel (stn_conv_1)
+    bool up2x = true;          // shared-tap epilogue for exact 2x up-sampling in the decoder 1x1s
+    bool w43h = true;          // fp16 F(4,3) kernels in the fp16 arithmetic modes
+  } sw;
 
   // max-|x| slots of the tensors of the current forward (see Tensor::amax): zeroed by amax_begin()
   unsigned* d_amax = nullptr;

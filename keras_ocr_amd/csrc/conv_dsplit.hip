@@ -577,7 +577,7 @@ int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   ProfScope ps(ctx, nm, flops, bytes);
   if (up) {
     // exactly 2x up-sampling with W % 4 == 0: the shared-tap epilogue (UP = 2)
-    static const bool no_up2 = getenv("KOCR_UP2X") && atoi(getenv("KOCR_UP2X")) == 0;
+    const bool no_up2 = !ctx->sw.up2x;
     if (!no_up2 && in.H == 2 * up->H && in.W == 2 * up->W && in.W % 4 == 0)
       return wcls == 128 ? ds_launch<1, 4, 0, 2>(ctx, p, M) : ds_launch<2, 2, 0, 2>(ctx, p, M);
     return wcls == 128 ? ds_launch<1, 4, 0, 1>(ctx, p, M) : ds_launch<2, 2, 0, 1>(ctx, p, M);

@@ -589,7 +589,7 @@ int launch_conv_hsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   p.amax_out = out.amax;
   const size_t M = in.pixels();
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
-  static const bool no16 = getenv("KOCR_HS16") && atoi(getenv("KOCR_HS16")) == 0;
+  const bool no16 = !ctx->sw.hs16;
   const bool use16 = L.d_hs16 && !no16;  // <= 16 couts: the 16-wide product tile
   char nm[64];
   if (per_layer)

@@ -197,7 +197,7 @@ int prepare_k5(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
 }
 
 bool k5_applicable(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out) {
-  static const bool off = getenv("KOCR_K5") && atoi(getenv("KOCR_K5")) == 0;
+  const bool off = !ctx->sw.k5;
   return !off && L.d_k5 && in.cs % 4 == 0 && in.co % 4 == 0 &&
          ((uintptr_t)in.p & 15) == 0 && out.cs % 4 == 0 && out.co % 4 == 0 && ((uintptr_t)out.p & 15) == 0 &&
          in.H * in.W <= K5_MAXM && (in.H + 4) * (in.W + 4) <= K5_MAXHP;

@@ -1802,8 +1802,9 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   const bool rowreuse = rgeo >= 0;
   // Cout > 64 on the same image geometry: the vertical-reuse arrangement (conv_w43v_kernel)
   static const bool no_v = getenv("KOCR_W43V") && atoi(getenv("KOCR_W43V")) == 0;
-  // geometry: 4 rows x 64 columns (H % 4 == 0, W % 64 == 0) or 2 rows x 128 columns (H even, W % 128 == 0); KOCR_W43V_GEO
-  // forces one of them where both apply (developer switch)
+  // geometries of conv_w43v_kernel: GEO 1 = 4 rows x 64 columns (H % 4 == 0, W % 64 == 0), GEO 2 = 8 rows x 32 columns
+  // (H % 8 == 0, W % 32 == 0, no fused pooling).  KOCR_W43V_GEO=2 forces GEO 2 where both apply (developer switch; the
+  // same variable = 0 / 1 picks the row-reuse kernel's 2 x 128 / 4 x 64 geometry above where both apply)
   const bool v_ok = !narrow && !no_v && L.dil == 1 && (!pool || fuse) && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31);
   // 4 rows x 64 columns where the image tiles that way, else 8 rows x 32 columns (the 96-wide layers); anything else (e.g.
   // H % 4 != 0) stays on conv_w43_kernel
@@ -1828,7 +1829,7 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   }
   // fp16 arithmetic (conv_w43h.hip) where an fp16 kernel exists for the arrangement; else the exact bf16x3 kernels
   const int pieces = ctx->split_mode == KOCR_SPLIT_F16X2 ? 2 : ctx->split_mode == KOCR_SPLIT_F16X1 ? 1 : 0;
-  static const bool no_h = getenv("KOCR_W43H") && atoi(getenv("KOCR_W43H")) == 0;
+  const bool no_h = !ctx->sw.w43h;
   const bool use_h = pieces && !no_h && L.d_w4h && vreuse;
   if (use_h) {
     const unsigned* slots = in.amax;

@@ -256,7 +256,7 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
   {
     // Dense(64) over 11 200 features: split-K (crnn_kernels.hip); the weight rows must be in plain k order
     const ConvLayer& Ld = net->L["stn_dense_1"];
-    static const bool no_sk = getenv("KOCR_DENSE_SPLITK") && atoi(getenv("KOCR_DENSE_SPLITK")) == 0;
+    const bool no_sk = !ctx->sw.dense_splitk;
     float* part = no_sk ? nullptr : (float*)ctx->ws_alloc(dense_splitk_workspace(M, 11200));
     if (part && Ld.Cout == 64 && Ld.Cin == 11200)
       KOCR_TRY(launch_dense_splitk(ctx, Ld, s2.p, d1.p, part, M));

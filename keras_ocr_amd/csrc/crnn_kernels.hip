@@ -340,7 +340,7 @@ int launch_dense_splitk(kocr_ctx* ctx, const ConvLayer& L, const float* d_in, fl
 int launch_lstm(kocr_ctx* ctx, const float* d_xp, const float* d_Uf, const float* d_Ub, float* d_out, int M, int T) {
   if (M <= 0) return KOCR_OK;
   ProfScope ps(ctx, "lstm_recurrence", 2.0 * 2 * M * (double)T * 128 * 512, 0);
-  static const bool old = getenv("KOCR_LSTM16") && atoi(getenv("KOCR_LSTM16")) == 0;
+  const bool old = !ctx->sw.lstm16;
   if (old)
     hipLaunchKernelGGL(lstm_kernel<128>, dim3((M + 31) / 32, 2), dim3(256), 0, ctx->stream, d_xp, d_Uf, d_Ub, d_out, M, T);
   else

@@ -13,10 +13,13 @@ def decode_labels(alphabet, labels):
     if labels.size == 0:
         return [""] * len(labels)
     n = len(alphabet)
-    if any(len(c) != 1 or c == "\0" for c in alphabet) or labels.min() < -1 or labels.max() > n:
-        # multi-character entries, or indices the reference's own expression would wrap / reject: evaluate that expression
+    if (labels.ndim != 2 or any(len(c) != 1 or c == "\0" or 0xD800 <= ord(c) <= 0xDFFF for c in alphabet)
+            or labels.min() < -1 or labels.max() > n):
+        # multi-character entries, lone surrogates (no UTF-32 encoding), a single row, or indices the reference's own
+        # expression would wrap / reject: evaluate that expression
         skip = (n, -1)
-        return ["".join([alphabet[i] for i in row if i not in skip]) for row in labels.tolist()]
+        rows = labels.tolist() if labels.ndim == 2 else [labels.tolist()] if labels.ndim == 1 else labels.reshape(-1, labels.shape[-1]).tolist()
+        return ["".join([alphabet[i] for i in row if i not in skip]) for row in rows]
     table = np.array([ord(c) for c in alphabet] + [0], "<u4")
     text = table[np.where(labels < 0, n, labels)].tobytes().decode("utf-32-le")
     w = labels.shape[1]

@@ -99,7 +99,8 @@ def test_decode_labels_matches_the_per_character_loop():
     from keras_ocr_amd.pipeline import decode_labels
 
     rng = np.random.default_rng(5)
-    for alphabet in ("0123456789abcdefghijklmnopqrstuvwxyz", "aé漢字\U0001f600z", ["ab", "c", "d"]):
+    for alphabet in ("0123456789abcdefghijklmnopqrstuvwxyz", "aé漢字\U0001f600z", ["ab", "c", "d"],
+                     ["a", "\ud83d", "b"]):  # a lone surrogate has no UTF-32 encoding: the per-character path must take it
         n = len(alphabet)
         labels = np.full((40, 48), -1, np.int32)
         for r in range(40):
@@ -109,5 +110,6 @@ def test_decode_labels_matches_the_per_character_loop():
         assert decode_labels(alphabet, labels) == want
         assert decode_labels(alphabet, labels.tolist()) == want
     assert decode_labels("abc", np.zeros((0, 48), np.int32)) == []
+    assert decode_labels("abc", np.array([0, 2, 3, -1, 1])) == ["acb"]          # a single row (1-D) is one string
     with pytest.raises(IndexError):
         decode_labels("abc", np.array([[0, 7]]))

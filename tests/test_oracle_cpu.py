@@ -142,3 +142,52 @@ def test_warp_association_orders_differ_in_few_pixels():
     assert n_px > 100000
     assert n_diff <= 2e-3 * n_px      # measured: a few 1e-5
     assert worst <= 2
+
+
+def test_ties_the_reference_leaves_to_opencv_are_pinned_in_the_oracle():
+    """VERDICT r03 item 6c.  Two places of detection.getBoxes (detection.py:273-285) are decided by float noise inside
+    OpenCV when the geometry is exactly symmetric; the oracle (and, bit for bit, the device code: tests/test_postproc_gpu.py)
+    makes a DETERMINISTIC choice there.  OpenCV's own choice is unobserved (cv2 is absent from this image): these
+    assertions document which answer the restatement gives, so that a real-library run can be compared one day.
+
+    1. np.roll(box, 4 - argmin(x + y)): a 45-degree rectangle has TWO corners with the same x + y (its top and its left
+       corner when the long side runs down-right).  numpy's argmin takes the FIRST minimum in boxPoints order; the oracle
+       lists the corners clockwise from (umin, vmin) of the chosen hull edge, so the tie goes to whichever of the two that
+       order meets first.
+    2. minAreaRect: an exactly equal-area tie between two hull edges (a square rotated by 45 degrees inside its axis-aligned
+       twin cannot happen on a hull, but a symmetric hexagon gives two edges with the same enclosing rectangle area) goes to
+       the FIRST hull edge in clockwise order from the top-most / left-most vertex."""
+    from oracle import postproc
+
+    # 1. a 45-degree 2*sqrt2 x sqrt2 rectangle: corners (1,0) (3,2) (2,3) (0,1); x + y = 1 for (1,0) AND (0,1)
+    hull = postproc.convex_hull_rows(np.array([[1, 0], [3, 2], [2, 3], [0, 1]]))
+    box = postproc.min_area_box(hull)
+    sums = box.sum(axis=1)
+    assert sorted(sums.tolist()) == [1.0, 1.0, 5.0, 5.0]                       # the tie exists in exact arithmetic
+    first = int(sums.argmin())
+    rolled = np.roll(box, 4 - first, 0)
+    assert tuple(rolled[0]) == (1.0, 0.0), rolled                               # the oracle's answer: the TOP corner starts the box
+    x, y = rolled[:, 0], rolled[:, 1]
+    assert (x * np.roll(y, -1) - np.roll(x, -1) * y).sum() > 0                  # and the order stays clockwise on screen
+    # 2. a hexagon symmetric under the swap of its two slanted edge directions: edges (0,0)->(2,0) ... give rectangles of
+    #    equal area for the edge pair (4,1)->(3,3) / (3,3)->... mirrored; the first in hull order wins
+    pts = np.array([[1, 0], [3, 0], [4, 2], [3, 4], [1, 4], [0, 2]])
+    hull = postproc.convex_hull_rows(pts)
+    assert hull[0] == (1, 0)                                                    # top-most, then left-most vertex first
+    areas = []
+    for i in range(len(hull)):
+        (x0, y0), (x1, y1) = hull[i], hull[(i + 1) % len(hull)]
+        dx, dy = x1 - x0, y1 - y0
+        us = [px * dx + py * dy for px, py in hull]
+        vs = [-px * dy + py * dx for px, py in hull]
+        areas.append(((max(us) - min(us)) * (max(vs) - min(vs)), dx * dx + dy * dy))
+    best = min(a / l for a, l in areas)
+    winners = [i for i, (a, l) in enumerate(areas) if a * 1.0 / l == best]
+    assert len(winners) >= 2                                                    # a genuine exact tie
+    box = postproc.min_area_box(hull)
+    i = winners[0]                                                              # the oracle takes the first edge of the tie
+    (x0, y0), (x1, y1) = hull[i], hull[(i + 1) % len(hull)]
+    dx, dy = x1 - x0, y1 - y0
+    # the box has a side parallel to that edge
+    side = box[1] - box[0]
+    assert abs(float(side[0]) * dy - float(side[1]) * dx) < 1e-5

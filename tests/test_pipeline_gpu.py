@@ -307,8 +307,8 @@ def test_duck_typed_stages_take_the_reference_stagewise_path(pipe):
     assert [[t for t, _ in g] for g in staged] == [[t for t, _ in g] for g in fused]
     for ga, gb in zip(staged, fused):
         assert all(np.array_equal(a[1], b[1]) for a, b in zip(ga, gb))
-    with pytest.raises(TypeError):
-        pipe.recognize([pages[0].astype(np.float32)])
+    # (a float image used to be refused here; since round 4 it takes the float stage-wise path:
+    #  test_float_images_take_the_float_path)
 
 
 def test_float_images_take_the_float_path(pipe, ctx):

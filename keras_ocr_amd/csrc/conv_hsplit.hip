@@ -356,6 +356,7 @@ struct FirstParams {
   const float* post_b;
   int H, W, Cout, out_cs, out_co, relu;
   int tiles_x, tiles_y;
+  unsigned* amax_out;  // per-image max-|x| slots of the output (Tensor::amax) or nullptr
 };
 
 namespace {
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(256, 4) void conv_first_kernel(FirstParams p) {
                                  (unsigned)__builtin_amdgcn_readfirstlane((int)ob);
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)obu, 0, 0x80000000, 0x00020000);
   const bool has_post = p.post_a != nullptr;
+  float mxv = 0.f;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int co = nt * 32 + l31;
@@ -512,9 +514,11 @@ __global__ __launch_bounds__(256, 4) void conv_first_kernel(FirstParams p) {
         const bool ok = y < p.H && x < p.W && co < p.Cout;
         const unsigned vo = ok ? (unsigned)(((y * p.W + x) * p.out_cs + co) * 4) : OOB;
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), ro, vo, 0, 0);
+        mxv = fmaxf(mxv, ok ? fabsf(o) : 0.f);
       }
     }
   }
+  if (p.amax_out) kocr_amax_update(p.amax_out + n, mxv);  // per-image slot (Tensor::amax): the tile lies inside image n
 }
 
 // ---------------------------------------------------------------------------------------
@@ -655,6 +659,7 @@ int launch_conv_first(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const
   p.relu = L.relu;
   p.tiles_x = (in.W + HS_TW - 1) / HS_TW;
   p.tiles_y = (in.H + HS_TH - 1) / HS_TH;
+  p.amax_out = out.amax;
   const size_t M = in.pixels();
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
   const double bytes = (double)M * 3 + 4.0 * ((double)M * L.Cout + (double)L.Kreal * L.Cout);
@@ -663,5 +668,5 @@ int launch_conv_first(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const
   if (grid > 0x7fffffff) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": too many tiles");
   hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
-  return KOCR_OK;  // (no max-|x| tracking in this kernel: launch_conv_pool reduces the output when it carries slots)
+  return KOCR_OK;
 }

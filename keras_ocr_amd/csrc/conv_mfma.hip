@@ -638,8 +638,7 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
                          conv_variant() != 10;
   if (!out.p) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": no output buffer");
   if (in_u8 && lut && conv_variant() == 0 && first_applicable(ctx, L, in)) {  // first layer from raw uint8 on the split path
-    KOCR_TRY(launch_conv_first(ctx, L, in, in_u8, lut, out));
-    if (out.amax) KOCR_TRY(launch_absmax(ctx, out, out.amax));
+    KOCR_TRY(launch_conv_first(ctx, L, in, in_u8, lut, out));  // maintains out.amax itself
     return pool ? launch_maxpool2x2(ctx, out, *pool) : KOCR_OK;
   }
   if (!in_u8 && !pool && variant == 0 && conv_variant() == 0 && k5_applicable(ctx, L, in, out))  // 5x5, 16 couts, small images

@@ -1830,7 +1830,7 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   // fp16 arithmetic (conv_w43h.hip) where an fp16 kernel exists for the arrangement; else the exact bf16x3 kernels
   const int pieces = ctx->split_mode == KOCR_SPLIT_F16X2 ? 2 : ctx->split_mode == KOCR_SPLIT_F16X1 ? 1 : 0;
   const bool no_h = !ctx->sw.w43h;
-  const bool use_h = pieces && !no_h && L.d_w4h && vreuse;
+  const bool use_h = pieces && !no_h && L.d_w4h && (vreuse || (rowreuse && rgeo == 1));
   if (use_h) {
     const unsigned* slots = in.amax;
     if (!slots) {  // the producer did not track: reduce the input once, per image
@@ -1852,9 +1852,9 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s:%s", use_h ? (pieces == 2 ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s:%s", use_h ? (pieces == 2 ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : (use_h ? "r" : "s"), rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s", use_h ? (pieces == 2 ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : "s", rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
+    snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s", use_h ? (pieces == 2 ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : (use_h ? "r" : "s"), rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   {
@@ -1882,8 +1882,10 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
       }
     }
 #endif
-    if (use_h) {
+    if (use_h && vreuse) {
       KOCR_TRY(launch_w43vh(ctx, p, fuse, vgeo, pieces));
+    } else if (use_h) {
+      KOCR_TRY(launch_w43rh(ctx, p, fuse, pieces));
     } else if (vreuse) {
       if (vgeo == 2) {
         KOCR_TRY((w4v_launch<0, 2>(ctx, p)));

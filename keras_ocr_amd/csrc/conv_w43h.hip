@@ -228,11 +228,15 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
   v2f raw1[6];
 
   // ---- consumer state ------------------------------------------------------------------------------------------
-  // weights: [16-ch group][ky][32-cout tile][xi][2 pieces][lane][8] fp16 (NP = 1 reads piece 0 only)
+  // weights: [16-ch group][ky][32-cout tile][xi][2 pieces][lane][8] fp16 (NP = 1 reads piece 0 only), fetched with raw
+  // buffer loads (lane offset in one VGPR, everything else scalar) TWO (channel group, ky) steps ahead into a ring of two
+  // register sets: one step is only 36 MFMAs (about 0.6 us) long in this arithmetic, less than an L2 round trip under load
   const int ntiles32 = p.Cout_pad >> 5;
-  const size_t w_step = (size_t)ntiles32 * 12 * 64 * 8;  // ushorts per (channel group, ky) step
-  auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * 4 + wn) * 12 * 64 + lane) * 8; };
-  hf8 bw[6][NP];
+  const unsigned w_step = (unsigned)ntiles32 * 12 * 64 * 16;  // bytes per (channel group, ky) step
+  const __amdgpu_buffer_rsrc_t wrsrc = w4_rsrc(reinterpret_cast<const float*>(p.wgt), 0x7FFFFFFFu);
+  const unsigned wlane = (unsigned)lane * 16u;
+  auto w_tile = [&](int nt) { return (unsigned)__builtin_amdgcn_readfirstlane((nt * 4 + wn) * 12 * 64 * 16); };
+  hf8 bw[2][6][NP];
   f16v acc[6][2];
   const int a_lane = GEO == 2 ? slot(l31 >> 3, l5, l31 & 7) : slot(l31 >> 4, l5, l31 & 15);
   const int a_lane1 = GEO == 2 ? slot((l31 >> 3) + 1, l5, l31 & 7) : 0;
@@ -253,35 +257,37 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
         a[m][s] = *reinterpret_cast<const hf8*>(plane + s * PLANE_R + off);
       }
   };
-  auto mfma_pt = [&](const hf8 (&a)[2][NP], int xi) __attribute__((always_inline)) {
+  auto mfma_pt = [&](const hf8 (&a)[2][NP], const hf8 (&b)[NP], int xi) __attribute__((always_inline)) {
     if constexpr (DBG & 4) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int s = 0; s < NP; ++s) acc[xi][m][s] += __builtin_bit_cast(v4f, a[m][s])[0] + __builtin_bit_cast(v4f, bw[xi][s])[0];
+        for (int s = 0; s < NP; ++s) acc[xi][m][s] += __builtin_bit_cast(v4f, a[m][s])[0] + __builtin_bit_cast(v4f, b[s])[0];
       return;
     }
     // smallest terms first; the two M-tiles alternate so consecutive MFMAs are independent
     if constexpr (NP == 2) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][1], bw[xi][0], acc[xi][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][1], b[0], acc[xi][m], 0, 0, 0);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], bw[xi][1], acc[xi][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], b[1], acc[xi][m], 0, 0, 0);
     }
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], bw[xi][0], acc[xi][m], 0, 0, 0);
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], b[0], acc[xi][m], 0, 0, 0);
   };
   // One (channel group, ky) step: consume rows ky .. (+ M-tile offset) of `bufc` (6 points x 2 PR MFMAs); KY = 0 / 1 also
-  // transforms item 0 / 1 of the NEXT channel group into `bufn`, one point per MFMA group.  The weights of the next step
-  // (w_next) replace this step's point by point.  a0 holds point 0 of this step on entry and point 0 of the next step on
+  // transforms item 0 / 1 of the NEXT channel group into `bufn`, one point per MFMA group.  The step uses ring slot SLOT of
+  // the weights; the weights of the step after next (byte offset w_next) replace them point by point.  a0 holds point 0 of this step on entry and point 0 of the next step on
   // exit; for KY = 2 the next step lives in `bufn`, published by the block barrier before the last point's MFMAs.
   hf8 a0[2][NP], a1[2][NP];
-  auto step = [&](auto ky_c, const unsigned short* bufc, unsigned short* bufn, const unsigned short* w_next, float sk) __attribute__((always_inline)) {
+  auto step = [&](auto ky_c, auto slot_c, const unsigned short* bufc, unsigned short* bufn, unsigned w_next, float sk) __attribute__((always_inline)) {
     constexpr int KY = decltype(ky_c)::value;
+    constexpr int SLOT = decltype(slot_c)::value;
     auto load_b = [&](int xi) __attribute__((always_inline)) {
       if constexpr (DBG & 2) return;
 #pragma unroll
-      for (int s = 0; s < NP; ++s) bw[xi][s] = *reinterpret_cast<const hf8*>(w_next + (size_t)(xi * 2 + s) * 64 * 8);
+      for (int s = 0; s < NP; ++s)
+        bw[SLOT][xi][s] = __builtin_bit_cast(hf8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (int)(w_next + (unsigned)(xi * 2 + s) * 1024u), 0));
     };
     auto produce = [&](int xi) __attribute__((always_inline)) {
       if constexpr (KY == 0) produce4(raw0, bufn, xi, 0, sk);
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
       __builtin_amdgcn_sched_barrier(0);
       load_a(a1, bufc, KY, 2 * q + 1);
       produce(2 * q);
-      mfma_pt(a0, 2 * q);
+      mfma_pt(a0, bw[SLOT][2 * q], 2 * q);
       interleave();
       __builtin_amdgcn_sched_barrier(0);
       load_b(2 * q);
@@ -315,18 +321,18 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
       if (q < 2) {
         load_a(a0, bufc, KY, 2 * q + 2);
         produce(2 * q + 1);
-        mfma_pt(a1, 2 * q + 1);
+        mfma_pt(a1, bw[SLOT][2 * q + 1], 2 * q + 1);
         interleave();
       } else if constexpr (KY < 2) {
         load_a(a0, bufc, KY + 1, 0);
         produce(5);
-        mfma_pt(a1, 5);
+        mfma_pt(a1, bw[SLOT][5], 5);
         interleave();
       } else {
         if constexpr (!(DBG & 32)) __syncthreads();  // the next channel group is complete in bufn, bufc is free
         load_a(a0, bufn, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_pt(a1, 5);
+        mfma_pt(a1, bw[SLOT][5], 5);
       }
       __builtin_amdgcn_sched_barrier(0);
       load_b(2 * q + 1);
@@ -342,11 +348,14 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
   {
     int mp0, nt0;
     w4_decode(p, kocr_xcd_remap(blockIdx.x, total), nblk_n, mp0, nt0);
-    const unsigned short* w0 = w_tile(nt0);
+    const unsigned w0 = w_tile(nt0);
 #pragma unroll
-    for (int xi = 0; xi < 6; ++xi)
+    for (int st = 0; st < 2; ++st)  // steps 0 and 1 of the first tile (ns >= 6)
 #pragma unroll
-      for (int s = 0; s < NP; ++s) bw[xi][s] = *reinterpret_cast<const hf8*>(w0 + (size_t)(xi * 2 + s) * 64 * 8);
+      for (int xi = 0; xi < 6; ++xi)
+#pragma unroll
+        for (int s = 0; s < NP; ++s)
+          bw[st][xi][s] = __builtin_bit_cast(hf8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (int)(w0 + st * w_step + (unsigned)(xi * 2 + s) * 1024u), 0));
   }
 #pragma unroll
   for (int xi = 0; xi < 6; ++xi) {
@@ -363,9 +372,9 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
     int mp, nt, mp_n, nt_n;
     w4_decode(p, kocr_xcd_remap(L, total), nblk_n, mp, nt);
     w4_decode(p, kocr_xcd_remap(L + G < total ? L + G : L, total), nblk_n, mp_n, nt_n);
-    const unsigned short* w_ptr = w_tile(nt);
-    const unsigned short* w_after = w_tile(nt_n);
-    auto w_at = [&](int s) { return s < ns ? w_ptr + (size_t)s * w_step : w_after; };
+    const unsigned w_ptr = w_tile(nt), w_after = w_tile(nt_n);
+    // byte offset of step s of this tile; steps ns, ns + 1 are the next tile's first two
+    auto w_at = [&](int s) { return s < ns ? w_ptr + (unsigned)s * w_step : w_after + (unsigned)(s - ns) * w_step; };
     const float s_cur = kocr_pow2(gc.e), s_nxt = kocr_pow2(gn.e);
     const float unscale = kocr_pow2(-gc.e);  // this tile's accumulators carry 2^(e + wexp[o]); wexp is folded into pre_a
 #pragma unroll
@@ -377,20 +386,23 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
     __builtin_amdgcn_s_waitcnt(0x0F70);
     for (int cg = 0; cg < ncg; cg += 2) {
       // even channel group: consume buffer 0, produce the odd one (this tile's) into buffer 1
-      step(std::integral_constant<int, 0>{}, As, As + BUF_R, w_at(3 * cg + 1), s_cur);
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      step(I0{}, I0{}, As, As + BUF_R, w_at(3 * cg + 2), s_cur);
       load_item0(raw0);
-      step(std::integral_constant<int, 1>{}, As, As + BUF_R, w_at(3 * cg + 2), s_cur);
+      step(I1{}, I1{}, As, As + BUF_R, w_at(3 * cg + 3), s_cur);
       load_item1(raw1);
       advance();
-      step(std::integral_constant<int, 2>{}, As, As + BUF_R, w_at(3 * cg + 3), s_cur);
+      step(I2{}, I0{}, As, As + BUF_R, w_at(3 * cg + 4), s_cur);
       // odd channel group: consume buffer 1, produce the next even one (the next tile's first after the last pair) into 0
       const float s_odd = cg + 2 < ncg ? s_cur : s_nxt;
-      step(std::integral_constant<int, 0>{}, As + BUF_R, As, w_at(3 * cg + 4), s_odd);
+      step(I0{}, I1{}, As + BUF_R, As, w_at(3 * cg + 5), s_odd);
       load_item0(raw0);
-      step(std::integral_constant<int, 1>{}, As + BUF_R, As, w_at(3 * cg + 5), s_odd);
+      step(I1{}, I0{}, As + BUF_R, As, w_at(3 * cg + 6), s_odd);
       load_item1(raw1);
       advance();
-      step(std::integral_constant<int, 2>{}, As + BUF_R, As, w_at(3 * cg + 6), s_odd);
+      step(I2{}, I1{}, As + BUF_R, As, w_at(3 * cg + 7), s_odd);
     }
     gc = gn;
     lc = ln;
@@ -493,6 +505,368 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * pcs4, 0);
             }
           }
+        }
+      }
+    }
+  }
+}
+
+// ===================================================================================================
+// conv_w43rh_kernel -- the 64-cout row-reuse arrangement (conv_w43r_kernel, GEO 1: tile = 4 rows x 64 columns of one
+// image x 64 couts; wave (ph, wn) owns both M-tiles x 32 couts x the three points 3 ph .. 3 ph + 2 = 96 accumulators; the
+// partner waves exchange their partial output transforms through LDS) in fp16 arithmetic: NP planes per point, PR = 3 (1)
+// products, the per-image power-of-two scale folded into the input transform, the per-cout weight scale into pre_a.
+// CRAFT's slice1.3 (64 -> 64 at full resolution) and upconv3.conv.3.
+// ===================================================================================================
+template <int POOL, int NP>
+__global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
+  constexpr int PR = NP == 2 ? 3 : 1;
+  constexpr int NROWS = 6, QPR = 16, KHS = QPR * 8, ROW_STRIDE = 2 * KHS, PLANE_R = NROWS * ROW_STRIDE;
+  constexpr int BUF_R = 6 * NP * PLANE_R;  // one channel group: 36 KB (NP = 2)
+  constexpr int TCOLS = QPR * 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned short As[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1, ph = wave >> 1;  // cout half, point half (points 3 ph .. 3 ph + 2)
+  const int l31 = lane & 31, l5 = lane >> 5;
+  const int total = p.total_tiles;  // pixel tiles; one cout block
+  const int ncg = p.Cin >> 4;
+  const int G = gridDim.x;
+  constexpr unsigned OOB = 0x80000000u;
+
+  auto tile_mt = [&](int mp, int m) {
+    const int rq = (int)w4_fdiv((unsigned)mp, p.dv_tpr), cb = mp - rq * p.tiles_per_row;  // rq: (image, row quad)
+    return (2 * rq + m) * p.tiles_per_row + cb;
+  };
+
+  // ---- producer state (conv_w43r_kernel GEO 1) ------------------------------------------------------------------
+  const int q4 = tid & 3, qd0 = (tid >> 2) & (QPR - 1), r0 = tid >> 6;
+  const int cp = tid & 7, qd1 = (tid >> 3) & 15, r1 = 4 + (tid >> 7);
+  int ldst[2];
+  ldst[0] = r0 * ROW_STRIDE + (q4 >> 1) * KHS + (((qd0 * 8) ^ ((q4 >> 1) * 32)) + (q4 & 1) * 4);
+  ldst[1] = r1 * ROW_STRIDE + (cp >> 2) * KHS + (((qd1 * 8) ^ ((cp >> 2) * 32)) + (cp & 3) * 2);
+  struct Geo {
+    unsigned off0[2];
+    unsigned ok;
+    int e;  // exponent of the image's input scale
+    const float* base;
+  };
+  auto make_geo = [&](int L, Geo& g, bool& left, bool& right) __attribute__((always_inline)) {
+    const int mp = kocr_xcd_remap(L < total ? L : 0, total);
+    int y0, x0;
+    const long pm = w4_mtile_pm0<1>(p, tile_mt(mp, 0), y0, x0);
+    g.base = p.in + (pm * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
+    g.off0[0] = (unsigned)(((r0 * p.W + 4 * qd0) * p.in_cs + q4 * 4) * 4);
+    g.off0[1] = (unsigned)(((r1 * p.W + 4 * qd1) * p.in_cs + cp * 2) * 4);
+    g.ok = ((L < total && (unsigned)(y0 - 1 + r0) < (unsigned)p.H) ? 1u : 0u) |
+           ((L < total && (unsigned)(y0 - 1 + r1) < (unsigned)p.H) ? 2u : 0u);
+    g.e = __builtin_amdgcn_readfirstlane(kocr_scale_exp(p.amax_in + w4_fdiv((unsigned)pm, p.dv_hw), W4H_TOP));
+    left = x0 == 0;
+    right = x0 + TCOLS >= p.W;
+  };
+  Geo gc, gn;
+  bool lc, rc, ln, rn;
+  int ld_cg = 0;
+  bool ld_next = false;
+  auto load_item0 = [&](v4f (&raw)[6]) __attribute__((always_inline)) {
+    const int soff = ld_cg * 64;
+    const bool ok = (ld_next ? gn.ok : gc.ok) & 1u;
+    const unsigned off0 = (ld_next ? gn.off0[0] : gc.off0[0]) | (ok ? 0u : OOB);
+    const bool left = (ld_next ? ln : lc) && qd0 == 0, right = (ld_next ? rn : rc) && qd0 == QPR - 1;
+    const unsigned stride = (unsigned)(p.in_cs * 4);
+    const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const unsigned padk = (k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u);
+      raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (off0 + k * stride) | padk, soff, 0));
+    }
+  };
+  auto load_item1 = [&](v2f (&raw)[6]) __attribute__((always_inline)) {
+    const int soff = ld_cg * 64;
+    const bool ok = ((ld_next ? gn.ok : gc.ok) >> 1) & 1u;
+    const unsigned off0 = (ld_next ? gn.off0[1] : gc.off0[1]) | (ok ? 0u : OOB);
+    const bool left = (ld_next ? ln : lc) && qd1 == 0, right = (ld_next ? rn : rc) && qd1 == QPR - 1;
+    const unsigned stride = (unsigned)(p.in_cs * 4);
+    const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const unsigned padk = (k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u);
+      raw[k] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (off0 + k * stride) | padk, soff, 0));
+    }
+  };
+  auto advance = [&]() __attribute__((always_inline)) {
+    const bool wrap = ld_cg == ncg - 1;
+    ld_cg = wrap ? 0 : ld_cg + 1;
+    ld_next = ld_next || wrap;
+  };
+  auto produce4 = [&](const v4f (&d)[6], unsigned short* bufp, int xi, float sk) __attribute__((always_inline)) {
+    W4H_SCALED_CONSTANTS(sk);
+    const v4f V = w4h_transform(d, xi, k_s, k_sA, k_sB, k_sA2, k_sB2, k_sA2B2, k_sA2PB2);
+    unsigned short* dst = bufp + xi * NP * PLANE_R + ldst[0];
+    if constexpr (NP == 2) {
+      u2v h, l;
+      kocr_split4_h(V, h, l);
+      *reinterpret_cast<u2v*>(dst) = h;
+      *reinterpret_cast<u2v*>(dst + PLANE_R) = l;
+    } else {
+      *reinterpret_cast<u2v*>(dst) = u2v{__builtin_bit_cast(unsigned, hf2{(_Float16)V[0], (_Float16)V[1]}),
+                                         __builtin_bit_cast(unsigned, hf2{(_Float16)V[2], (_Float16)V[3]})};
+    }
+  };
+  auto produce2 = [&](const v2f (&d)[6], unsigned short* bufp, int xi, float sk) __attribute__((always_inline)) {
+    W4H_SCALED_CONSTANTS(sk);
+    const v2f V = w4h_transform(d, xi, k_s, k_sA, k_sB, k_sA2, k_sB2, k_sA2B2, k_sA2PB2);
+    unsigned short* dst = bufp + xi * NP * PLANE_R + ldst[1];
+    if constexpr (NP == 2) {
+      unsigned h, l;
+      kocr_split2_h(V, h, l);
+      *reinterpret_cast<unsigned*>(dst) = h;
+      *reinterpret_cast<unsigned*>(dst + PLANE_R) = l;
+    } else {
+      *reinterpret_cast<unsigned*>(dst) = __builtin_bit_cast(unsigned, hf2{(_Float16)V[0], (_Float16)V[1]});
+    }
+  };
+  v4f raw0[6];
+  v2f raw1[6];
+
+  // ---- consumer state ------------------------------------------------------------------------------------------
+  const size_t w_step = (size_t)2 * 12 * 64 * 8;  // ushorts per (channel group, ky) step: two 32-cout tiles, 2 pieces
+  const unsigned short* w_ptr = p.wgt + ((size_t)wn * 12 * 64 + lane) * 8;
+  const int ns = 3 * ncg;
+  hf8 bw[3][NP];
+  f16v acc[3][2];  // [point of this wave's half][M-tile]
+  const int a_lane = (l31 >> 4) * ROW_STRIDE + l5 * KHS + (((l31 & 15) * 8) ^ (l5 * 32));
+  constexpr int M_OFF = 2 * ROW_STRIDE;  // M-tile 1: two rows down
+  auto load_a = [&](hf8 (&a)[2][NP], const unsigned short* bufp, int ky, int pl) __attribute__((always_inline)) {
+    const unsigned short* base = bufp + a_lane + ky * ROW_STRIDE + (3 * ph + pl) * NP * PLANE_R;
+#pragma unroll
+    for (int s = NP - 1; s >= 0; --s)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m][s] = *reinterpret_cast<const hf8*>(base + s * PLANE_R + m * M_OFF);
+  };
+  auto mfma_grp = [&](const hf8 (&a)[2][NP], int pl) __attribute__((always_inline)) {
+    if constexpr (NP == 2) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][1], bw[pl][0], acc[pl][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], bw[pl][1], acc[pl][m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], bw[pl][0], acc[pl][m], 0, 0, 0);
+  };
+  // One channel group: nine groups (ky, point of the wave's half) of 2 PR MFMAs; the NEXT channel group is transformed
+  // meanwhile (12 chunks: six points of item 0, six of the half item, spread 2,1,1 per three groups) with the scale `sk`
+  // of the image it belongs to.  See conv_w43r_kernel for the a0 / a1 flip and the weight replacement.
+  hf8 a0[2][NP], a1[2][NP];
+  auto phase = [&](const unsigned short* bufc, unsigned short* bufn, int s0, int flip, float sk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int ky = g / 3, pp = g - ky * 3;
+      hf8(&cur)[2][NP] = ((g & 1) ^ flip) ? a1 : a0;
+      hf8(&nxt)[2][NP] = ((g & 1) ^ flip) ? a0 : a1;
+      const int nchunks = (g % 3 == 0) ? 2 : 1;
+      const int c0 = (g / 3) * 4 + (g % 3 == 0 ? 0 : g % 3 + 1);  // first chunk of this group: 0,2,3 | 4,6,7 | 8,10,11
+      if (g < 8) load_a(nxt, bufc, (g + 1) / 3, (g + 1) % 3);
+#pragma unroll
+      for (int c = c0; c < c0 + nchunks; ++c) {
+        if (c < 6)
+          produce4(raw0, bufn, c, sk);
+        else
+          produce2(raw1, bufn, c - 6, sk);
+      }
+      if (g < 8) {
+        mfma_grp(cur, pp);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);  // the LDS fetches of the next group first
+        // VALU per MFMA gap: a full chunk is ~22 VALU, a half chunk ~10; the group's LDS stores before its last MFMA
+        auto ilv = [&](auto v_c, auto st_c) __attribute__((always_inline)) {
+          constexpr int V = decltype(v_c)::value, ST = decltype(st_c)::value;
+#pragma unroll
+          for (int i = 0; i < 2 * PR - 1; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x200, ST, 0);
+        };
+        const bool half = c0 >= 6;
+        if (nchunks == 2) {
+          if (half)
+            ilv(std::integral_constant<int, 20 / (2 * PR - 1) + 1>{}, std::integral_constant<int, 2 * NP>{});
+          else
+            ilv(std::integral_constant<int, 44 / (2 * PR - 1) + 1>{}, std::integral_constant<int, 2 * NP>{});
+        } else {
+          if (half)
+            ilv(std::integral_constant<int, 10 / (2 * PR - 1) + 1>{}, std::integral_constant<int, NP>{});
+          else
+            ilv(std::integral_constant<int, 22 / (2 * PR - 1) + 1>{}, std::integral_constant<int, NP>{});
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      } else {
+        __syncthreads();  // the next channel group is complete in bufn, bufc is free
+        load_a(nxt, bufn, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_grp(cur, pp);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {  // this point's weights of the next step
+        int sn = s0 + ky + 1;
+        sn = sn >= ns ? sn - ns : sn;
+        const unsigned short* wq = w_ptr + (size_t)sn * w_step;
+#pragma unroll
+        for (int s = 0; s < NP; ++s) bw[pp][s] = *reinterpret_cast<const hf8*>(wq + (size_t)((3 * ph + pp) * 2 + s) * 64 * 8);
+      }
+      if (g == 3) load_item0(raw0);
+    }
+    load_item1(raw1);
+    advance();
+  };
+
+  // ---- prologue ------------------------------------------------------------------------------------------------
+  make_geo(blockIdx.x, gc, lc, rc);
+  make_geo(blockIdx.x + G, gn, ln, rn);
+  load_item0(raw0);
+  load_item1(raw1);
+  advance();  // channel group 0 loaded
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+    for (int s = 0; s < NP; ++s) bw[pl][s] = *reinterpret_cast<const hf8*>(w_ptr + (size_t)((3 * ph + pl) * 2 + s) * 64 * 8);
+#pragma unroll
+  for (int xi = 0; xi < 6; ++xi) {
+    produce4(raw0, As, xi, kocr_pow2(gc.e));
+    produce2(raw1, As, xi, kocr_pow2(gc.e));
+  }
+  load_item0(raw0);
+  load_item1(raw1);
+  advance();  // channel group 1 loaded
+  __syncthreads();
+  load_a(a0, As, 0, 0);
+
+  for (int L = blockIdx.x; L < total; L += G) {
+    const int mp = kocr_xcd_remap(L, total);
+    const float s_cur = kocr_pow2(gc.e), s_nxt = kocr_pow2(gn.e);
+    const float unscale = kocr_pow2(-gc.e);
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][m][r] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int cg = 0; cg < ncg; cg += 2) {
+      phase(As, As + BUF_R, 3 * cg, 0, s_cur);                             // produces channel group cg + 1 (this tile's)
+      phase(As + BUF_R, As, 3 * cg + 3, 1, cg + 2 < ncg ? s_cur : s_nxt);  // ... cg + 2, or the next tile's first
+    }
+    gc = gn;
+    lc = ln;
+    rc = rn;
+    make_geo(L + 2 * G, gn, ln, rn);
+    ld_next = false;
+
+    // ---- epilogue (conv_w43r_kernel's: partial output transforms exchanged between the point halves) -----------------
+    {
+      const int n = wn * 32 + l31;
+      const int nc = n < p.Cout ? n : p.Cout - 1;
+      const float pa = p.pre_a[nc] * unscale, pb = p.pre_b[nc];  // pre_a = pre_a 2^-wexp[o] (ConvLayer::d_pre_a_h)
+      const bool has_post = p.post_a != nullptr;
+      const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
+      const bool live = n < p.Cout;
+      const float lo = p.relu ? 0.f : -INFINITY;
+      auto act = [&](float v) { return fmaxf(v * pa + pb, lo); };
+      v4f* xch = reinterpret_cast<v4f*>(As + BUF_R);  // the K loop's second buffer: free since the last block barrier
+      float out[4][16];
+      auto halves = [&](auto ph_c) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph_c)::value;
+        auto partial = [&](auto m_c, int r, float (&o)[4]) __attribute__((always_inline)) {
+          constexpr int M = decltype(m_c)::value;
+          const float u = acc[0][M][r], v = acc[1][M][r], w = acc[2][M][r];
+          if constexpr (PH == 0) {
+            const float s12 = v + w, d12 = v - w;
+            o[0] = u + s12;
+            o[1] = W4_A * d12;
+            o[2] = W4_A2 * s12;
+            o[3] = W4_A3 * d12;
+          } else {
+            const float s34 = u + v, d34 = u - v;
+            o[0] = s34;
+            o[1] = W4_B * d34;
+            o[2] = W4_B2 * s34;
+            o[3] = W4_B3 * d34 + w;
+          }
+        };
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float o[4];
+          partial(std::integral_constant<int, 1 - PH>{}, r, o);
+          xch[(wave * 16 + r) * 64 + lane] = v4f{o[0], o[1], o[2], o[3]};
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float o[4];
+          partial(std::integral_constant<int, PH>{}, r, o);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) out[j][r] = o[j];
+        }
+      };
+      if (ph == 0)
+        halves(std::integral_constant<int, 0>{});
+      else
+        halves(std::integral_constant<int, 1>{});
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const v4f q = xch[((wave ^ 2) * 16 + r) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j][r] = act(out[j][r] + q[j]);
+      }
+      if (has_post) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) out[j][r] = out[j][r] * qa + qb;
+      }
+      __syncthreads();  // the next channel group is transformed into this buffer
+      int ocs4 = p.out_cs * 4;
+      asm volatile("" : "+s"(ocs4));
+      int pcs4 = p.pool_cs * 4;
+      asm volatile("" : "+s"(pcs4));
+      int y0, x0;
+      const long pm = w4_mtile_pm0<1>(p, tile_mt(mp, ph), y0, x0);
+      if (p.amax_out || p.amax_pool) {
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(out[j][r]));
+        mx = live ? mx : 0.f;
+        const unsigned nimg = w4_fdiv((unsigned)pm, p.dv_hw);
+        if (p.amax_out) kocr_amax_update(p.amax_out + nimg, mx);
+        if (p.amax_pool) kocr_amax_update(p.amax_pool + nimg, mx);
+      }
+      if (!POOL || p.write_full) {
+        const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (pm * p.out_cs + p.out_co), 0x7FFFFFFFu);
+        const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int px = 4 * ((r & 3) + 8 * (r >> 2));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out[j][r]), ro, vo, (px + j) * ocs4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out[j][r + 8]), ro, vo, (px + j + p.W) * ocs4, 0);
+          }
+        }
+      }
+      if constexpr (POOL) {
+        const long pp0 = ((pm - x0) >> 2) + (x0 >> 1);
+        const __amdgpu_buffer_rsrc_t rp = w4_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
+        const unsigned vp = live ? (unsigned)((8 * l5 * p.pool_cs + n) * 4) : OOB;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int pq = 2 * ((r & 3) + 8 * (r >> 2));
+          const float v0 = fmaxf(fmaxf(out[0][r], out[1][r]), fmaxf(out[0][r + 8], out[1][r + 8]));
+          const float v1 = fmaxf(fmaxf(out[2][r], out[3][r]), fmaxf(out[2][r + 8], out[3][r + 8]));
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * pcs4, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * pcs4, 0);
         }
       }
     }
@@ -621,4 +995,33 @@ int launch_w43vh(kocr_ctx* ctx, W4Params& p, bool fuse, int geo, int pieces) {
   }
   if (geo == 2) return w4vh_launch<0, 2, 1>(ctx, p);
   return fuse ? w4vh_launch<1, 1, 1>(ctx, p) : w4vh_launch<0, 1, 1>(ctx, p);
+}
+
+template <int POOL, int NP>
+static int w4rh_launch(kocr_ctx* ctx, W4Params& p) {
+  constexpr int LDSR = 6 * NP * 6 * 256 * 2 + 4 * 16 * 64 * 16;  // one 36 KB buffer + the epilogue's 64 KB exchange area
+  static std::atomic<bool> attr_done[64];
+  const int dev = ctx->device & 63;
+  if (!attr_done[dev]) {
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43rh_kernel<POOL, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSR));
+    attr_done[dev] = true;
+  }
+  static std::atomic<int> n_cus[64];
+  if (!n_cus[dev]) {
+    hipDeviceProp_t prop;
+    KOCR_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    n_cus[dev] = prop.multiProcessorCount;
+  }
+  const int n_cu = n_cus[dev];
+  const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
+  hipLaunchKernelGGL((conv_w43rh_kernel<POOL, NP>), dim3(grid), dim3(256), LDSR, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
+// the 64-cout row-reuse arrangement (4 x 64 tiles) in fp16 arithmetic: p as launch_conv_w43 filled it for
+// conv_w43r_kernel<POOL, 1>, with wgt = d_w4h, pre_a = d_pre_a_h and amax_in set
+int launch_w43rh(kocr_ctx* ctx, W4Params& p, bool fuse, int pieces) {
+  if (pieces == 2) return fuse ? w4rh_launch<1, 2>(ctx, p) : w4rh_launch<0, 2>(ctx, p);
+  return fuse ? w4rh_launch<1, 1>(ctx, p) : w4rh_launch<0, 1>(ctx, p);
 }

@@ -361,7 +361,7 @@ int craft_run(kocr_ctx* ctx, CraftNet* net, const void* d_img, int dtype, int N,
   // conv + 2x2 max-pool: fused epilogue when the shape tiles, else two kernels; need_full: the pre-pool tensor is
   // consumed elsewhere (skip connection).  The full-resolution buffer of an un-needed tensor is returned at once.
   Tensor a1, a2, p1, b1, cat4, p2, c1, cat3, c3, p3, e1, cat2, f1, p4, g1, cat1, h0, h1;
-  KOCR_TRY(mk(d.H, d.W, 64, &a1));  // (feeds slice1.3: 64 couts, bf16x3 row-reuse kernel -- no slots needed)
+  KOCR_TRY(mk(d.H, d.W, 64, &a1, true));
   RUN(launch_conv(ctx, L("basenet.slice1.0"), x0, u8, lut, a1));
   KOCR_TRY(mk(d.H, d.W, 64, &a2));
   KOCR_TRY(mk(d.H2, d.W2, 64, &p1, true));

@@ -111,7 +111,7 @@ def test_conv_transpose_detecting(ctx):
 SPLIT_CASES = [
     # N, H, W, Cin, Cout, family
     (1, 96, 192, 256, 256, "conv_w4hv_256x128"),   # 288 tiles > 256 CUs: blocks take a second tile; vertical reuse, 4 x 64
-    (2, 64, 128, 64, 64, "conv_w4s_256x64"),       # 64 couts: row-reuse arrangement, 4 x 64
+    (2, 64, 128, 64, 64, "conv_w4hr_256x64"),       # 64 couts: row-reuse arrangement, 4 x 64
     (1, 40, 64, 48, 96, "conv_ws_128x128"),        # Cin % 32 != 0: F(2,3) kernel, 9 K-steps (odd)
     (1, 30, 50, 512, 130, "conv_ws_128x128"),      # W % 4 != 0: F(2,3), ragged couts, tiles crossing image rows
     # conv_w43.hip (Winograd F(4,3): Cin % 32 == 0, Cout > 64, W % 4 == 0)
@@ -121,13 +121,13 @@ SPLIT_CASES = [
     (3, 8, 4, 32, 96, "conv_w4s_256x128"),         # a single quad per row: both column paddings in one quad
     # 32 < Cout <= 64: the 64-cout arrangement of conv_w43.hip (512-pixel tiles, two gather items per thread)
     (1, 17, 36, 32, 48, "conv_w4s_512x64"),        # ragged couts, odd height, last tile mostly outside
-    (2, 40, 128, 128, 64, "conv_w4s_256x64"),      # upconv3.conv.3 class (row reuse, 4 x 64)
+    (2, 40, 128, 128, 64, "conv_w4hr_256x64"),      # upconv3.conv.3 class (row reuse, 4 x 64)
     # 32 < Cout <= 64 on images that tile as 4 rows x 64 columns / 2 rows x 128 columns: the row-reuse arrangement
     (1, 6, 128, 32, 48, "conv_w4s_256x64"),        # 2 x 128 (H % 4 != 0): two channel groups, one tile per row pair, ragged couts
-    (2, 8, 256, 64, 64, "conv_w4s_256x64"),        # 4 x 64: slice1.3 class, four channel groups, four tiles per row quad, two images
-    (1, 4, 384, 96, 40, "conv_w4s_256x64"),        # 4 x 64: six channel groups, one row quad
+    (2, 8, 256, 64, 64, "conv_w4hr_256x64"),        # 4 x 64: slice1.3 class, four channel groups, four tiles per row quad, two images
+    (1, 4, 384, 96, 40, "conv_w4hr_256x64"),        # 4 x 64: six channel groups, one row quad
     (2, 10, 256, 64, 64, "conv_w4s_256x64"),       # 2 x 128: two tiles per row pair, two images
-    (3, 12, 64, 32, 33, "conv_w4s_256x64"),        # 4 x 64: one tile per row quad, one live column in the second cout half
+    (3, 12, 64, 32, 33, "conv_w4hr_256x64"),        # 4 x 64: one tile per row quad, one live column in the second cout half
     # Cout > 64 on images that tile as 4 rows x 64 columns or 8 rows x 32 columns: the vertical-reuse arrangement
     (2, 8, 256, 64, 128, "conv_w4hv_256x128"),     # 4 x 64: slice1.7 class, four channel groups, four tiles per row quad, two images
     (1, 4, 192, 32, 130, "conv_w4hv_256x128"),     # 4 x 64: one row quad (both vertical paddings in every tile), ragged couts
@@ -150,7 +150,7 @@ def _expect_family(ctx, rows, family):
     if any(k.startswith("KOCR_") and k not in ("KOCR_SPLIT",) for k in os.environ):
         return
     if ctx.get_split_mode() == 0:
-        family = family.replace("conv_w4h", "conv_w4")
+        family = family.replace("conv_w4hr", "conv_w4s").replace("conv_w4h", "conv_w4")
     conv = sorted(k for k in rows if k.startswith("conv"))
     assert conv == [family], f"expected the launch on {family}, profiler rows: {sorted(rows)}"
 

@@ -76,7 +76,8 @@ CASES = [
     # N, H, W, Cin, Cout, k, dil, kernel family in f16x2 mode
     (1, 48, 192, 256, 256, 3, 1, "conv_w4hv_256x128"),   # fp16 F(4,3), 4 x 64 tiles
     (2, 16, 96, 128, 128, 3, 1, "conv_w4ht_256x128"),    # fp16 F(4,3), 8 x 32 tiles, two images
-    (1, 32, 128, 64, 64, 3, 1, "conv_w4s_256x64"),       # 64 couts: bf16x3 row-reuse kernel in both modes
+    (1, 32, 128, 64, 64, 3, 1, "conv_w4hr_256x64"),      # 64 couts: fp16 row-reuse kernel, 4 x 64 tiles
+    (1, 6, 128, 32, 48, 3, 1, "conv_w4s_256x64"),        # 64 couts, 2 x 128 tiles: bf16x3 row-reuse kernel in both modes
     (1, 96, 96, 128, 192, 1, 1, "conv_ds_256x128"),      # direct split kernel, 1x1 (bf16x3 in both modes)
     (1, 80, 64, 64, 128, 3, 6, "conv_ds_256x128"),       # direct split kernel, dilated, W % 24 != 0
 ]
@@ -91,7 +92,7 @@ def test_fp32_class_on_ordinary_data(mode_ctx, case):
     wt = (rng.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32)
     got, rows = _conv_rows(ctx, x, wt, dilation=dil)
     if _plain_env():
-        want_row = family if mode == "f16x2" else family.replace("conv_w4h", "conv_w4")
+        want_row = family if mode == "f16x2" else family.replace("conv_w4hr", "conv_w4s").replace("conv_w4h", "conv_w4")
         assert rows == [want_row], f"{mode}: expected {want_row}, profiler rows {rows}"
     _check(got, x, wt, dil, mode)
 

@@ -237,6 +237,7 @@ struct W4Params;
 int prepare_w43h(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, const float* pre_a);
 int launch_w43vh(kocr_ctx* ctx, W4Params& p, bool fuse, int geo, int pieces);
 int launch_w43rh(kocr_ctx* ctx, W4Params& p, bool fuse, int pieces);
+int launch_w43fh(kocr_ctx* ctx, W4Params& p, int pieces);
 bool w43_applicable(const kocr_ctx* ctx, const ConvLayer& L, const Tensor& in);
 int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
                     bool need_full);

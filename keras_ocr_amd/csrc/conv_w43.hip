@@ -1822,15 +1822,18 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   w4_div_magic((unsigned)(in.H * in.W), p.dv_hw);
   // Per-image max-|x| slots (Tensor::amax): the one-image tiles of the row-reuse / vertical-reuse arrangements maintain
   // them in their epilogue; the flattened-pixel arrangements leave them to a reduction pass after the launch.
-  const bool tracks = rowreuse || vreuse;
+  // fp16 arithmetic (conv_w43h.hip) where an fp16 kernel exists for the arrangement; else the exact bf16x3 kernels
+  const int pieces = ctx->split_mode == KOCR_SPLIT_F16X2 ? 2 : ctx->split_mode == KOCR_SPLIT_F16X1 ? 1 : 0;
+  const bool no_h = !ctx->sw.w43h;
+  // ... the flattened-pixel arrangement too (no fused pooling, dilation 1; a 256-pixel tile must not span three images)
+  const bool flat_h = pieces && !no_h && L.d_w4h && !narrow && !vreuse && !rowreuse && L.dil == 1 && !fuse &&
+                      (size_t)in.H * in.W >= 256;
+  const bool use_h = (pieces && !no_h && L.d_w4h && (vreuse || (rowreuse && rgeo == 1))) || flat_h;
+  const bool tracks = rowreuse || vreuse || flat_h;
   if (tracks) {
     p.amax_out = (!fuse || need_full) ? out.amax : nullptr;
     p.amax_pool = fuse ? pool->amax : nullptr;
   }
-  // fp16 arithmetic (conv_w43h.hip) where an fp16 kernel exists for the arrangement; else the exact bf16x3 kernels
-  const int pieces = ctx->split_mode == KOCR_SPLIT_F16X2 ? 2 : ctx->split_mode == KOCR_SPLIT_F16X1 ? 1 : 0;
-  const bool no_h = !ctx->sw.w43h;
-  const bool use_h = pieces && !no_h && L.d_w4h && (vreuse || (rowreuse && rgeo == 1));
   if (use_h) {
     const unsigned* slots = in.amax;
     if (!slots) {  // the producer did not track: reduce the input once, per image
@@ -1852,9 +1855,9 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s:%s", use_h ? (pieces == 2 ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : (use_h ? "r" : "s"), rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s:%s", use_h ? (pieces == 2 ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : (flat_h ? "f" : use_h ? "r" : "s"), rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s", use_h ? (pieces == 2 ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : (use_h ? "r" : "s"), rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
+    snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s", use_h ? (pieces == 2 ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : (flat_h ? "f" : use_h ? "r" : "s"), rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   {
@@ -1884,6 +1887,8 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
 #endif
     if (use_h && vreuse) {
       KOCR_TRY(launch_w43vh(ctx, p, fuse, vgeo, pieces));
+    } else if (flat_h) {
+      KOCR_TRY(launch_w43fh(ctx, p, pieces));
     } else if (use_h) {
       KOCR_TRY(launch_w43rh(ctx, p, fuse, pieces));
     } else if (vreuse) {

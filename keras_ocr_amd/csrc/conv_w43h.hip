@@ -873,6 +873,283 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
   }
 }
 
+// ===================================================================================================
+// conv_w43fh_kernel -- the flattened-pixel arrangement (conv_w43_kernel, no fused pooling, dilation 1) in fp16 arithmetic,
+// for Cout > 64 layers whose images tile neither as 4 x 64 nor as 8 x 32: the recogniser's conv_2 ... conv_5 (31 x 200 and
+// 15 x 100 crops), odd CRAFT sizes.  Tile = 64 quads (256 flattened pixels, may cross image rows and IMAGES) x 128 couts;
+// K-step = (16-channel group, ky): every step gathers, transforms and splits the input row it needs (no vertical reuse).
+// The input scale is per image, so here it is per QUAD: a producer thread looks up the slot of the image its quad lies
+// in; a tile of 256 pixels touches at most two images (the launcher requires H W >= 256), so the epilogue undoes the
+// scale with a per-accumulator-row select between two factors and maintains the two images' max-|x| slots separately.
+// ===================================================================================================
+template <int NP>
+__global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
+  constexpr int PR = NP == 2 ? 3 : 1;
+  constexpr int PLANE_F = PLANE;          // one (xi, piece) plane: 2 M-tiles x 2 k halves x 256 ushorts (w43_common.h)
+  constexpr int BUF_F = 6 * NP * PLANE_F; // one K-step: 24 KB (NP = 2)
+  extern __shared__ __attribute__((aligned(16))) unsigned short As[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, l5 = lane >> 5;
+  const int nblk_n = p.Cout_pad >> 7;
+  const int total = p.total_tiles;
+  const int ns = p.nsteps;
+  const int G = gridDim.x;
+  const int hw = p.H * p.W;
+  constexpr unsigned OOB = 0x80000000u;
+
+  // ---- producer state: this thread's gather item = (quad qi of the 64-quad tile, channel quad q4) ----------------------
+  const int qi = tid >> 2, q4 = tid & 3;
+  const int ldst = ((qi >> 5) * 2 + (q4 >> 1)) * KH_STRIDE + ((((qi & 31) * 8) ^ ((q4 >> 1) * 32)) + (q4 & 1) * 4);
+  struct Geo {
+    unsigned goff[6];
+    int gy;
+    bool gok;
+    float s;  // 2^e of the image this thread's quad lies in
+    const float* base;
+  };
+  auto make_geo = [&](int L, Geo& g) __attribute__((always_inline)) {
+    int mp, nt_unused;
+    w4_decode(p, kocr_xcd_remap(L < total ? L : 0, total), nblk_n, mp, nt_unused);
+    const long pm_a = (long)mp * 256;
+    g.base = p.in + (pm_a * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
+    const int rel = 4 * qi;
+    const long gp = pm_a + rel;
+    g.gok = L < total && gp < p.Mtotal;
+    const int x0 = (int)(gp % p.W);
+    g.gy = (int)((gp / p.W) % p.H);
+    const long gpc = gp < p.Mtotal ? gp : (long)p.Mtotal - 1;
+    g.s = kocr_pow2(kocr_scale_exp(p.amax_in + w4_fdiv((unsigned)gpc, p.dv_hw), W4H_TOP));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const bool pad = (k == 0 && x0 < 1) || (k == 5 && x0 + 4 >= p.W);  // column zero padding
+      g.goff[k] = pad ? OOB : (unsigned)(((rel + k) * p.in_cs + q4 * 4) * 4);
+    }
+  };
+  Geo gc, gn;
+  int ld_ky = 0, ld_cg = 0;  // position of the NEXT K-step to load inside its tile
+  bool ld_next = false;      // ... and whether that tile is already the next one
+  const int ncg = p.Cin >> 4;
+  auto load_raw = [&](v4f (&raw)[6]) __attribute__((always_inline)) {
+    const int soff = (ld_ky * p.W * p.in_cs + ld_cg * 16) * 4;
+    const int gy = ld_next ? gn.gy : gc.gy;
+    const bool ok = (ld_next ? gn.gok : gc.gok) & ((unsigned)(gy + (ld_ky - 1)) < (unsigned)p.H);
+    const unsigned kill = ok ? 0u : OOB;
+    const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (ld_next ? gn.goff[k] : gc.goff[k]) | kill, soff, 0));
+    const bool wrap_ky = ld_ky == 2;
+    ld_ky = wrap_ky ? 0 : ld_ky + 1;
+    const bool wrap_cg = wrap_ky && ld_cg == ncg - 1;
+    ld_cg = wrap_cg ? 0 : (wrap_ky ? ld_cg + 1 : ld_cg);
+    ld_next = ld_next || wrap_cg;
+  };
+  auto produce_point = [&](const v4f (&d)[6], unsigned short* bufp, int xi, float sk) __attribute__((always_inline)) {
+    W4H_SCALED_CONSTANTS(sk);
+    const v4f V = w4h_transform(d, xi, k_s, k_sA, k_sB, k_sA2, k_sB2, k_sA2B2, k_sA2PB2);
+    unsigned short* dst = bufp + xi * NP * PLANE_F + ldst;
+    if constexpr (NP == 2) {
+      u2v h, l;
+      kocr_split4_h(V, h, l);
+      *reinterpret_cast<u2v*>(dst) = h;
+      *reinterpret_cast<u2v*>(dst + PLANE_F) = l;
+    } else {
+      *reinterpret_cast<u2v*>(dst) = u2v{__builtin_bit_cast(unsigned, hf2{(_Float16)V[0], (_Float16)V[1]}),
+                                         __builtin_bit_cast(unsigned, hf2{(_Float16)V[2], (_Float16)V[3]})};
+    }
+  };
+
+  // ---- consumer state ------------------------------------------------------------------------------------------------
+  const int ntiles32 = p.Cout_pad >> 5;
+  const size_t w_step = (size_t)ntiles32 * 12 * 64 * 8;  // ushorts per K-step
+  auto w_tile = [&](int nt) { return p.wgt + ((size_t)(nt * 4 + wn) * 12 * 64 + lane) * 8; };
+  hf8 bw[6][NP];
+  f16v acc[6][2];
+  const int a_lane = l5 * KH_STRIDE + ((l31 * 8) ^ (l5 * 32));
+  auto load_a = [&](hf8 (&a)[2][NP], const unsigned short* bufp, int xi) __attribute__((always_inline)) {
+    const unsigned short* base = bufp + xi * NP * PLANE_F + a_lane;
+#pragma unroll
+    for (int s = NP - 1; s >= 0; --s)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m][s] = *reinterpret_cast<const hf8*>(base + s * PLANE_F + m * 2 * KH_STRIDE);
+  };
+  auto mfma_pt = [&](const hf8 (&a)[2][NP], int xi) __attribute__((always_inline)) {
+    if constexpr (NP == 2) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][1], bw[xi][0], acc[xi][m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], bw[xi][1], acc[xi][m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) acc[xi][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], bw[xi][0], acc[xi][m], 0, 0, 0);
+  };
+  // One K-step: consume `bufc` (6 points x 2 PR MFMAs) while producing the NEXT step from `raw` (scale sk) into `bufn`;
+  // see conv_w43_kernel::step for the order of fetches, stores, the weight replacement and the barrier placement.
+  hf8 a0[2][NP], a1[2][NP];
+  auto step = [&](const unsigned short* bufc, unsigned short* bufn, const v4f (&raw)[6], const unsigned short* w_next, float sk)
+                  __attribute__((always_inline)) {
+    auto load_b = [&](int xi) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < NP; ++s) bw[xi][s] = *reinterpret_cast<const hf8*>(w_next + (size_t)(xi * 2 + s) * 64 * 8);
+    };
+    auto interleave = [&]() __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);
+      constexpr int VPG = 30 / (2 * PR - 1) + 1;
+#pragma unroll
+      for (int i = 0; i < 2 * PR - 1; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x200, NP, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    };
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(a1, bufc, 2 * q + 1);
+      produce_point(raw, bufn, 2 * q, sk);
+      mfma_pt(a0, 2 * q);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(2 * q);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q < 2) {
+        load_a(a0, bufc, 2 * q + 2);
+        produce_point(raw, bufn, 2 * q + 1, sk);
+        mfma_pt(a1, 2 * q + 1);
+        interleave();
+      } else {
+        produce_point(raw, bufn, 5, sk);
+        __syncthreads();  // next step complete in bufn, bufc free
+        load_a(a0, bufn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_pt(a1, 5);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(2 * q + 1);
+    }
+  };
+
+  // ---- pipeline prologue ---------------------------------------------------------------------------------------------
+  make_geo(blockIdx.x, gc);
+  make_geo(blockIdx.x + G, gn);
+  v4f rawA[6], rawB[6];
+  load_raw(rawA);  // global step 0
+  load_raw(rawB);  // global step 1
+  {
+    int mp0, nt0;
+    w4_decode(p, kocr_xcd_remap(blockIdx.x, total), nblk_n, mp0, nt0);
+    const unsigned short* w0 = w_tile(nt0);
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi)
+#pragma unroll
+      for (int s = 0; s < NP; ++s) bw[xi][s] = *reinterpret_cast<const hf8*>(w0 + (size_t)(xi * 2 + s) * 64 * 8);
+  }
+#pragma unroll
+  for (int xi = 0; xi < 6; ++xi) produce_point(rawA, As, xi, gc.s);
+  load_raw(rawA);  // global step 2
+  __syncthreads();
+  load_a(a0, As, 0);
+
+  for (int L = blockIdx.x; L < total; L += G) {
+    int mp, nt, mp_n, nt_n;
+    w4_decode(p, kocr_xcd_remap(L, total), nblk_n, mp, nt);
+    w4_decode(p, kocr_xcd_remap(L + G < total ? L + G : L, total), nblk_n, mp_n, nt_n);
+    const unsigned short* w_ptr = w_tile(nt);
+    const unsigned short* w_after = w_tile(nt_n);
+    const float s_cur = gc.s, s_nxt = gn.s;
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][m][r] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int s = 0; s < ns; s += 2) {
+      step(As, As + BUF_F, rawB, w_ptr + (size_t)(s + 1) * w_step, s_cur);  // produces the odd step s + 1 (this tile's)
+      load_raw(rawB);
+      // produces step s + 2: this tile's, or the next tile's first
+      step(As + BUF_F, As, rawA, s + 2 < ns ? w_ptr + (size_t)(s + 2) * w_step : w_after, s + 2 < ns ? s_cur : s_nxt);
+      load_raw(rawA);
+    }
+    gc = gn;
+    make_geo(L + 2 * G, gn);
+    ld_next = false;
+
+    // ---- epilogue: 32x32 C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----------------------------
+    {
+      const int n = (nt * 4 + wn) * 32 + l31;
+      const int nc = n < p.Cout ? n : p.Cout - 1;
+      const long pm0 = (long)mp * 256;
+      // the tile's (at most two) images, the first quad of the second one, their unscale factors 2^-e
+      const long pm0c = pm0 < (long)p.Mtotal ? pm0 : (long)p.Mtotal - 1;
+      const int n0 = __builtin_amdgcn_readfirstlane((int)w4_fdiv((unsigned)pm0c, p.dv_hw));
+      const long b1 = ((long)(n0 + 1) * hw - pm0) >> 2;  // quads of the tile that lie in image n0 (W % 4 == 0)
+      const int qb = __builtin_amdgcn_readfirstlane((int)(b1 < 64 ? b1 : 64));
+      const int n1 = ((long)(n0 + 1) * hw < (long)p.Mtotal) ? n0 + 1 : n0;
+      const float u0 = kocr_pow2(-kocr_scale_exp(p.amax_in + n0, W4H_TOP)), u1 = kocr_pow2(-kocr_scale_exp(p.amax_in + n1, W4H_TOP));
+      const float pa0 = p.pre_a[nc] * u0, pa1 = p.pre_a[nc] * u1, pb = p.pre_b[nc];
+      const bool has_post = p.post_a != nullptr;
+      const float qa = has_post ? p.post_a[nc] : 1.f, qb_ = has_post ? p.post_b[nc] : 0.f;
+      const bool live = n < p.Cout;
+      const float lo = p.relu ? 0.f : -INFINITY;
+      const int qlim = (int)((((long)p.Mtotal - pm0) >> 2) < 64 ? (((long)p.Mtotal - pm0) >> 2) : 64);  // quads inside the tensor
+      float mx0 = 0.f, mx1 = 0.f;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int q = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * l5;
+          const bool first = q < qb;
+          const float pa = first ? pa0 : pa1;
+          const float m0 = acc[0][m][r], m1 = acc[1][m][r], m2 = acc[2][m][r], m3 = acc[3][m][r], m4 = acc[4][m][r],
+                      m5 = acc[5][m][r];
+          const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+          float o0 = fmaxf(((m0 + s12) + s34) * pa + pb, lo);
+          float o1 = fmaxf((W4_A * d12 + W4_B * d34) * pa + pb, lo);
+          float o2 = fmaxf((W4_A2 * s12 + W4_B2 * s34) * pa + pb, lo);
+          float o3 = fmaxf(((W4_A3 * d12 + W4_B3 * d34) + m5) * pa + pb, lo);
+          if (has_post) {
+            o0 = o0 * qa + qb_;
+            o1 = o1 * qa + qb_;
+            o2 = o2 * qa + qb_;
+            o3 = o3 * qa + qb_;
+          }
+          acc[0][m][r] = o0;
+          acc[1][m][r] = o1;
+          acc[2][m][r] = o2;
+          acc[3][m][r] = o3;
+          if (p.amax_out) {
+            const float mq = (live && q < qlim) ? fmaxf(fmaxf(fabsf(o0), fabsf(o1)), fmaxf(fabsf(o2), fabsf(o3))) : 0.f;
+            mx0 = fmaxf(mx0, first ? mq : 0.f);
+            mx1 = fmaxf(mx1, first ? 0.f : mq);
+          }
+        }
+      if (p.amax_out) {
+        kocr_amax_update(p.amax_out + n0, mx0);
+        if (qb < 64) kocr_amax_update(p.amax_out + n1, mx1);
+      }
+      int ocs4 = p.out_cs * 4;
+      asm volatile("" : "+s"(ocs4));
+      // bytes from the tile's first pixel to the end of the tensor: stores past it are dropped
+      const long rem = ((long)p.Mtotal - pm0) * ocs4;
+      const __amdgpu_buffer_rsrc_t ro =
+          w4_rsrc(p.out + (pm0 * p.out_cs + p.out_co), rem < 0x7FFFFFFFL ? (unsigned)(rem > 0 ? rem : 0) : 0x7FFFFFFFu);
+      const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int px = 4 * (m * 32 + (r & 3) + 8 * (r >> 2));  // + 16 l5 in vo
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vo, (px + j) * ocs4, 0);
+        }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -1025,3 +1302,29 @@ int launch_w43rh(kocr_ctx* ctx, W4Params& p, bool fuse, int pieces) {
   if (pieces == 2) return fuse ? w4rh_launch<1, 2>(ctx, p) : w4rh_launch<0, 2>(ctx, p);
   return fuse ? w4rh_launch<1, 1>(ctx, p) : w4rh_launch<0, 1>(ctx, p);
 }
+
+template <int NP>
+static int w4fh_launch(kocr_ctx* ctx, W4Params& p) {
+  constexpr int LDSF = 2 * 6 * NP * 2 * 2 * 256 * 2;  // 2 x 24 KB (NP = 2)
+  static std::atomic<bool> attr_done[64];
+  const int dev = ctx->device & 63;
+  if (!attr_done[dev]) {
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43fh_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSF));
+    attr_done[dev] = true;
+  }
+  static std::atomic<int> n_cus[64];
+  if (!n_cus[dev]) {
+    hipDeviceProp_t prop;
+    KOCR_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    n_cus[dev] = prop.multiProcessorCount;
+  }
+  const int n_cu = n_cus[dev];
+  const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
+  hipLaunchKernelGGL((conv_w43fh_kernel<NP>), dim3(grid), dim3(256), LDSF, ctx->stream, p);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
+// the flattened-pixel arrangement (no fused pooling, dilation 1, H W >= 256) in fp16 arithmetic: p as launch_conv_w43
+// filled it for conv_w43_kernel<0>, with wgt = d_w4h, pre_a = d_pre_a_h, amax_in set and amax_out = out.amax (per image)
+int launch_w43fh(kocr_ctx* ctx, W4Params& p, int pieces) { return pieces == 2 ? w4fh_launch<2>(ctx, p) : w4fh_launch<1>(ctx, p); }

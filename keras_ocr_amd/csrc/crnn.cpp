@@ -185,12 +185,16 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
   if (!net || !net->loaded) KOCR_FAIL(ctx, KOCR_ENOWEIGHTS, "kocr_crnn_forward: call kocr_load_crnn first");
   if (M <= 0) return KOCR_OK;
   KOCR_TRY(ctx->amax_begin());
-  // The recogniser always runs the exact bf16x3 split (its conv stack has no fp16 F(4,3) arrangement yet: 31 x 200 and
-  // 15 x 100 crops tile neither as 4 x 64 nor as 8 x 32).
+  // Arithmetic: conv_2 ... conv_5 take the flattened-pixel F(4,3) kernel in the context's mode -- fp16x2 with one input scale
+  // per CROP (the "images" of this batch), so a crop's result does not depend on its neighbours in the batch; the
+  // reduced-precision KOCR_SPLIT_F16X1 is a detector-only mode: the recogniser then runs fp16x2 (its decoded strings hang on
+  // top-1 margins).  conv_6 / conv_7 (width 50) stay on the exact bf16x3 F(2,3) kernel.
   struct ModeGuard {
     kocr_ctx* c;
     int old;
-    explicit ModeGuard(kocr_ctx* ctx) : c(ctx), old(ctx->split_mode) { c->split_mode = KOCR_SPLIT_BF16X3; }
+    explicit ModeGuard(kocr_ctx* ctx) : c(ctx), old(ctx->split_mode) {
+      if (c->split_mode == KOCR_SPLIT_F16X1) c->split_mode = KOCR_SPLIT_F16X2;
+    }
     ~ModeGuard() { c->split_mode = old; }
   } mode_guard(ctx);
   auto mk = [&](int n, int h, int w, int c, Tensor* t) -> int {
@@ -227,14 +231,19 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
   x0.co = 0;
   x0.p = const_cast<float*>(d_crops);
   KOCR_TRY(mk(M, HC, WC, 64, &c1));
+  c1.amax = ctx->amax_slots(M);  // per-crop max |x| for the fp16 consumer (conv_2); nullptr in bf16x3 mode
   KOCR_TRY(conv("conv_1", x0, c1));
   KOCR_TRY(mk(M, HC, WC, 128, &c2));
+  c2.amax = ctx->amax_slots(M);
   KOCR_TRY(conv("conv_2", c1, c2));
   KOCR_TRY(mk(M, HC, WC, 256, &c3));
+  c3.amax = ctx->amax_slots(M);
   KOCR_TRY(conv("conv_3", c2, c3));  // ReLU then bn_3
   KOCR_TRY(mk(M, HC / 2, WC / 2, 256, &p3));
+  p3.amax = ctx->amax_slots(M);
   KOCR_TRY(launch_maxpool2x2(ctx, c3, p3, /*row_off=*/1));
   KOCR_TRY(mk(M, HC / 2, WC / 2, 256, &c4));
+  c4.amax = ctx->amax_slots(M);
   KOCR_TRY(conv("conv_4", p3, c4));
   KOCR_TRY(mk(M, HC / 2, WC / 2, 512, &c5));
   KOCR_TRY(conv("conv_5", c4, c5));

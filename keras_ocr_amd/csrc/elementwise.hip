@@ -6,6 +6,7 @@
 // All kernels move float4 (4 channels) per lane, lanes run along channels then pixels, so a
 // wave touches whole 128-B lines of both the source and the destination.
 #include "common.h"
+#include <algorithm>
 
 struct EwParams {
   const float* in;
@@ -348,8 +349,11 @@ int launch_absmax(kocr_ctx* ctx, const Tensor& t, unsigned* slots) {
   const size_t total = (size_t)t.H * t.W * (t.C / 4);
   if (!total || !t.N) return KOCR_OK;
   ProfScope ps(ctx, "absmax", 0, 4.0 * t.pixels() * t.C);
-  size_t b = (total + 255) / 256;
-  if (b > 1024) b = 1024;
+  // >= 16 sixteen-byte loads per thread and at most a few thousand blocks in all: a block per 256 values drowned small
+  // images (the recogniser's 512 crops) in block launches and same-address atomics (0.3 TB/s)
+  size_t b = (total + 4095) / 4096;
+  const size_t cap = std::max<size_t>(1, 4096 / (size_t)t.N);
+  if (b > cap) b = cap;
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)b, (unsigned)t.N), dim3(256), 0, ctx->stream, t.p, (size_t)t.H * t.W, t.C / 4, t.cs, t.co, slots);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;

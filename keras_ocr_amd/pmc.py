@@ -28,6 +28,7 @@ PROF_TO_KERNEL = {
     "conv_w4ht_256x128": "void conv_w43vh_kernel<0, 2, 2",
     "conv_w4qv_256x128": "void conv_w43vh_kernel<0, 1, 1", "conv_w4qv_256x128_pool": "void conv_w43vh_kernel<1, 1, 1",
     "conv_w4qt_256x128": "void conv_w43vh_kernel<0, 2, 1",
+    "conv_w4hf_256x128": "void conv_w43fh_kernel<2", "conv_w4qf_256x128": "void conv_w43fh_kernel<1",
     "conv_w4hr_256x64": "void conv_w43rh_kernel<0, 2", "conv_w4hr_256x64_pool": "void conv_w43rh_kernel<1, 2",
     "conv_w4qr_256x64": "void conv_w43rh_kernel<0, 1", "conv_w4qr_256x64_pool": "void conv_w43rh_kernel<1, 1",
     "conv_w4s_256x64": "void conv_w43r_kernel<0", "conv_w4s_256x64_pool": "void conv_w43r_kernel<1",

@@ -115,8 +115,8 @@ SPLIT_CASES = [
     (1, 40, 64, 48, 96, "conv_ws_128x128"),        # Cin % 32 != 0: F(2,3) kernel, 9 K-steps (odd)
     (1, 30, 50, 512, 130, "conv_ws_128x128"),      # W % 4 != 0: F(2,3), ragged couts, tiles crossing image rows
     # conv_w43.hip (Winograd F(4,3): Cin % 32 == 0, Cout > 64, W % 4 == 0)
-    (1, 30, 52, 512, 130, "conv_w4s_256x128"),     # H % 4 != 0: flattened-pixel tiles, ragged couts, last tile partly outside
-    (2, 17, 36, 64, 128, "conv_w4s_256x128"),      # 12 K-steps, two images, odd height
+    (1, 30, 52, 512, 130, "conv_w4hf_256x128"),     # H % 4 != 0: flattened-pixel tiles, ragged couts, last tile partly outside
+    (2, 17, 36, 64, 128, "conv_w4hf_256x128"),      # 12 K-steps, two images, odd height
     (1, 64, 128, 128, 256, "conv_w4hv_256x128"),   # two cout tiles per pixel tile
     (3, 8, 4, 32, 96, "conv_w4s_256x128"),         # a single quad per row: both column paddings in one quad
     # 32 < Cout <= 64: the 64-cout arrangement of conv_w43.hip (512-pixel tiles, two gather items per thread)
@@ -135,7 +135,9 @@ SPLIT_CASES = [
     (2, 16, 96, 64, 128, "conv_w4ht_256x128"),     # 8 x 32: slice4.34 class geometry (96 wide), two images
     (1, 8, 32, 32, 130, "conv_w4ht_256x128"),      # 8 x 32: a single tile per image (all four paddings), ragged couts
     (3, 24, 160, 96, 96, "conv_w4ht_256x128"),     # 8 x 32: five column blocks, three row octets, three images
-    (1, 6, 128, 32, 130, "conv_w4s_256x128"),      # H % 4 != 0: stays on conv_w43_kernel (flattened-pixel tiles)
+    (1, 6, 128, 32, 130, "conv_w4hf_256x128"),
+    (5, 31, 200, 64, 128, "conv_w4hf_256x128"),    # the recogniser's conv_2: 31 x 200 crops, tiles crossing rows AND crops
+    (7, 15, 100, 256, 130, "conv_w4hf_256x128"),   # conv_5 class: 1500-pixel crops, ragged couts, last tile partly outside      # H % 4 != 0: stays on conv_w43_kernel (flattened-pixel tiles)
     # Cout <= 32 (conv_hsplit.hip: haloed 8x32 tile split once into LDS; needs >= 4096 pixels)
     (1, 64, 64, 32, 32, "conv_hs_256x32"),         # conv_cls.0 / .2 class, tiles exact
     (2, 70, 45, 64, 32, "conv_hs_256x32"),         # upconv4.conv.3 class: 4 chunks, ragged tiles in both directions, two images
@@ -150,7 +152,7 @@ def _expect_family(ctx, rows, family):
     if any(k.startswith("KOCR_") and k not in ("KOCR_SPLIT",) for k in os.environ):
         return
     if ctx.get_split_mode() == 0:
-        family = family.replace("conv_w4hr", "conv_w4s").replace("conv_w4h", "conv_w4")
+        family = family.replace("conv_w4hr", "conv_w4s").replace("conv_w4hf", "conv_w4s").replace("conv_w4h", "conv_w4")
     conv = sorted(k for k in rows if k.startswith("conv"))
     assert conv == [family], f"expected the launch on {family}, profiler rows: {sorted(rows)}"
 

@@ -49,6 +49,11 @@ struct Tensor {
   // of an image from its slot -- per image, so that a result never depends on the rest of the batch; a tensor without
   // slots is reduced on demand (launch_absmax).  Slices / views share the buffer's slots.
   unsigned* amax = nullptr;
+  // Valid width (0 = W): columns [Wv, W) of every row are ZERO padding that belongs to the tensor -- its producer writes
+  // zeros there, a convolution reading it sees exactly the 'same' padding it would see at the image edge.  Lets a tensor
+  // whose width is not a multiple of 4 (the recogniser's 50-wide conv_6 / conv_7) run on the F(4,3) kernels at width 52.
+  int Wv = 0;
+  int wv() const { return Wv ? Wv : W; }
   size_t pixels() const { return (size_t)N * H * W; }
   Tensor slice(int off, int c) const {
     Tensor t = *this;

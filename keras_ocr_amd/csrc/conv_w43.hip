@@ -1785,6 +1785,8 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
   p.amax_out = p.amax_pool = nullptr;  // set below for the arrangements that maintain the per-image slots themselves
   p.amax_in = nullptr;
+  p.Wv = (out.Wv && out.Wv < out.W) ? out.Wv : 0;
+  w4_div_magic((unsigned)in.W, p.dv_w);
   if (fuse) {
     p.pool_out = pool->p;
     p.pool_cs = pool->cs;
@@ -1829,6 +1831,8 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   const bool flat_h = pieces && !no_h && L.d_w4h && !narrow && !vreuse && !rowreuse && L.dil == 1 && !fuse &&
                       (size_t)in.H * in.W >= 256;
   const bool use_h = (pieces && !no_h && L.d_w4h && (vreuse || (rowreuse && rgeo == 1))) || flat_h;
+  if (p.Wv && !flat_h)  // only the flattened fp16 kernel writes the zero columns of a width-padded output
+    KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": a width-padded output (Tensor::Wv) needs the flattened fp16 F(4,3) kernel");
   const bool tracks = rowreuse || vreuse || flat_h;
   if (tracks) {
     p.amax_out = (!fuse || need_full) ? out.amax : nullptr;

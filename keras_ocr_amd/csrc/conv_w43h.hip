@@ -1116,6 +1116,14 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
             o2 = o2 * qa + qb_;
             o3 = o3 * qa + qb_;
           }
+          if (p.Wv) {  // width-padded output (Tensor::Wv): the columns behind the valid width are zero padding
+            const unsigned pq = (unsigned)(pm0 + 4 * q);
+            const int x0 = (int)(pq - w4_fdiv(pq, p.dv_w) * (unsigned)p.W);
+            o0 = x0 < p.Wv ? o0 : 0.f;
+            o1 = x0 + 1 < p.Wv ? o1 : 0.f;
+            o2 = x0 + 2 < p.Wv ? o2 : 0.f;
+            o3 = x0 + 3 < p.Wv ? o3 : 0.f;
+          }
           acc[0][m][r] = o0;
           acc[1][m][r] = o1;
           acc[2][m][r] = o2;

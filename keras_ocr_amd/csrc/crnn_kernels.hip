@@ -28,8 +28,9 @@ __global__ void crnn_input_kernel(const float* __restrict__ in, float* __restric
 
 // in: [M][Hn][Wn][C] (natural crop orientation) -> out: [M][Wn][Hn][C] with out[m][w][j] = in[m][Hn-1-j][w]
 // (the Permute((2,1,3)) + flip of recognition.py:215-216 applied after the conv stack instead of before)
+// Wp = width pitch of `in` in pixels (>= Wn: a width-padded tensor, Tensor::Wv)
 __global__ void crnn_to_keras_kernel(const float* __restrict__ in, float* __restrict__ out, int M, int Hn, int Wn,
-                                     int C4) {
+                                     int C4, int Wp) {
   const size_t total = (size_t)M * Hn * Wn * C4;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c4 = i % C4;
@@ -39,7 +40,7 @@ __global__ void crnn_to_keras_kernel(const float* __restrict__ in, float* __rest
     const int w = t % Wn;
     const size_t m = t / Wn;
     reinterpret_cast<float4*>(out)[i] =
-        reinterpret_cast<const float4*>(in)[((m * Hn + (Hn - 1 - j)) * Wn + w) * C4 + c4];
+        reinterpret_cast<const float4*>(in)[((m * Hn + (Hn - 1 - j)) * Wp + w) * C4 + c4];
   }
 }
 
@@ -261,15 +262,15 @@ int launch_crnn_input(kocr_ctx* ctx, const float* d_crops, float* d_x, int M, in
 }
 
 int launch_crnn_to_keras(kocr_ctx* ctx, const Tensor& in, const Tensor& out) {
-  if (in.C % 4 || in.cs != in.C || out.cs != out.C || out.H != in.W || out.W != in.H || out.C != in.C)
+  if (in.C % 4 || in.cs != in.C || out.cs != out.C || out.H != in.wv() || out.W != in.H || out.C != in.C)
     KOCR_FAIL(ctx, KOCR_EINVAL, "crnn_to_keras: bad shapes");
-  const size_t total = in.pixels() * (in.C / 4);
+  const size_t total = out.pixels() * (in.C / 4);
   if (!total) return KOCR_OK;
   ProfScope ps(ctx, "crnn_to_keras", 0, 8.0 * in.pixels() * in.C);
   size_t b = (total + 255) / 256;
   if (b > 8192) b = 8192;
-  hipLaunchKernelGGL(crnn_to_keras_kernel, dim3((unsigned)b), dim3(256), 0, ctx->stream, in.p, out.p, in.N, in.H, in.W,
-                     in.C / 4);
+  hipLaunchKernelGGL(crnn_to_keras_kernel, dim3((unsigned)b), dim3(256), 0, ctx->stream, in.p, out.p, in.N, in.H, in.wv(),
+                     in.C / 4, in.W);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }

@@ -15,6 +15,7 @@ struct EwParams {
   int in_cs, in_co, out_cs, out_co;
   float sy, sx;
   int row_off;  // maxpool2x2: first input row of output row 0 (0, or 1 for the flipped CRNN layout)
+  int Wov;      // maxpool2x2: valid output width (Tensor::Wv): output columns [Wov, Wo) are written as zeros
 };
 
 __global__ void maxpool2x2_kernel(EwParams p) {
@@ -27,6 +28,11 @@ __global__ void maxpool2x2_kernel(EwParams p) {
     t /= p.Wo;
     const int oy = t % p.Ho;
     const int n = t / p.Ho;
+    const size_t o = (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.out_cs + p.out_co + c4 * 4;
+    if (ox >= p.Wov) {  // zero padding columns of a width-padded output
+      *reinterpret_cast<float4*>(p.out + o) = float4{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
     const size_t base = (((size_t)n * p.Hi + 2 * oy + p.row_off) * p.Wi + 2 * ox) * p.in_cs + p.in_co + c4 * 4;
     const float4 a = *reinterpret_cast<const float4*>(p.in + base);
     const float4 b = *reinterpret_cast<const float4*>(p.in + base + p.in_cs);
@@ -37,7 +43,6 @@ __global__ void maxpool2x2_kernel(EwParams p) {
     r.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
     r.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z));
     r.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
-    const size_t o = (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.out_cs + p.out_co + c4 * 4;
     *reinterpret_cast<float4*>(p.out + o) = r;
   }
 }
@@ -154,6 +159,7 @@ static EwParams make_params(const Tensor& in, const Tensor& out) {
   p.out_co = out.co;
   p.sy = p.sx = 1.f;
   p.row_off = 0;
+  p.Wov = out.W;
   return p;
 }
 
@@ -166,9 +172,10 @@ static dim3 ew_grid(size_t total) {
 
 int launch_maxpool2x2(kocr_ctx* ctx, const Tensor& in, const Tensor& out, int row_off) {
   KOCR_TRY(check_vec(ctx, in, out, "maxpool2x2"));
-  if (out.H != (in.H - row_off) / 2 || out.W != in.W / 2) KOCR_FAIL(ctx, KOCR_EINVAL, "maxpool2x2: bad output size");
+  if (out.H != (in.H - row_off) / 2 || out.wv() != in.wv() / 2) KOCR_FAIL(ctx, KOCR_EINVAL, "maxpool2x2: bad output size");
   EwParams p = make_params(in, out);
   p.row_off = row_off;
+  p.Wov = out.wv();
   const size_t total = out.pixels() * p.C4;
   if (!total) return KOCR_OK;
   {

@@ -38,6 +38,8 @@ struct W4Params {
   unsigned dv_nb[2];   // by the number of cout blocks
   unsigned dv_hw[2];   // by H * W (pixel index -> image, for the per-image max-|x| slots)
   const unsigned* amax_in;  // fp16 kernels: per-image max-|x| slots of the INPUT (Tensor::amax[n]), never null there
+  int Wv;              // conv_w43fh_kernel: valid output width (Tensor::Wv): columns >= Wv are written as zeros; 0 = all valid
+  unsigned dv_w[2];    // by W
 };
 
 // host: multiplier / shift of the division by d (1 <= d < 2^31)

@@ -211,3 +211,91 @@ def test_winograd_f43_split_error_is_inside_the_conv_test_bound():
         res[name] = (float(r.max()), float(np.sqrt((r ** 2).mean())))
     assert res["kernel"][0] <= 1e-6 and res["kernel"][1] <= 1.5e-7
     assert res["kernel"][1] < res["textbook"][1]
+
+
+# ---------------------------------------------------------------------------------------------------
+# csrc/conv_w43h.hip: F(4,3) in fp16 arithmetic (round 4) -- per-image input scale, per-cout weight scale
+# ---------------------------------------------------------------------------------------------------
+W4H_TOP = 12  # conv_w43h.hip: scaled inputs lie below 2^13
+
+
+def w4h_scale_exp(amax):
+    """kocr_scale_exp(slot, W4H_TOP): e = 12 - exponent(max |x| of the image), clamped to [-100, 100]; 0 for an all-zero image."""
+    b = np.float32(amax).view(np.uint32)
+    if b == 0:
+        return 0
+    return max(-100, min(100, W4H_TOP - (int(b >> 23) - 127)))
+
+
+def w4h_weight_exp(u_of_cout):
+    """prepare_w43h: per output channel, max |U 2^wexp| over the channel's transformed weights lies in [2^14, 2^15)."""
+    umax = float(np.abs(u_of_cout).max())
+    if umax == 0:
+        return 0
+    return 15 - int(np.frexp(np.float32(umax))[1])
+
+
+def _w43h_conv_rows(x, w, pieces):
+    """One output row of a 3x3 convolution through F(4,3) as conv_w43h.hip evaluates it: inputs scaled by 2^e, weights by
+    2^wexp[o], both split into fp16 pieces (round to nearest), products a_l b_h + a_h b_l + a_h b_h (pieces = 2) or a_h b_h
+    (pieces = 1) per 16-channel K-step with fp32 accumulation, the scales undone after the output transform."""
+    W, cin, cout = x.shape[1] - 2, x.shape[2], w.shape[3]
+    nq = W // 4
+    e = w4h_scale_exp(np.abs(x).max())
+    Uall = w43_weight_transform(np.moveaxis(w.astype(np.float64), 1, -1))           # (3, cin, cout, 6)
+    wexp = np.array([w4h_weight_exp(Uall[:, :, o, :]) for o in range(cout)])
+    acc = np.zeros((6, nq, cout), np.float32)
+    for c0 in range(0, cin, 16):
+        for ky in range(3):
+            U = np.moveaxis(Uall[ky, c0:c0 + 16], -1, 0)                              # (6, 16, cout)
+            Us = (U.astype(np.float32) * np.float32(2.0) ** wexp).astype(np.float32)  # exact: powers of two
+            d = np.stack([x[ky, 4 * q:4 * q + 6, c0:c0 + 16] for q in range(nq)]) * np.float32(2.0) ** e
+            V = np.moveaxis(w43_input_transform(np.moveaxis(d, 1, -1)), -1, 0)        # (6, nq, 16); the kernel folds 2^e into
+            assert float(np.abs(V).max()) < 65504                                     # the constants: same value, exactly
+            for xi in range(6):
+                ah, al = f16_split2(V[xi])
+                bh, bl = f16_split2(Us[xi])
+                prods = ((al, bh), (ah, bl), (ah, bh)) if pieces == 2 else ((ah, bh),)
+                for pq, qq in prods:
+                    acc[xi] = (acc[xi] + pq.astype(np.float64) @ qq.astype(np.float64)).astype(np.float32)
+    out = w43_output_transform(np.moveaxis(acc, 0, -1))                               # (nq, cout, 4)
+    out = out * (np.float32(2.0) ** -(e + wexp))[None, :, None]
+    return out.transpose(0, 2, 1).reshape(W, cout)
+
+
+def test_winograd_f43_fp16_modes_error_classes():
+    """fp16x2 (KOCR_SPLIT_F16X2): inside the bound the GPU tests hold the kernels to (1e-6 max / 1.5e-7 rms of |x| conv |w|)
+    and no worse than the bf16x3 F(4,3) arithmetic; one fp16 piece (KOCR_SPLIT_F16X1, the reduced-precision fast mode):
+    inside ITS stated tolerance (1e-3 max / 1e-4 rms) and ~1000x above the fp32-class modes."""
+    rng = np.random.default_rng(7)
+    cin, cout, W = 128, 40, 64
+    x = (np.maximum(rng.standard_normal((3, W + 2, cin)), 0) * 37.0).astype(np.float32)   # max |x| far from a power of two
+    x[:, 0] = x[:, -1] = 0
+    w = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    w[..., ::5] *= 1e-3                                                                    # channels of very different scale
+    truth = sum(x[ky, kx:kx + W].astype(np.float64) @ w[ky, kx].astype(np.float64) for ky in range(3) for kx in range(3))
+    bound = sum(np.abs(x[ky, kx:kx + W].astype(np.float64)) @ np.abs(w[ky, kx].astype(np.float64)) for ky in range(3) for kx in range(3))
+    r_bf = np.abs(_w43_conv_rows(x, w, W4_A, W4_B) - truth) / bound
+    r_h2 = np.abs(_w43h_conv_rows(x, w, 2) - truth) / bound
+    r_h1 = np.abs(_w43h_conv_rows(x, w, 1) - truth) / bound
+    assert r_h2.max() <= 1e-6 and np.sqrt((r_h2 ** 2).mean()) <= 1.5e-7
+    assert r_h2.max() <= 1.5 * r_bf.max()
+    assert 5e-6 < r_h1.max() <= 1e-3 and np.sqrt((r_h1 ** 2).mean()) <= 1e-4
+
+
+def test_fp16_scales_keep_every_operand_inside_fp16():
+    """The F(4,3) input transform grows a value by at most 5.28 (row sums of |B^T| with the points 0, +-5/8, +-3/2, inf), so
+    inputs below 2^13 stay below 43 300 < 65 504; the per-cout weight exponent puts the channel's largest |U| in [2^14, 2^15)."""
+    a, b = W4_A, W4_B
+    rows = [a * a * b * b + (a * a + b * b) + 1, 1 + b * b + a * (1 + b * b), 1 + a * a + b * (1 + a * a)]
+    assert max(rows) < 5.29 and max(rows) * 2.0 ** 13 < 65504
+    for amax in (1e-30, 3e-7, 0.999, 1.0, 37.0, 65504.0, 3e20):
+        e = w4h_scale_exp(amax)
+        assert float(np.float32(amax)) * 2.0 ** e < 2.0 ** 13 and (e in (-100, 100) or float(np.float32(amax)) * 2.0 ** e >= 2.0 ** 12)
+    assert w4h_scale_exp(0.0) == 0
+    rng = np.random.default_rng(8)
+    for scale in (1e-12, 1.0, 1e9):
+        u = rng.standard_normal(200) * scale
+        k = w4h_weight_exp(u)
+        top = float(np.abs(u).max()) * 2.0 ** k
+        assert 2.0 ** 14 <= top < 2.0 ** 15

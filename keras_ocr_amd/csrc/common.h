@@ -91,8 +91,11 @@ struct ConvLayer {
   unsigned short* d_ds = nullptr;  // direct-conv weights, 3-way bf16 split, conv_dsplit.hip order
   int ds_cout_pad = 0;
   unsigned short* d_first = nullptr;  // 3 -> <= 64 first layer on raw uint8, im2col K = 27 -> 32, conv_hsplit.hip order
+  float first_bound = 0.f;            // ... an upper bound of |output| over every uint8 image (prepare_conv)
   unsigned short* d_hs = nullptr;  // 3x3, <= 32 couts: 3-way bf16 split, conv_hsplit.hip order
   unsigned short* d_hs16 = nullptr;  // the same for <= 16 couts: tap pairs on the 16x16x32 MFMA (conv_hs16_kernel)
+  unsigned short* d_hsh = nullptr;   // conv_hsh_kernel: the <= 32-cout weights scaled per cout and split into two fp16 pieces
+  std::vector<int> hs_wexp;          // ... their exponents (d_pre_a_h = pre_a 2^-wexp is uploaded by prepare_conv)
   unsigned short* d_k5 = nullptr;  // 5x5, 16 couts, small images: 3-way bf16 split, conv_k5.hip order
   bool tap_inner = false;  // K order [16-channel group][tap][16] (Cin % 16 == 0) instead of [tap][Cin]
   bool ready() const { return d_w != nullptr; }

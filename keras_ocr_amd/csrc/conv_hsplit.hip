@@ -17,6 +17,7 @@
 //   48 KB of LDS and 164 registers let three blocks share a CU, which is what hides the barriers.
 #include "split_common.h"
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 
 struct HsParams {
@@ -32,6 +33,7 @@ struct HsParams {
   int relu;
   int tiles_x, tiles_y;
   unsigned* amax_out;
+  const unsigned* amax_in;  // conv_hsh_kernel: per-image max-|x| slots of the input (Tensor::amax), never null there
 };
 
 namespace {
@@ -335,6 +337,140 @@ __global__ __launch_bounds__(256, 3) void conv_hs16_kernel(HsParams p) {
 }
 
 // ===================================================================================================
+// conv_hsh_kernel -- conv_hs_kernel in fp16 arithmetic (round 4; KOCR_SPLIT_F16X2 / F16X1): the haloed tile is scaled by the
+// image's exact power of two 2^e (e = 14 - exponent of the image's tracked max |x|: no transform here, so |x 2^e| < 2^15)
+// and split ONCE into two fp16 planes (round to nearest), the weights are stored scaled per output channel and split the
+// same way; per (chunk, tap) 4 ds_read_b128 + 2 weight loads + 6 v_mfma_f32_32x32x16_f16 (a_l b_h, a_h b_l, a_h b_h)
+// instead of 6 + 3 + 12; 32 KB of LDS, four blocks per CU.  Same error class as the bf16x3 kernel (tests/test_conv_gpu.py).
+// ===================================================================================================
+__global__ __launch_bounds__(256, 4) void conv_hsh_kernel(HsParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[2 * HS_PLANE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, l5 = lane >> 5;
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x;
+  t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int n = t / p.tiles_y;
+  const int y0 = ty * HS_TH, x0 = tx * HS_TW;
+  constexpr unsigned OOB = 0x80000000u;
+  const int e = __builtin_amdgcn_readfirstlane(kocr_scale_exp(p.amax_in + n, 14));
+  const float sc = kocr_pow2(e);
+
+  const float* img = p.in + (size_t)n * p.H * p.W * p.in_cs + p.in_co;
+  const unsigned long long ib = (unsigned long long)img;
+  const unsigned long long ibu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ib >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)ib);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ibu, 0, 0x80000000, 0x00020000);
+
+  unsigned goff[HS_IPT];
+  int ldst[HS_IPT];
+#pragma unroll
+  for (int it = 0; it < HS_IPT; ++it) {
+    const int item = tid + it * 256;
+    const int px = item >> 2, c4 = item & 3;
+    const int hy = px / HS_HW, hx = px - hy * HS_HW;
+    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+    const bool ok = px < HS_NPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    goff[it] = ok ? (unsigned)(((gy * p.W + gx) * p.in_cs + c4 * 4) * 4) : OOB;
+    ldst[it] = px < HS_NPX ? px * HS_PS + c4 * 4 : -1;
+  }
+  auto load_raw = [&](v4f (&raw)[HS_IPT], int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < HS_IPT; ++it)
+      raw[it] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[it], chunk * 64, 0));
+  };
+  auto produce = [&](const v4f (&raw)[HS_IPT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < HS_IPT; ++it) {
+      u2v h, l;
+      kocr_split4_h(raw[it] * sc, h, l);  // exact scaling
+      if (it + 1 < HS_IPT || ldst[it] >= 0) {
+        unsigned short* dst = As + ldst[it];
+        *reinterpret_cast<u2v*>(dst) = h;
+        *reinterpret_cast<u2v*>(dst + HS_PLANE) = l;
+      }
+    }
+  };
+
+  f16v acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  const int a_lane = ((2 * wave) * HS_HW + l31) * HS_PS + l5 * 8;
+  const unsigned short* w_lane = p.wgt + lane * 8;  // [Cin/16][9 taps][2 pieces][64 lanes][8] fp16
+  const int nchunks = p.Cin >> 4;
+
+  v4f raw[HS_IPT];
+  load_raw(raw, 0);
+  produce(raw);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) load_raw(raw, c + 1);
+    const unsigned short* wc = w_lane + (size_t)c * 9 * 2 * 512;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      hf8 b[2], a[2][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) b[s] = *reinterpret_cast<const hf8*>(wc + (tap * 2 + s) * 512);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          a[m][s] = *reinterpret_cast<const hf8*>(As + s * HS_PLANE + a_lane + ((m + ky) * HS_HW + kx) * HS_PS);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][1], b[0], acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], b[1], acc[m], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], b[0], acc[m], 0, 0, 0);
+    }
+    if (c + 1 < nchunks) {
+      __syncthreads();  // every wave has read this chunk
+      produce(raw);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (conv_hs_kernel's; pre_a carries 2^-wexp[o], the input scale is undone here) -----------------------------
+  const int nc = l31 < p.Cout ? l31 : p.Cout - 1;
+  const float pa = p.pre_a[nc] * kocr_pow2(-e), pb = p.pre_b[nc];
+  const bool has_post = p.post_a != nullptr;
+  const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float o = acc[m][r] * pa + pb;
+      if (p.relu) o = fmaxf(o, 0.f);
+      if (has_post) o = o * qa + qb;
+      acc[m][r] = o;
+    }
+  float* oimg = p.out + (size_t)n * p.H * p.W * p.out_cs + p.out_co;
+  const unsigned long long ob = (unsigned long long)oimg;
+  const unsigned long long obu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ob >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)ob);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)obu, 0, 0x80000000, 0x00020000);
+  float mxv = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int y = y0 + 2 * wave + m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * l5;
+      const bool ok = y < p.H && x < p.W && l31 < p.Cout;
+      const unsigned vo = ok ? (unsigned)(((y * p.W + x) * p.out_cs + l31) * 4) : OOB;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][r]), ro, vo, 0, 0);
+      if (ok) mxv = fmaxf(mxv, fabsf(acc[m][r]));
+    }
+  }
+  if (p.amax_out) kocr_amax_update(p.amax_out + n, mxv);
+}
+
+// ===================================================================================================
 // conv_first_kernel -- CRAFT's first layer (basenet.slice1.0, detection.py:312-322: 3x3, 3 -> 64, BN, ReLU) straight from
 // the uint8 image, on the same bf16x3 split arithmetic.  K = 27 (tap, channel) values per output pixel, padded to 32 =
 // two 16-k MFMA steps: the fp32-MFMA kernel that ran it before spent 48 padded K per pixel on the slow pipe (43 % busy,
@@ -542,6 +678,39 @@ int prepare_hsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) 
   KOCR_TRY(ctx->dev_alloc(&d, u.size() * sizeof(unsigned short)));
   KOCR_HIP(ctx, hipMemcpy(d, u.data(), u.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
   L.d_hs = (unsigned short*)d;
+  {  // conv_hsh_kernel: w 2^wexp[o] in two fp16 pieces, [Cin/16][9 taps][2 pieces][64 lanes][8]; d_pre_a_h = pre_a 2^-wexp
+     // (the field the F(4,3) fp16 kernels use for layers with more than 32 couts: a layer has one or the other)
+    std::vector<int> wexp(32, 0);
+    for (int o = 0; o < Cout; ++o) {
+      float wmax = 0.f;
+      for (int c = 0; c < Cin; ++c)
+        for (int tap = 0; tap < 9; ++tap)
+          wmax = std::max(wmax, std::fabs(w_is_oihw ? w[((size_t)o * Cin + c) * 9 + tap] : w[((size_t)tap * Cin + c) * Cout + o]));
+      if (wmax > 0.f && std::isfinite(wmax)) {
+        int E;
+        std::frexp(wmax, &E);
+        wexp[o] = std::max(-100, std::min(100, 15 - E));
+      }
+    }
+    std::vector<unsigned short> v((size_t)(Cin / 16) * 9 * 2 * 512, 0);
+    for (int c = 0; c < Cin; ++c)
+      for (int tap = 0; tap < 9; ++tap)
+        for (int o = 0; o < Cout; ++o) {
+          const float g = std::ldexp(w_is_oihw ? w[((size_t)o * Cin + c) * 9 + tap] : w[((size_t)tap * Cin + c) * Cout + o], wexp[o]);
+          const int k = c % 16, lane = (k >> 3) * 32 + o, j = k & 7;
+          const _Float16 h = (_Float16)g, l = (_Float16)(g - (float)h);
+          unsigned short hb, lb;
+          memcpy(&hb, &h, 2);
+          memcpy(&lb, &l, 2);
+          v[((((size_t)(c / 16) * 9 + tap) * 2 + 0) * 64 + lane) * 8 + j] = hb;
+          v[((((size_t)(c / 16) * 9 + tap) * 2 + 1) * 64 + lane) * 8 + j] = lb;
+        }
+    void* dh = nullptr;
+    KOCR_TRY(ctx->dev_alloc(&dh, v.size() * sizeof(unsigned short)));
+    KOCR_HIP(ctx, hipMemcpy(dh, v.data(), v.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    L.d_hsh = (unsigned short*)dh;
+    L.hs_wexp.assign(wexp.begin(), wexp.end());
+  }
   if (Cout <= 16) {  // conv_hs16_kernel: [Cin/16][5 tap pairs][3 pieces][64 lanes][8]
     std::vector<unsigned short> v((size_t)(Cin / 16) * 5 * 3 * 512, 0);
     for (int c = 0; c < Cin; ++c)
@@ -591,15 +760,30 @@ int launch_conv_hsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   p.tiles_x = (in.W + HS_TW - 1) / HS_TW;
   p.tiles_y = (in.H + HS_TH - 1) / HS_TH;
   p.amax_out = out.amax;
+  p.amax_in = nullptr;
   const size_t M = in.pixels();
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   const bool no16 = !ctx->sw.hs16;
   const bool use16 = L.d_hs16 && !no16;  // <= 16 couts: the 16-wide product tile
+  // fp16 arithmetic (conv_hsh_kernel) in the fp16 modes, for the 32-wide product tile
+  const bool half = !use16 && ctx->split_mode != KOCR_SPLIT_BF16X3 && ctx->sw.w43h && L.d_hsh && L.d_pre_a_h;
+  if (half) {
+    const unsigned* slots = in.amax;
+    if (!slots) {
+      unsigned* tmp = ctx->amax_slots(in.N);
+      if (!tmp) KOCR_FAIL(ctx, KOCR_ECAPACITY, "conv " + L.name + ": out of max-|x| slots");
+      KOCR_TRY(launch_absmax(ctx, in, tmp));
+      slots = tmp;
+    }
+    p.amax_in = slots;
+    p.wgt = L.d_hsh;
+    p.pre_a = L.d_pre_a_h;
+  }
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_hs_256x%d:%s", use16 ? 16 : 32, L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_h%s_256x%d:%s", half ? "h" : "s", use16 ? 16 : 32, L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_hs_256x%d", use16 ? 16 : 32);
+    snprintf(nm, sizeof nm, "conv_h%s_256x%d", half ? "h" : "s", use16 ? 16 : 32);
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   ProfScope ps(ctx, nm, flops, bytes);
@@ -607,7 +791,9 @@ int launch_conv_hsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   if (use16) {
     p.wgt = L.d_hs16;
     hipLaunchKernelGGL(conv_hs16_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, p);
-  } else
+  } else if (half)
+    hipLaunchKernelGGL(conv_hsh_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, p);
+  else
     hipLaunchKernelGGL(conv_hs_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
@@ -659,7 +845,18 @@ int launch_conv_first(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const
   p.relu = L.relu;
   p.tiles_x = (in.W + HS_TW - 1) / HS_TW;
   p.tiles_y = (in.H + HS_TH - 1) / HS_TH;
-  p.amax_out = out.amax;
+  // per-image max-|x| slots of the output: the layer's constant bound (ConvLayer::first_bound) when it is known -- no
+  // reduction in the kernel --, else tracked by the kernel
+  p.amax_out = nullptr;
+  if (out.amax) {
+    if (L.first_bound > 0.f && std::isfinite(L.first_bound)) {
+      unsigned bits;
+      memcpy(&bits, &L.first_bound, 4);
+      KOCR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)out.amax, (int)bits, (size_t)in.N, ctx->stream));
+    } else {
+      p.amax_out = out.amax;
+    }
+  }
   const size_t M = in.pixels();
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
   const double bytes = (double)M * 3 + 4.0 * ((double)M * L.Cout + (double)L.Kreal * L.Cout);

@@ -473,13 +473,13 @@ int craft_run(kocr_ctx* ctx, CraftNet* net, const void* d_img, int dtype, int N,
   KOCR_TRY(mk(d.H4, d.W4, 64, &u3b));
   RUN(launch_conv(ctx, L("upconv3.conv.3"), u3a, nullptr, nullptr, u3b));
   done(u3a);
-  KOCR_TRY(mk(d.H2, d.W2, 64, &u4a));
+  KOCR_TRY(mk(d.H2, d.W2, 64, &u4a, true));
   KOCR_TRY(up_conv("upconv4.conv.0", u3b, cat4, u4a));
-  KOCR_TRY(mk(d.H2, d.W2, 32, &feat));
+  KOCR_TRY(mk(d.H2, d.W2, 32, &feat, true));
   RUN(launch_conv(ctx, L("upconv4.conv.3"), u4a, nullptr, nullptr, feat));
   done(u4a);
   // ---- head (detection.py:392-410), linear output ---------------------------------------
-  KOCR_TRY(mk(d.H2, d.W2, 32, &k0));
+  KOCR_TRY(mk(d.H2, d.W2, 32, &k0, true));
   RUN(launch_conv(ctx, L("conv_cls.0"), feat, nullptr, nullptr, k0));
   done(feat);
   KOCR_TRY(mk(d.H2, d.W2, 32, &k1));

@@ -15,6 +15,7 @@ _FAMILIES = [
     ("conv_w4t", "bf16", 0.5 * 6.0, "1/2 (Winograd F(4,3): 6 multiplies per 4 outputs x 3 taps) x 6 bf16x3 split products"),
     ("conv_ws", "bf16", 2.0 / 3.0 * 6.0, "2/3 (Winograd F(2,3)) x 6 bf16x3 split products"),
     ("conv_ds", "bf16", 6.0, "6 bf16x3 split products (direct 1x1 / dilated convolution)"),
+    ("conv_hh", "fp16", 3.0, "3 fp16x2 split products (direct 3x3 convolution, <= 32 output channels)"),
     ("conv_hs_256x16", "bf16", 6.0 * 10.0 / 9.0, "6 bf16x3 split products x 10/9 (3x3 taps issued in 5 pairs; <= 16 output channels)"),
     ("conv_hs", "bf16", 6.0, "6 bf16x3 split products (direct 3x3 convolution, <= 32 output channels)"),
     ("conv_k5", "bf16", 6.0 * 26.0 / 25.0, "6 bf16x3 split products x 26/25 (5x5 taps issued in 13 pairs; 16 output channels, small images)"),

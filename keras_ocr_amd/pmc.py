@@ -37,7 +37,7 @@ PROF_TO_KERNEL = {
     "conv_ds_256x128": "void conv_ds_kernel<1, 4, 0, 0", "conv_ds_512x64": "void conv_ds_kernel<2, 2, 0, 0",
     # exact 2x up-sampling (every CRAFT shape); the generic-ratio variant <..., 1> shares the profiler row
     "conv_ds_256x128_up": "void conv_ds_kernel<1, 4, 0, 2", "conv_ds_512x64_up": "void conv_ds_kernel<2, 2, 0, 2",
-    "conv_hs_256x32": "conv_hs_kernel", "conv_hs_256x16": "conv_hs16_kernel", "conv_hs_first_256x64": "conv_first_kernel", "conv_k5_352x16": "conv_k5_kernel",
+    "conv_hh_256x32": "conv_hsh_kernel", "conv_hs_256x32": "conv_hs_kernel", "conv_hs_256x16": "conv_hs16_kernel", "conv_hs_first_256x64": "conv_first_kernel", "conv_k5_352x16": "conv_k5_kernel",
 }
 
 

@@ -139,8 +139,8 @@ SPLIT_CASES = [
     (5, 31, 200, 64, 128, "conv_w4hf_256x128"),    # the recogniser's conv_2: 31 x 200 crops, tiles crossing rows AND crops
     (7, 15, 100, 256, 130, "conv_w4hf_256x128"),   # conv_5 class: 1500-pixel crops, ragged couts, last tile partly outside      # H % 4 != 0: stays on conv_w43_kernel (flattened-pixel tiles)
     # Cout <= 32 (conv_hsplit.hip: haloed 8x32 tile split once into LDS; needs >= 4096 pixels)
-    (1, 64, 64, 32, 32, "conv_hs_256x32"),         # conv_cls.0 / .2 class, tiles exact
-    (2, 70, 45, 64, 32, "conv_hs_256x32"),         # upconv4.conv.3 class: 4 chunks, ragged tiles in both directions, two images
+    (1, 64, 64, 32, 32, "conv_hh_256x32"),         # conv_cls.0 / .2 class, tiles exact
+    (2, 70, 45, 64, 32, "conv_hh_256x32"),         # upconv4.conv.3 class: 4 chunks, ragged tiles in both directions, two images
     (1, 67, 100, 32, 16, "conv_hs_256x16"),        # conv_cls.4 class: the 16-wide product tile
     (1, 130, 33, 16, 7, "conv_hs_256x16"),         # one chunk, a single used column in the second tile column
 ]
@@ -152,7 +152,7 @@ def _expect_family(ctx, rows, family):
     if any(k.startswith("KOCR_") and k not in ("KOCR_SPLIT",) for k in os.environ):
         return
     if ctx.get_split_mode() == 0:
-        family = family.replace("conv_w4hr", "conv_w4s").replace("conv_w4hf", "conv_w4s").replace("conv_w4h", "conv_w4")
+        family = family.replace("conv_w4hr", "conv_w4s").replace("conv_w4hf", "conv_w4s").replace("conv_w4h", "conv_w4").replace("conv_hh", "conv_hs")
     conv = sorted(k for k in rows if k.startswith("conv"))
     assert conv == [family], f"expected the launch on {family}, profiler rows: {sorted(rows)}"
 

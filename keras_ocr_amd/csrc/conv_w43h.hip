@@ -47,14 +47,6 @@ __device__ __forceinline__ T w4h_transform(const T (&d)[6], int xi, float k_s, f
   }
 }
 
-// two-way fp16 split of two values (one dword per piece)
-__device__ __forceinline__ void kocr_split2_h(const v2f v, unsigned& h, unsigned& l) {
-  const _Float16 h0 = (_Float16)v[0], h1 = (_Float16)v[1];
-  const _Float16 l0 = (_Float16)(v[0] - (float)h0), l1 = (_Float16)(v[1] - (float)h1);
-  h = __builtin_bit_cast(unsigned, hf2{h0, h1});
-  l = __builtin_bit_cast(unsigned, hf2{l0, l1});
-}
-
 constexpr int W4H_TOP = 12;  // scaled inputs lie below 2^13: 5.28 x 2^13 < 65 504
 
 }  // namespace

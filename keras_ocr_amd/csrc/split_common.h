@@ -10,6 +10,7 @@ typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // blockIdx -> tile: workgroups are dealt round-robin to the 8 XCDs (each with a private L2); this bijection gives
 // every XCD a CONTIGUOUS range of tiles so that neighbouring tiles share one L2.
@@ -39,7 +40,6 @@ __device__ __forceinline__ void kocr_split4(const v4f v, u2v& h, u2v& m, u2v& l)
 }
 
 // the same for two values: one dword (2 bf16) per piece
-typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void kocr_split2(const v2f v, unsigned& h, unsigned& m, unsigned& l) {
   unsigned uh[2], um[2], ul[2];
 #pragma unroll
@@ -56,15 +56,30 @@ __device__ __forceinline__ void kocr_split2(const v2f v, unsigned& h, unsigned& 
 
 // fp16 mode: 2-way RNE fp16 split of four values, v ~ h + l with |v - h - l| <= 2^-22 |v| (2^-24 rms) while l is a
 // normal fp16 (the caller scales the tensor by an exact power of two so that max |v| ~ 2^14)
+// v - float(h) for the fp16 value in the low / high half of `hh`, as ONE mixed-precision fma (v_fma_mix_f32: the f16 source is
+// widened inside the instruction; the result is exact, h being v rounded to 11 bits) instead of a conversion plus a
+// subtraction -- hipcc canonicalises fma(float(h), -1, v) back into the two-instruction form, hence the inline assembly
+__device__ __forceinline__ float kocr_resid_lo(unsigned hh, float v) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(v));
+  return r;
+}
+__device__ __forceinline__ float kocr_resid_hi(unsigned hh, float v) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(v));
+  return r;
+}
+__device__ __forceinline__ void kocr_split2_h(const v2f v, unsigned& h, unsigned& l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, hf2));  // v_cvt_pk_f16_f32, round to nearest
+  const v2f r = {kocr_resid_lo(h, v[0]), kocr_resid_hi(h, v[1])};
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, hf2));
+}
 __device__ __forceinline__ void kocr_split4_h(const v4f v, u2v& h, u2v& l) {
-  _Float16 hh[4], ll[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    hh[c] = (_Float16)v[c];
-    ll[c] = (_Float16)(v[c] - (float)hh[c]);
-  }
-  h = u2v{__builtin_bit_cast(unsigned, hf2{hh[0], hh[1]}), __builtin_bit_cast(unsigned, hf2{hh[2], hh[3]})};
-  l = u2v{__builtin_bit_cast(unsigned, hf2{ll[0], ll[1]}), __builtin_bit_cast(unsigned, hf2{ll[2], ll[3]})};
+  unsigned h0, l0, h1, l1;
+  kocr_split2_h(v2f{v[0], v[1]}, h0, l0);
+  kocr_split2_h(v2f{v[2], v[3]}, h1, l1);
+  h = u2v{h0, h1};
+  l = u2v{l0, l1};
 }
 
 // exponent e of the exact input scale 2^e: with E = exponent of the tracked max |x| (Tensor::amax), e = top - E puts

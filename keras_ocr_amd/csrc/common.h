@@ -201,14 +201,40 @@ struct ProfScope {
 
 // wave-level max |x| into a Tensor::amax slot (device code; values are non-negative, so uint order = float order)
 #if defined(__HIPCC__)
-__device__ __forceinline__ void kocr_amax_update(unsigned* slot, float m) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  // One address for a whole tensor: issue the atomic only when it can still raise the slot (a stale read
-  // merely costs a redundant atomic).  Unconditional atomics from every tile serialise in L2 -- measured
-  // 4x on the first layer.
-  if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > *(volatile const unsigned*)slot) atomicMax(slot, __float_as_uint(m));
+// max over the wave of a value that is >= 0 (not NaN) in every lane, as its bits, wave-uniform.  Non-negative floats order
+// like their bit patterns, so the cross-row step is four v_readlane + scalar max; the in-row steps are DPP modifiers.  No
+// lane-index operand anywhere: the __shfl_xor version kept six (lane ^ o) * 4 addresses alive across a persistent kernel's
+// K loop -- spilled there, and reloaded one by one (each a full memory round trip) in every tile's epilogue.
+__device__ __forceinline__ unsigned kocr_wave_max_bits(float m) {
+  int v = __float_as_int(m);
+  int t;
+  t = __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
+  v = v > t ? v : t;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);  // quad_perm [2, 3, 0, 1]
+  v = v > t ? v : t;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  v = v > t ? v : t;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror: every lane holds its row's maximum
+  v = v > t ? v : t;
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane(v, 0), b = (unsigned)__builtin_amdgcn_readlane(v, 16),
+                 c = (unsigned)__builtin_amdgcn_readlane(v, 32), d = (unsigned)__builtin_amdgcn_readlane(v, 48);
+  const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
 }
+__device__ __forceinline__ unsigned kocr_amax_peek(const unsigned* slot) {
+  // a relaxed agent-scope atomic load: read at L2 like a volatile read, but without the s_waitcnt vmcnt(0) hipcc puts
+  // behind every volatile access
+  return __hip_atomic_load(const_cast<unsigned*>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The slot's value as the caller read it beforehand (kocr_amax_peek at the start of its epilogue, consumed here after the
+// epilogue's arithmetic): the read's latency is hidden instead of being waited for tile after tile.
+// One address for a whole image: the atomic is issued only when it can still raise the slot (a stale read merely costs a
+// redundant atomic).  Unconditional atomics from every tile serialise in L2 -- measured 4x on the first layer.
+__device__ __forceinline__ void kocr_amax_update_known(unsigned* slot, float m, unsigned seen) {
+  const unsigned bits = kocr_wave_max_bits(m);
+  if (bits > seen && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicMax(slot, bits);
+}
+__device__ __forceinline__ void kocr_amax_update(unsigned* slot, float m) { kocr_amax_update_known(slot, m, kocr_amax_peek(slot)); }
 #endif
 
 // ---------------------------------------------------------------------------------------

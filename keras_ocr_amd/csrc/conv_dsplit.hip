@@ -15,6 +15,8 @@
 // LDS: As[buf][piece][M-tile][k half][32 rows x 8 ch] bf16, 24 KB * WM per buffer, the same
 // conflict-free layout as conv_wsplit.hip.  Weights: [16-ch group][tap][32-cout tile][piece][lane][8].
 #include "split_common.h"
+#include "w43_common.h"  // w4_div_magic / w4_fdiv
+#include "probe_clock.h"
 #include <cmath>
 #include <algorithm>
 
@@ -40,7 +42,11 @@ struct DsParams {
   const float* up;     // [N][up_H][up_W][Cout] contiguous
   int up_H, up_W;
   float up_sy, up_sx;  // up_H / H, up_W / W
+  unsigned dv_hw[2];   // w4_div_magic(H W): the image of a flattened pixel without a 64-bit division
 };
+
+// probe_clock.h bins: consumer wave 0: [0] K loop  [1] up-sampled addend  [2] post + amax  [3] store issue;  producer wave 4:
+// [4] LDS fill (with the wait for its raw loads)  [5] barrier  [6] load issue
 
 template <int WM, int WN, int HALF, int UP>
 __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
@@ -143,21 +149,33 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
     const int my_tiles = (total - (int)blockIdx.x + G - 1) / G;
     const int T = my_tiles * ns;
     tile_geometry();
-    v4f rawA[IPT], rawB[IPT];
-    load_raw(rawA);
+    // D - 1 K-steps of raw input in flight ahead of the LDS fill (the LDS ring itself stays two deep): these layers are
+    // HBM-bound (K = 64 .. 256 per pixel), and one 32 KB step in flight per CU is 8 MB on the chip -- half of what 8 TB/s
+    // times the loaded latency asks for.  Loads past the block's last step are out-of-range buffer loads (no traffic).
+    constexpr int D = 4;
+    v4f raw[D][IPT];
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) load_raw(raw[d]);
     int k = 0;
-    for (; k + 2 <= T; k += 2) {
-      load_raw(rawB);
-      produce(rawA, 0);
-      __syncthreads();
-      load_raw(rawA);
-      produce(rawB, 1);
-      __syncthreads();
+    PROBE_T0();
+    for (; k + D <= T; k += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        load_raw(raw[(d + D - 1) % D]);
+        PROBE_T(6);
+        produce(raw[d], d & 1);  // k is a multiple of D (even): step k + d fills buffer d & 1
+        PROBE_T(4);
+        __syncthreads();
+        PROBE_T(5);
+      }
     }
-    if (k < T) {
-      produce(rawA, 0);
-      __syncthreads();
-    }
+    PROBE_TEND((tid & 255) == 0, 4, 7);
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+      if (k + d < T) {
+        produce(raw[d], d & 1);
+        __syncthreads();
+      }
     __syncthreads();  // pairs with the consumers' barrier inside the last K-step
     return;
   }
@@ -212,8 +230,11 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
   // current one; the barrier publishing the next K-step sits before the last pair's MFMAs; the next
   // step's weights (3 x 16 B per lane) are fetched at the start of the step.
   bf8 a0[2][NP], a1[2][NP];
-  auto compute_step = [&](const unsigned short* bufp, const unsigned short* bufn,
+  // last_c (UP kernels, a tile's last step): the first A fragments of the NEXT tile are fetched after the epilogue instead
+  // of here -- 24 registers the up-sampling epilogue needs for its loads in flight (it spilled accumulators otherwise)
+  auto compute_step = [&](auto last_c, const unsigned short* bufp, const unsigned short* bufn,
                           const unsigned short* w_next) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last_c)::value;
 #pragma unroll
     for (int s = 0; s < NP; ++s) bwn[s] = *reinterpret_cast<const bf8*>(w_next + (size_t)s * 64 * 8);
     load_a(a1, bufp, 1);
@@ -229,7 +250,7 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
     mfma6(a0, 2);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    load_a(a0, bufn, 0);
+    if constexpr (!LAST) load_a(a0, bufn, 0);
     __builtin_amdgcn_sched_barrier(0);
     mfma6(a1, 3);
     __builtin_amdgcn_sched_barrier(0);
@@ -246,6 +267,7 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
   }
   __syncthreads();  // global step 0 is in LDS
   load_a(a0, As, 0);
+  PROBE_T0();
   for (int L = blockIdx.x; L < total; L += G) {
     const int tile = kocr_xcd_remap(L, total);
     const int mt = tile / nblk_n, nt = tile - mt * nblk_n;
@@ -259,8 +281,16 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[g][m][r] = 0.f;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the epilogue's stores once per tile (see conv_wsplit.hip)
-    for (int s = 0; s < ns; ++s, ++gs)
-      compute_step(As + (gs & 1) * BUF, As + ((gs + 1) & 1) * BUF, s + 1 < ns ? w_ptr + (size_t)(s + 1) * w_step : w_after);
+    if constexpr (UP != 0) {
+      for (int s = 0; s < ns - 1; ++s, ++gs)
+        compute_step(std::false_type{}, As + (gs & 1) * BUF, As + ((gs + 1) & 1) * BUF, w_ptr + (size_t)(s + 1) * w_step);
+      compute_step(std::true_type{}, As + (gs & 1) * BUF, As + ((gs + 1) & 1) * BUF, w_after);
+      ++gs;
+    } else {
+      for (int s = 0; s < ns; ++s, ++gs)
+        compute_step(std::false_type{}, As + (gs & 1) * BUF, As + ((gs + 1) & 1) * BUF, s + 1 < ns ? w_ptr + (size_t)(s + 1) * w_step : w_after);
+    }
+    PROBE_T(0);
 
     // ---- epilogue: 32x32 C/D map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -------------
     // branch-free, in place, raw buffer stores back to back (see conv_wsplit.hip)
@@ -321,35 +351,53 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
           // (ox0 = 4 q) of a register group read the source columns k - 1, k, k + 1, k + 2 (k = ox0 / 2; clamped at the image
           // edges by the table entries of the group's first and last pixel) of two source rows: 8 loads instead of 16, the
           // same blend arithmetic
+          // One stage = one M-tile (g, m): its 32 loads are issued a whole stage ahead of their blend, so that 32 .. 64
+          // loads per lane are always in flight (issued batch by batch behind their own use, the 32 batches of a tile each
+          // exposed one full memory latency: 26 of the 42 us a tile of upconv4.conv.0 took).
+          float tb[2][4][8];  // [stage parity][rr][top k-1 .. k+2, bottom k-1 .. k+2]
+          // the lane's table base is made opaque once per tile: every entry address below is then base + an immediate DS
+          // offset (left visible as loop-invariant, hipcc hoists ~100 precomputed addresses out of the tile loop and spills them)
+          unsigned tab_lane = 4 * l5 * 8;
+          asm volatile("" : "+v"(tab_lane));  // (an integer, not the pointer: an opaque pointer would lose its LDS address space)
+          const unsigned* tab_l = tab + tab_lane;
+          auto up_issue = [&](int gm, float (&v)[4][8]) __attribute__((always_inline)) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
+            for (int rr = 0; rr < 4; ++rr) {
+              const unsigned* e = tab_l + (gm * 32 + 8 * rr) * 8;
+              const uint4 oa = *reinterpret_cast<const uint4*>(e);          // pixel 0: (y0,k-1) (y0,k) (y1,k-1) (y1,k)
+              const uint4 od = *reinterpret_cast<const uint4*>(e + 3 * 8);  // pixel 3: (y0,k+1) (y0,k+2) (y1,k+1) (y1,k+2)
+              v[rr][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, oa.x + ch, 0, 0));
+              v[rr][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, oa.y + ch, 0, 0));
+              v[rr][2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, od.x + ch, 0, 0));
+              v[rr][3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, od.y + ch, 0, 0));
+              v[rr][4] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, oa.z + ch, 0, 0));
+              v[rr][5] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, oa.w + ch, 0, 0));
+              v[rr][6] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, od.z + ch, 0, 0));
+              v[rr][7] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, od.w + ch, 0, 0));
+            }
+          };
+          auto up_blend = [&](f16v& a, int gm, const float (&v)[4][8]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int rr = 0; rr < 4; ++rr) {
+              const unsigned* e = tab_l + (gm * 32 + 8 * rr) * 8;
 #pragma unroll
-              for (int rr = 0; rr < 4; ++rr) {
-                const unsigned* e = tab + ((g * 2 + m) * 32 + 8 * rr + 4 * l5) * 8;
-                const uint4 oa = *reinterpret_cast<const uint4*>(e);          // pixel 0: (y0,k-1) (y0,k) (y1,k-1) (y1,k)
-                const uint4 od = *reinterpret_cast<const uint4*>(e + 3 * 8);  // pixel 3: (y0,k+1) (y0,k+2) (y1,k+1) (y1,k+2)
-                float2 wl[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wl[j] = *reinterpret_cast<const float2*>(e + j * 8 + 4);
-                float t[4], b[4];  // top / bottom source row, columns k - 1 .. k + 2
-                t[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, oa.x + ch, 0, 0));
-                t[1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, oa.y + ch, 0, 0));
-                t[2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, od.x + ch, 0, 0));
-                t[3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, od.y + ch, 0, 0));
-                b[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, oa.z + ch, 0, 0));
-                b[1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, oa.w + ch, 0, 0));
-                b[2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, od.z + ch, 0, 0));
-                b[3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ru, od.w + ch, 0, 0));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  const int c0 = (j + 1) >> 1;  // left tap of output j: columns (k-1,k) (k,k+1) (k,k+1) (k+1,k+2)
-                  const float top = t[c0] + (t[c0 + 1] - t[c0]) * wl[j].x;
-                  const float bot = b[c0] + (b[c0 + 1] - b[c0]) * wl[j].x;
-                  acc[g][m][rr * 4 + j] += top + (bot - top) * wl[j].y;
-                }
+              for (int j = 0; j < 4; ++j) {
+                const float2 wl = *reinterpret_cast<const float2*>(e + j * 8 + 4);
+                const int c0 = (j + 1) >> 1;  // left tap of output j: columns (k-1,k) (k,k+1) (k,k+1) (k+1,k+2)
+                const float top = v[rr][c0] + (v[rr][c0 + 1] - v[rr][c0]) * wl.x;
+                const float bot = v[rr][4 + c0] + (v[rr][4 + c0 + 1] - v[rr][4 + c0]) * wl.x;
+                a[rr * 4 + j] += top + (bot - top) * wl.y;
               }
+            }
+          };
+          up_issue(0, tb[0]);
+#pragma unroll
+          for (int gm = 0; gm < 8; ++gm) {
+            if (gm + 1 < 8) up_issue(gm + 1, tb[(gm + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            up_blend(acc[gm >> 1][gm & 1], gm, tb[gm & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -382,26 +430,34 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
             }
         }
       }
+      PROBE_T(1);
+      {
+        const float lo = p.relu ? 0.f : -INFINITY;
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+          for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float o = acc[g][m][r] * pa + pb;
-            if (p.relu) o = fmaxf(o, 0.f);
-            if (has_post) o = o * qa + qb;
-            acc[g][m][r] = o;
-          }
+            for (int r = 0; r < 16; ++r) acc[g][m][r] = fmaxf(acc[g][m][r] * pa + pb, lo);
+        if (has_post) {  // uniform
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[g][m][r] = acc[g][m][r] * qa + qb;
+        }
+      }
       if (p.amax_out) {
         // per-image max |x| (Tensor::amax[n]): the wave's 256 consecutive pixels lie inside one image unless H W is not a
         // multiple of 256 -- then every image the wave touches gets the maximum over ITS pixels only (a slot must not
         // depend on the neighbouring image, nor on the rows past the end of the tensor)
-        const long w0 = pm0 + (long)wm * 256;
-        const long wend = w0 + 256 < (long)p.Mtotal ? w0 + 256 : (long)p.Mtotal;
+        const unsigned w0 = (unsigned)(pm0 + (long)wm * 256);
+        const unsigned wend = w0 + 256 < (unsigned)p.Mtotal ? w0 + 256 : (unsigned)p.Mtotal;
         if (wend > w0) {
-          const int hw = p.H * p.W;
-          const int n_lo = __builtin_amdgcn_readfirstlane((int)(w0 / hw)), n_hi = __builtin_amdgcn_readfirstlane((int)((wend - 1) / hw));
+          const unsigned hw = (unsigned)(p.H * p.W);
+          const int n_lo = __builtin_amdgcn_readfirstlane((int)w4_fdiv(w0, p.dv_hw)),
+                    n_hi = __builtin_amdgcn_readfirstlane((int)w4_fdiv(wend - 1, p.dv_hw));
           if (n_lo == n_hi && wend == w0 + 256) {
             float mx = 0.f;
 #pragma unroll
@@ -412,9 +468,11 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[g][m][r]));
             kocr_amax_update(p.amax_out + n_lo, n < p.Cout ? mx : 0.f);
           } else {
+            int l5o = 4 * l5;
+            asm volatile("" : "+v"(l5o));  // keeps the 128 row indices below out of the tile loop's preheader (and of scratch)
             for (int ni = n_lo; ni <= n_hi; ++ni) {
-              const long i0 = (long)ni * hw, i1 = i0 + hw;
-              const int lo = (int)((i0 > w0 ? i0 : w0) - w0), hi = (int)((i1 < wend ? i1 : wend) - w0);
+              const unsigned i0 = (unsigned)ni * hw, i1 = i0 + hw;
+              const int lo_r = (int)((i0 > w0 ? i0 : w0) - w0), hi_r = (int)((i1 < wend ? i1 : wend) - w0);
               float mx = 0.f;
 #pragma unroll
               for (int g = 0; g < 4; ++g)
@@ -422,14 +480,15 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                   for (int r = 0; r < 16; ++r) {
-                    const int rel = (g * 2 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * l5;
-                    if (rel >= lo && rel < hi) mx = fmaxf(mx, fabsf(acc[g][m][r]));
+                    const int rel = (g * 2 + m) * 32 + (r & 3) + 8 * (r >> 2) + l5o;
+                    if (rel >= lo_r && rel < hi_r) mx = fmaxf(mx, fabsf(acc[g][m][r]));
                   }
               kocr_amax_update(p.amax_out + ni, n < p.Cout ? mx : 0.f);
             }
           }
         }
       }
+      PROBE_T(2);
       const int ocs4 = p.out_cs * 4;
       const long rem = ((long)p.Mtotal - pm0) * ocs4;  // stores past the end of the tensor are dropped
       const unsigned long long bb = (unsigned long long)(p.out + (pm0 * p.out_cs + p.out_co));
@@ -447,8 +506,11 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
             const int px = ((wm * 4 + g) * 2 + m) * 32 + (r & 3) + 8 * (r >> 2);  // + 4*l5 in vo
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[g][m][r]), ro, vo, px * ocs4, 0);
           }
+      PROBE_T(3);
     }
+    if constexpr (UP != 0) load_a(a0, As + (gs & 1) * BUF, 0);  // the next tile's first fragments (see compute_step)
   }
+  PROBE_TEND((tid & 255) == 0, 0, 4);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -512,8 +574,15 @@ static int ds_launch(kocr_ctx* ctx, DsParams& p, size_t M) {
   const size_t mtiles = (M + 256 * WM - 1) / (256 * WM);
   p.total_tiles = (int)(mtiles * (p.Cout_pad / (32 * WN)));
   const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
+  PROBE_RESET(ctx);
   hipLaunchKernelGGL((conv_ds_kernel<WM, WN, HALF, UP>), dim3(grid), dim3(512), LDS_BYTES, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
+  {
+    char what[64];
+    snprintf(what, sizeof what, "conv_ds<%d,%d,%d> tiles %d steps %d", WM, WN, UP, p.total_tiles, p.nsteps);
+    (void)what;
+    PROBE_REPORT(ctx, what, grid);
+  }
   return KOCR_OK;
 }
 
@@ -565,6 +634,7 @@ int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   }
   p.amax_in = nullptr;
   p.w_exp = 0;
+  w4_div_magic((unsigned)(in.H * in.W), p.dv_hw);
   const int wcls = L.Cout > 64 ? 128 : 64;
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];

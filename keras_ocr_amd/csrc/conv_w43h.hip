@@ -26,6 +26,7 @@
 // v_mfma_f32_32x32x16_f16 per point and M-tile instead of six, and the power-of-two scale folded into the constants of the
 // input transform (so it costs two extra multiplies per value and channel group, not one per point).
 #include "w43_common.h"
+#include "probe_clock.h"
 
 namespace {
 
@@ -880,6 +881,9 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
   constexpr int PLANE_F = PLANE;          // one (xi, piece) plane: 2 M-tiles x 2 k halves x 256 ushorts (w43_common.h)
   constexpr int BUF_F = 6 * NP * PLANE_F; // one K-step: 24 KB (NP = 2)
   extern __shared__ __attribute__((aligned(16))) unsigned short As[];
+  // behind the two K-step buffers: the epilogue's per-channel coefficients [pre_a | pre_b | post_a | post_b][Cout_pad],
+  // staged once per block -- fetched from global memory in every tile's epilogue they cost it one memory latency each time
+  float* coef = reinterpret_cast<float*>(As + 2 * BUF_F);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, l5 = lane >> 5;
@@ -897,7 +901,8 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
     unsigned goff[6];
     int gy;
     bool gok;
-    float s;  // 2^e of the image this thread's quad lies in
+    float s;     // 2^e of the image this thread's quad lies in
+    int e0, e1;  // (uniform) scale exponents of the tile's first image and of the next one (the tile's second, if it has one)
     const float* base;
   };
   auto make_geo = [&](int L, Geo& g) __attribute__((always_inline)) {
@@ -905,13 +910,24 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
     w4_decode(p, kocr_xcd_remap(L < total ? L : 0, total), nblk_n, mp, nt_unused);
     const long pm_a = (long)mp * 256;
     g.base = p.in + (pm_a * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
+    const int tid_f = wn * 64 + kocr_fresh_lane();  // see kocr_fresh_lane
+    const int qi = tid_f >> 2, q4 = tid_f & 3;
     const int rel = 4 * qi;
     const long gp = pm_a + rel;
     g.gok = L < total && gp < p.Mtotal;
-    const int x0 = (int)(gp % p.W);
-    g.gy = (int)((gp / p.W) % p.H);
-    const long gpc = gp < p.Mtotal ? gp : (long)p.Mtotal - 1;
-    g.s = kocr_pow2(kocr_scale_exp(p.amax_in + w4_fdiv((unsigned)gpc, p.dv_hw), W4H_TOP));
+    // (row, image) of the quad's first pixel by multiply-high (gp < 2^31): a 64-bit % and / here compile to two software
+    // division loops per tile and thread
+    const unsigned gpc = (unsigned)(gp < p.Mtotal ? gp : (long)p.Mtotal - 1);
+    const unsigned row = w4_fdiv(gpc, p.dv_w), nimg = w4_fdiv(gpc, p.dv_hw);
+    const int x0 = (int)(gpc - row * (unsigned)p.W);
+    g.gy = (int)(row - nimg * (unsigned)p.H);
+    // the tile's (at most two) images' slots through the scalar cache
+    const unsigned pmc = (unsigned)(pm_a < (long)p.Mtotal ? pm_a : (long)p.Mtotal - 1);
+    const int n0 = __builtin_amdgcn_readfirstlane((int)w4_fdiv(pmc, p.dv_hw));
+    const int n1 = ((long)(n0 + 1) * hw < (long)p.Mtotal) ? n0 + 1 : n0;
+    g.e0 = kocr_scale_exp_bits(kocr_sload(p.amax_in + n0), W4H_TOP);
+    g.e1 = kocr_scale_exp_bits(kocr_sload(p.amax_in + n1), W4H_TOP);
+    g.s = kocr_pow2((int)nimg == n0 ? g.e0 : g.e1);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
       const bool pad = (k == 0 && x0 < 1) || (k == 5 && x0 + 4 >= p.W);  // column zero padding
@@ -1024,6 +1040,13 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
   };
 
   // ---- pipeline prologue ---------------------------------------------------------------------------------------------
+  for (int i = tid; i < p.Cout_pad; i += 256) {
+    const int c = i < p.Cout ? i : p.Cout - 1;
+    coef[i] = p.pre_a[c];
+    coef[p.Cout_pad + i] = p.pre_b[c];
+    coef[2 * p.Cout_pad + i] = p.post_a ? p.post_a[c] : 1.f;
+    coef[3 * p.Cout_pad + i] = p.post_a ? p.post_b[c] : 0.f;
+  }
   make_geo(blockIdx.x, gc);
   make_geo(blockIdx.x + G, gn);
   v4f rawA[6], rawB[6];
@@ -1044,6 +1067,7 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
   __syncthreads();
   load_a(a0, As, 0);
 
+  PROBE_T0();  // bins: [0] K loop  [1] next tile's geometry  [2] epilogue arithmetic + amax  [3] store issue
   for (int L = blockIdx.x; L < total; L += G) {
     int mp, nt, mp_n, nt_n;
     w4_decode(p, kocr_xcd_remap(L, total), nblk_n, mp, nt);
@@ -1065,14 +1089,18 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
       step(As + BUF_F, As, rawA, s + 2 < ns ? w_ptr + (size_t)(s + 2) * w_step : w_after, s + 2 < ns ? s_cur : s_nxt);
       load_raw(rawA);
     }
+    PROBE_T(0);
+    const int e0c = gc.e0, e1c = gc.e1;
     gc = gn;
     make_geo(L + 2 * G, gn);
     ld_next = false;
+    PROBE_T(1);
 
     // ---- epilogue: 32x32 C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----------------------------
     {
-      const int n = (nt * 4 + wn) * 32 + l31;
-      const int nc = n < p.Cout ? n : p.Cout - 1;
+      const int lane_e = kocr_fresh_lane();  // every lane term of the epilogue derives from this
+      const int l31e = lane_e & 31, l5e = lane_e >> 5;
+      const int n = (nt * 4 + wn) * 32 + l31e;
       const long pm0 = (long)mp * 256;
       // the tile's (at most two) images, the first quad of the second one, their unscale factors 2^-e
       const long pm0c = pm0 < (long)p.Mtotal ? pm0 : (long)p.Mtotal - 1;
@@ -1080,63 +1108,79 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
       const long b1 = ((long)(n0 + 1) * hw - pm0) >> 2;  // quads of the tile that lie in image n0 (W % 4 == 0)
       const int qb = __builtin_amdgcn_readfirstlane((int)(b1 < 64 ? b1 : 64));
       const int n1 = ((long)(n0 + 1) * hw < (long)p.Mtotal) ? n0 + 1 : n0;
-      const float u0 = kocr_pow2(-kocr_scale_exp(p.amax_in + n0, W4H_TOP)), u1 = kocr_pow2(-kocr_scale_exp(p.amax_in + n1, W4H_TOP));
-      const float pa0 = p.pre_a[nc] * u0, pa1 = p.pre_a[nc] * u1, pb = p.pre_b[nc];
+      // the output slots as they are now: read here, compared after the arithmetic below (kocr_amax_update_known)
+      unsigned seen0 = 0, seen1 = 0;
+      if (p.amax_out) {
+        seen0 = kocr_amax_peek(p.amax_out + n0);
+        seen1 = kocr_amax_peek(p.amax_out + n1);
+      }
+      const float u0 = kocr_pow2(-e0c), u1 = kocr_pow2(-e1c);
+      const float pre_a = coef[n], pb = coef[p.Cout_pad + n];  // n < Cout_pad; the padding channels repeat the last one
+      const float pa0 = pre_a * u0, pa1 = pre_a * u1;
       const bool has_post = p.post_a != nullptr;
-      const float qa = has_post ? p.post_a[nc] : 1.f, qb_ = has_post ? p.post_b[nc] : 0.f;
       const bool live = n < p.Cout;
       const float lo = p.relu ? 0.f : -INFINITY;
       const int qlim = (int)((((long)p.Mtotal - pm0) >> 2) < 64 ? (((long)p.Mtotal - pm0) >> 2) : 64);  // quads inside the tensor
-      float mx0 = 0.f, mx1 = 0.f;
+      // (from the fresh lane id: as loop invariants the 32 quad indices below and what derives from them are hoisted out of
+      // the tile loop into scratch and come back through ~35 serialised scratch loads per tile)
+      const int l5q = 4 * l5e;
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int q = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * l5;
-          const bool first = q < qb;
-          const float pa = first ? pa0 : pa1;
+          const int q = m * 32 + (r & 3) + 8 * (r >> 2) + l5q;
+          const float pa = q < qb ? pa0 : pa1;
           const float m0 = acc[0][m][r], m1 = acc[1][m][r], m2 = acc[2][m][r], m3 = acc[3][m][r], m4 = acc[4][m][r],
                       m5 = acc[5][m][r];
           const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-          float o0 = fmaxf(((m0 + s12) + s34) * pa + pb, lo);
-          float o1 = fmaxf((W4_A * d12 + W4_B * d34) * pa + pb, lo);
-          float o2 = fmaxf((W4_A2 * s12 + W4_B2 * s34) * pa + pb, lo);
-          float o3 = fmaxf(((W4_A3 * d12 + W4_B3 * d34) + m5) * pa + pb, lo);
-          if (has_post) {
-            o0 = o0 * qa + qb_;
-            o1 = o1 * qa + qb_;
-            o2 = o2 * qa + qb_;
-            o3 = o3 * qa + qb_;
-          }
-          if (p.Wv) {  // width-padded output (Tensor::Wv): the columns behind the valid width are zero padding
+          acc[0][m][r] = fmaxf(((m0 + s12) + s34) * pa + pb, lo);
+          acc[1][m][r] = fmaxf((W4_A * d12 + W4_B * d34) * pa + pb, lo);
+          acc[2][m][r] = fmaxf((W4_A2 * s12 + W4_B2 * s34) * pa + pb, lo);
+          acc[3][m][r] = fmaxf(((W4_A3 * d12 + W4_B3 * d34) + m5) * pa + pb, lo);
+        }
+      if (has_post) {  // uniform
+        const float qa = coef[2 * p.Cout_pad + n], qb_ = coef[3 * p.Cout_pad + n];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][m][r] = acc[j][m][r] * qa + qb_;
+      }
+      if (p.Wv) {  // width-padded output (Tensor::Wv): the columns behind the valid width are zero padding
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int q = m * 32 + (r & 3) + 8 * (r >> 2) + l5q;
             const unsigned pq = (unsigned)(pm0 + 4 * q);
             const int x0 = (int)(pq - w4_fdiv(pq, p.dv_w) * (unsigned)p.W);
-            o0 = x0 < p.Wv ? o0 : 0.f;
-            o1 = x0 + 1 < p.Wv ? o1 : 0.f;
-            o2 = x0 + 2 < p.Wv ? o2 : 0.f;
-            o3 = x0 + 3 < p.Wv ? o3 : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j][m][r] = x0 + j < p.Wv ? acc[j][m][r] : 0.f;
           }
-          acc[0][m][r] = o0;
-          acc[1][m][r] = o1;
-          acc[2][m][r] = o2;
-          acc[3][m][r] = o3;
-          if (p.amax_out) {
-            const float mq = (live && q < qlim) ? fmaxf(fmaxf(fabsf(o0), fabsf(o1)), fmaxf(fabsf(o2), fabsf(o3))) : 0.f;
-            mx0 = fmaxf(mx0, first ? mq : 0.f);
-            mx1 = fmaxf(mx1, first ? 0.f : mq);
-          }
-        }
-      if (p.amax_out) {
-        kocr_amax_update(p.amax_out + n0, mx0);
-        if (qb < 64) kocr_amax_update(p.amax_out + n1, mx1);
       }
+      if (p.amax_out) {
+        float mx0 = 0.f, mx1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int q = m * 32 + (r & 3) + 8 * (r >> 2) + l5q;
+            const float mq = (live && q < qlim) ? fmaxf(fmaxf(fabsf(acc[0][m][r]), fabsf(acc[1][m][r])), fmaxf(fabsf(acc[2][m][r]), fabsf(acc[3][m][r]))) : 0.f;
+            mx0 = fmaxf(mx0, q < qb ? mq : 0.f);
+            mx1 = fmaxf(mx1, q < qb ? 0.f : mq);
+          }
+        kocr_amax_update_known(p.amax_out + n0, mx0, seen0);
+        if (qb < 64) kocr_amax_update_known(p.amax_out + n1, mx1, seen1);
+      }
+      PROBE_T(2);
       int ocs4 = p.out_cs * 4;
       asm volatile("" : "+s"(ocs4));
       // bytes from the tile's first pixel to the end of the tensor: stores past it are dropped
       const long rem = ((long)p.Mtotal - pm0) * ocs4;
       const __amdgpu_buffer_rsrc_t ro =
           w4_rsrc(p.out + (pm0 * p.out_cs + p.out_co), rem < 0x7FFFFFFFL ? (unsigned)(rem > 0 ? rem : 0) : 0x7FFFFFFFu);
-      const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;
+      const unsigned vo = live ? (unsigned)((16 * l5e * p.out_cs + n) * 4) : OOB;
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1146,8 +1190,10 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
           for (int j = 0; j < 4; ++j)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vo, (px + j) * ocs4, 0);
         }
+      PROBE_T(3);
     }
   }
+  PROBE_TEND(tid == 0, 0, 4);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1305,11 +1351,12 @@ int launch_w43rh(kocr_ctx* ctx, W4Params& p, bool fuse, int pieces) {
 
 template <int NP>
 static int w4fh_launch(kocr_ctx* ctx, W4Params& p) {
-  constexpr int LDSF = 2 * 6 * NP * 2 * 2 * 256 * 2;  // 2 x 24 KB (NP = 2)
+  const int LDSF = 2 * 6 * NP * 2 * 2 * 256 * 2 + 4 * p.Cout_pad * 4;  // 2 x 24 KB (NP = 2) + the epilogue's coefficients
   static std::atomic<bool> attr_done[64];
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
-    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43fh_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSF));
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43fh_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      2 * 6 * NP * 2 * 2 * 256 * 2 + 4 * 1024 * 4));
     attr_done[dev] = true;
   }
   static std::atomic<int> n_cus[64];
@@ -1320,8 +1367,15 @@ static int w4fh_launch(kocr_ctx* ctx, W4Params& p) {
   }
   const int n_cu = n_cus[dev];
   const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
+  PROBE_RESET(ctx);
   hipLaunchKernelGGL((conv_w43fh_kernel<NP>), dim3(grid), dim3(256), LDSF, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
+  {
+    char what[64];
+    snprintf(what, sizeof what, "conv_w43fh<%d> tiles %d steps %d", NP, p.total_tiles, p.nsteps);
+    (void)what;
+    PROBE_REPORT(ctx, what, grid);
+  }
   return KOCR_OK;
 }
 

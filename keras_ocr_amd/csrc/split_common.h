@@ -90,6 +90,29 @@ __device__ __forceinline__ int kocr_scale_exp(const unsigned* amax, int top) {
   int e = top - ((int)(b >> 23) - 127);
   return e < -100 ? -100 : (e > 100 ? 100 : e);
 }
+// ... from the bits of a slot the caller fetched itself
+__device__ __forceinline__ int kocr_scale_exp_bits(unsigned b, int top) {
+  if (b == 0) return 0;
+  int e = top - ((int)(b >> 23) - 127);
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+// A dword at a wave-uniform address in memory that nothing writes while this kernel runs (the max-|x| slots of an INPUT
+// tensor): a scalar load through the constant address space, scheduled and waited for by the compiler -- no VGPR and no
+// vmcnt round trip (a vector load of it in a persistent kernel's per-tile code costs one full memory latency per tile: one
+// wave per SIMD has nothing else to run meanwhile).
+__device__ __forceinline__ unsigned kocr_sload(const unsigned* p) {
+  typedef const unsigned __attribute__((address_space(4))) cu4;
+  return *(cu4*)(unsigned long long)p;
+}
+// The lane id recomputed (two mbcnt) and made opaque: per-tile code of a persistent kernel that derives its lane terms
+// from this instead of from values computed before the tile loop does not keep those alive across the K loop -- where the
+// F(4,3) kernels have no register to spare, so they are spilled and come back through one serialised scratch load each,
+// a full memory round trip per value and tile at one wave per SIMD.
+__device__ __forceinline__ int kocr_fresh_lane() {
+  int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(l));
+  return l;
+}
 __device__ __forceinline__ float kocr_pow2(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
 
 // host: round-to-nearest-even 3-way bf16 split of a weight (finite inputs)

@@ -93,13 +93,14 @@ __device__ __forceinline__ long w4_mtile_pm0(const W4Params& p, int mt, int& y0,
 
 // tile index -> (pixel tile, cout block)
 __device__ __forceinline__ void w4_decode(const W4Params& p, int tile, int nblk_n, int& mp, int& nt) {
-  if (p.m_fastest) {
-    nt = (int)w4_fdiv((unsigned)tile, p.dv_mp);
-    mp = tile - nt * p.n_mpairs;
-  } else {
-    mp = (int)w4_fdiv((unsigned)tile, p.dv_nb);
-    nt = tile - mp * nblk_n;
-  }
+  // selects, not an if / else over the two assignment orders: hipcc lowers that to a two-element stack array written at a
+  // dynamic index and read back -- a scratch store + load with a full memory round trip in every tile of every F(4,3) kernel
+  const bool mf = p.m_fastest != 0;
+  const unsigned dv[2] = {mf ? p.dv_mp[0] : p.dv_nb[0], mf ? p.dv_mp[1] : p.dv_nb[1]};
+  const int quot = (int)w4_fdiv((unsigned)tile, dv);
+  const int rem = tile - quot * (mf ? p.n_mpairs : nblk_n);
+  nt = mf ? quot : rem;
+  mp = mf ? rem : quot;
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t w4_rsrc(const float* base, unsigned bytes) {

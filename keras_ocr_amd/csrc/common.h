@@ -232,7 +232,11 @@ __device__ __forceinline__ unsigned kocr_amax_peek(const unsigned* slot) {
 // redundant atomic).  Unconditional atomics from every tile serialise in L2 -- measured 4x on the first layer.
 __device__ __forceinline__ void kocr_amax_update_known(unsigned* slot, float m, unsigned seen) {
   const unsigned bits = kocr_wave_max_bits(m);
-  if (bits > seen && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicMax(slot, bits);
+  if (bits > seen) {  // uniform
+    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));  // not a loop invariant to hoist (and spill) out of the caller's tile loop
+    if (l == 0) atomicMax(slot, bits);
+  }
 }
 __device__ __forceinline__ void kocr_amax_update(unsigned* slot, float m) { kocr_amax_update_known(slot, m, kocr_amax_peek(slot)); }
 #endif

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
   constexpr int BUF_R = 6 * NP * PLANE_R;                  // one channel group: 36 / 30 KB (NP = 2)
   constexpr int TCOLS = QPR * 4;                           // tile columns
   extern __shared__ __attribute__((aligned(16))) unsigned short As[];
+  float* coef = reinterpret_cast<float*>(As + 2 * BUF_R);  // behind the two channel-group buffers: see w4_stage_coef
   const int tid = threadIdx.x, lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = cout sub-tile
   const int l31 = lane & 31, l5 = lane >> 5;
@@ -121,11 +122,18 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
     int y0, x0;
     const long pm = tile_org(mp, y0, x0);
     g.base = p.in + (pm * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
+    // the thread's item coordinates again, from a fresh lane id (kocr_fresh_lane: nothing of this per-tile code is kept
+    // alive -- spilled -- across the K loop)
+    const int tid = wn * 64 + kocr_fresh_lane();
+    const int q4 = tid & 3, qd0 = (tid >> 2) & (QPR - 1), r0 = GEO == 2 ? (tid >> 5) : (tid >> 6);
+    const int cp = tid & 7;
+    const int qd1 = GEO == 2 ? ((tid >> 3) & 7) : ((tid >> 3) & 15);
+    const int r1 = GEO == 2 ? 8 + ((tid >> 6) & 1) : 4 + (tid >> 7);
     g.off0[0] = (unsigned)(((r0 * p.W + 4 * qd0) * p.in_cs + q4 * 4) * 4);
     g.off0[1] = (unsigned)(((r1 * p.W + 4 * qd1) * p.in_cs + cp * 2) * 4);
     g.ok = ((L < total && (unsigned)(y0 - 1 + r0) < (unsigned)p.H) ? 1u : 0u) |
            ((L < total && (unsigned)(y0 - 1 + r1) < (unsigned)p.H) ? 2u : 0u);
-    g.e = __builtin_amdgcn_readfirstlane(kocr_scale_exp(p.amax_in + w4_fdiv((unsigned)pm, p.dv_hw), W4H_TOP));
+    g.e = kocr_scale_exp_bits(kocr_sload(p.amax_in + __builtin_amdgcn_readfirstlane((int)w4_fdiv((unsigned)pm, p.dv_hw))), W4H_TOP);
     // d0 / d5 are column zero padding only at the image edges (W is a multiple of the tile width)
     left = x0 == 0;
     right = x0 + TCOLS >= p.W;
@@ -333,6 +341,7 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
   };
 
   // ---- prologue ------------------------------------------------------------------------------------------------
+  w4_stage_coef(p, coef, tid);
   make_geo(blockIdx.x, gc, lc, rc);
   make_geo(blockIdx.x + G, gn, ln, rn);
   load_item0(raw0);
@@ -361,6 +370,7 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
   __syncthreads();
   load_a(a0, As, 0, 0);
 
+  PROBE_T0();  // bins: [0] K loop  [1] next tile's geometry  [2] epilogue arithmetic + amax  [3] store issue
   for (int L = blockIdx.x; L < total; L += G) {
     int mp, nt, mp_n, nt_n;
     w4_decode(p, kocr_xcd_remap(L, total), nblk_n, mp, nt);
@@ -397,19 +407,29 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
       advance();
       step(I2{}, I1{}, As + BUF_R, As, w_at(3 * cg + 7), s_odd);
     }
+    PROBE_T(0);
     gc = gn;
     lc = ln;
     rc = rn;
     make_geo(L + 2 * G, gn, ln, rn);
     ld_next = false;
+    PROBE_T(1);
 
     // ---- epilogue --------------------------------------------------------------------------------------------------
     {
-      const int n = (nt * 4 + wn) * 32 + l31;
-      const int nc = n < p.Cout ? n : p.Cout - 1;
-      const float pa = p.pre_a[nc] * unscale, pb = p.pre_b[nc];  // pre_a here = pre_a 2^-wexp[o] (ConvLayer::d_pre_a_h)
+      // every lane term of the epilogue derives from a fresh lane id (kocr_fresh_lane), the coefficients come from LDS and
+      // the output slots are read here, long before they are compared: no memory round trip is waited for in a tile's epilogue
+      const int lane_e = kocr_fresh_lane();
+      const int l31e = lane_e & 31, l5e = lane_e >> 5;
+      const int n = (nt * 4 + wn) * 32 + l31e;
+      int ty0, tx0;
+      const long tpm = tile_org(mp, ty0, tx0);
+      const int nimg = __builtin_amdgcn_readfirstlane((int)w4_fdiv((unsigned)tpm, p.dv_hw));  // the tile lies inside one image
+      const unsigned seen_out = p.amax_out ? kocr_amax_peek(p.amax_out + nimg) : 0u;
+      const unsigned seen_pool = p.amax_pool ? kocr_amax_peek(p.amax_pool + nimg) : 0u;
+      const float pa = coef[n] * unscale, pb = coef[p.Cout_pad + n];  // pre_a here = pre_a 2^-wexp[o] (ConvLayer::d_pre_a_h)
       const bool has_post = p.post_a != nullptr;
-      const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
+      const float qa = coef[2 * p.Cout_pad + n], qb = coef[3 * p.Cout_pad + n];
       const bool live = n < p.Cout;
       const float lo = p.relu ? 0.f : -INFINITY;
       auto act = [&](float v) { return fmaxf(v * pa + pb, lo); };
@@ -437,8 +457,6 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
       asm volatile("" : "+s"(ocs4));
       int pcs4 = p.pool_cs * 4;
       asm volatile("" : "+s"(pcs4));
-      int ty0, tx0;
-      const long tpm = tile_org(mp, ty0, tx0);
       if (p.amax_out || p.amax_pool) {
         float mx = 0.f;
 #pragma unroll
@@ -448,14 +466,14 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[j][m][r]));
         mx = live ? mx : 0.f;
-        const unsigned nimg = w4_fdiv((unsigned)tpm, p.dv_hw);  // per-image slots: the tile lies inside one image
-        if (p.amax_out) kocr_amax_update(p.amax_out + nimg, mx);
-        if (p.amax_pool) kocr_amax_update(p.amax_pool + nimg, mx);
+        if (p.amax_out) kocr_amax_update_known(p.amax_out + nimg, mx, seen_out);
+        if (p.amax_pool) kocr_amax_update_known(p.amax_pool + nimg, mx, seen_pool);
       }
+      PROBE_T(2);
       if constexpr (GEO == 2) {
         // M-tile m = rows 4 m .. 4 m + 3 x 8 quads: accumulator register r of lane half l5 is row r >> 2, quad (r & 3) + 4 l5
         const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (tpm * p.out_cs + p.out_co), 0x7FFFFFFFu);
-        const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
+        const unsigned vo = live ? (unsigned)((16 * l5e * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -473,7 +491,7 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
           const int x0 = tx0;
           if (!POOL || p.write_full) {
             const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (pm * p.out_cs + p.out_co), 0x7FFFFFFFu);
-            const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
+            const unsigned vo = live ? (unsigned)((16 * l5e * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
               const int px = 4 * ((r & 3) + 8 * (r >> 2));  // quad column (r&3) + 8 (r>>2) [+ 4 l5] of row y
@@ -488,7 +506,7 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
             // 2x2 max: rows y (r) and y+1 (r+8), columns (0,1) and (2,3) of the quad
             const long pp0 = ((pm - x0) >> 2) + (x0 >> 1);  // (nimg H/2 + y0/2) W/2 + x0/2: H, W even
             const __amdgpu_buffer_rsrc_t rp = w4_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
-            const unsigned vp = live ? (unsigned)((8 * l5 * p.pool_cs + n) * 4) : OOB;  // 4 quads = 8 pooled px per l5
+            const unsigned vp = live ? (unsigned)((8 * l5e * p.pool_cs + n) * 4) : OOB;  // 4 quads = 8 pooled px per l5
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
               const int pq = 2 * ((r & 3) + 8 * (r >> 2));
@@ -500,8 +518,10 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
           }
         }
       }
+      PROBE_T(3);
     }
   }
+  PROBE_TEND(tid == 0, 0, 4);
 }
 
 // ===================================================================================================
@@ -518,6 +538,7 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
   constexpr int BUF_R = 6 * NP * PLANE_R;  // one channel group: 36 KB (NP = 2)
   constexpr int TCOLS = QPR * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned short As[];
+  float* coef = reinterpret_cast<float*>(As + BUF_R + 4 * 16 * 64 * 8);  // behind the buffer and the exchange area: w4_stage_coef
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, ph = wave >> 1;  // cout half, point half (points 3 ph .. 3 ph + 2)
@@ -549,11 +570,14 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
     int y0, x0;
     const long pm = w4_mtile_pm0<1>(p, tile_mt(mp, 0), y0, x0);
     g.base = p.in + (pm * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
+    const int tid = wave * 64 + kocr_fresh_lane();  // see conv_w43vh_kernel's make_geo
+    const int q4 = tid & 3, qd0 = (tid >> 2) & (QPR - 1), r0 = tid >> 6;
+    const int cp = tid & 7, qd1 = (tid >> 3) & 15, r1 = 4 + (tid >> 7);
     g.off0[0] = (unsigned)(((r0 * p.W + 4 * qd0) * p.in_cs + q4 * 4) * 4);
     g.off0[1] = (unsigned)(((r1 * p.W + 4 * qd1) * p.in_cs + cp * 2) * 4);
     g.ok = ((L < total && (unsigned)(y0 - 1 + r0) < (unsigned)p.H) ? 1u : 0u) |
            ((L < total && (unsigned)(y0 - 1 + r1) < (unsigned)p.H) ? 2u : 0u);
-    g.e = __builtin_amdgcn_readfirstlane(kocr_scale_exp(p.amax_in + w4_fdiv((unsigned)pm, p.dv_hw), W4H_TOP));
+    g.e = kocr_scale_exp_bits(kocr_sload(p.amax_in + __builtin_amdgcn_readfirstlane((int)w4_fdiv((unsigned)pm, p.dv_hw))), W4H_TOP);
     left = x0 == 0;
     right = x0 + TCOLS >= p.W;
   };
@@ -715,6 +739,7 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
   };
 
   // ---- prologue ------------------------------------------------------------------------------------------------
+  w4_stage_coef(p, coef, tid);
   make_geo(blockIdx.x, gc, lc, rc);
   make_geo(blockIdx.x + G, gn, ln, rn);
   load_item0(raw0);
@@ -758,11 +783,18 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
 
     // ---- epilogue (conv_w43r_kernel's: partial output transforms exchanged between the point halves) -----------------
     {
-      const int n = wn * 32 + l31;
-      const int nc = n < p.Cout ? n : p.Cout - 1;
-      const float pa = p.pre_a[nc] * unscale, pb = p.pre_b[nc];  // pre_a = pre_a 2^-wexp[o] (ConvLayer::d_pre_a_h)
+      // (fresh lane id, LDS coefficients, early slot reads: see conv_w43vh_kernel's epilogue)
+      const int lane_e = kocr_fresh_lane();
+      const int l31e = lane_e & 31, l5e = lane_e >> 5;
+      const int n = wn * 32 + l31e;
+      int y0, x0;
+      const long pm = w4_mtile_pm0<1>(p, tile_mt(mp, ph), y0, x0);
+      const int nimg = __builtin_amdgcn_readfirstlane((int)w4_fdiv((unsigned)pm, p.dv_hw));
+      const unsigned seen_out = p.amax_out ? kocr_amax_peek(p.amax_out + nimg) : 0u;
+      const unsigned seen_pool = p.amax_pool ? kocr_amax_peek(p.amax_pool + nimg) : 0u;
+      const float pa = coef[n] * unscale, pb = coef[p.Cout_pad + n];  // pre_a = pre_a 2^-wexp[o] (ConvLayer::d_pre_a_h)
       const bool has_post = p.post_a != nullptr;
-      const float qa = has_post ? p.post_a[nc] : 1.f, qb = has_post ? p.post_b[nc] : 0.f;
+      const float qa = coef[2 * p.Cout_pad + n], qb = coef[3 * p.Cout_pad + n];
       const bool live = n < p.Cout;
       const float lo = p.relu ? 0.f : -INFINITY;
       auto act = [&](float v) { return fmaxf(v * pa + pb, lo); };
@@ -791,7 +823,7 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
         for (int r = 0; r < 16; ++r) {
           float o[4];
           partial(std::integral_constant<int, 1 - PH>{}, r, o);
-          xch[(wave * 16 + r) * 64 + lane] = v4f{o[0], o[1], o[2], o[3]};
+          xch[(wave * 16 + r) * 64 + lane_e] = v4f{o[0], o[1], o[2], o[3]};
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -808,7 +840,7 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const v4f q = xch[((wave ^ 2) * 16 + r) * 64 + lane];
+        const v4f q = xch[((wave ^ 2) * 16 + r) * 64 + lane_e];
 #pragma unroll
         for (int j = 0; j < 4; ++j) out[j][r] = act(out[j][r] + q[j]);
       }
@@ -823,8 +855,6 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
       asm volatile("" : "+s"(ocs4));
       int pcs4 = p.pool_cs * 4;
       asm volatile("" : "+s"(pcs4));
-      int y0, x0;
-      const long pm = w4_mtile_pm0<1>(p, tile_mt(mp, ph), y0, x0);
       if (p.amax_out || p.amax_pool) {
         float mx = 0.f;
 #pragma unroll
@@ -832,13 +862,12 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(out[j][r]));
         mx = live ? mx : 0.f;
-        const unsigned nimg = w4_fdiv((unsigned)pm, p.dv_hw);
-        if (p.amax_out) kocr_amax_update(p.amax_out + nimg, mx);
-        if (p.amax_pool) kocr_amax_update(p.amax_pool + nimg, mx);
+        if (p.amax_out) kocr_amax_update_known(p.amax_out + nimg, mx, seen_out);
+        if (p.amax_pool) kocr_amax_update_known(p.amax_pool + nimg, mx, seen_pool);
       }
       if (!POOL || p.write_full) {
         const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (pm * p.out_cs + p.out_co), 0x7FFFFFFFu);
-        const unsigned vo = live ? (unsigned)((16 * l5 * p.out_cs + n) * 4) : OOB;
+        const unsigned vo = live ? (unsigned)((16 * l5e * p.out_cs + n) * 4) : OOB;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const int px = 4 * ((r & 3) + 8 * (r >> 2));
@@ -852,7 +881,7 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
       if constexpr (POOL) {
         const long pp0 = ((pm - x0) >> 2) + (x0 >> 1);
         const __amdgpu_buffer_rsrc_t rp = w4_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
-        const unsigned vp = live ? (unsigned)((8 * l5 * p.pool_cs + n) * 4) : OOB;
+        const unsigned vp = live ? (unsigned)((8 * l5e * p.pool_cs + n) * 4) : OOB;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const int pq = 2 * ((r & 3) + 8 * (r >> 2));
@@ -1040,13 +1069,7 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
   };
 
   // ---- pipeline prologue ---------------------------------------------------------------------------------------------
-  for (int i = tid; i < p.Cout_pad; i += 256) {
-    const int c = i < p.Cout ? i : p.Cout - 1;
-    coef[i] = p.pre_a[c];
-    coef[p.Cout_pad + i] = p.pre_b[c];
-    coef[2 * p.Cout_pad + i] = p.post_a ? p.post_a[c] : 1.f;
-    coef[3 * p.Cout_pad + i] = p.post_a ? p.post_b[c] : 0.f;
-  }
+  w4_stage_coef(p, coef, tid);
   make_geo(blockIdx.x, gc);
   make_geo(blockIdx.x + G, gn);
   v4f rawA[6], rawB[6];
@@ -1265,11 +1288,12 @@ int prepare_w43h(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, co
 
 template <int POOL, int GEO, int NP, int DBG = 0>
 static int w4vh_launch(kocr_ctx* ctx, W4Params& p) {
-  constexpr int LDSV = (GEO == 2 ? 2 * 6 * 10 * 128 * 2 : 2 * 6 * 6 * 256 * 2) * NP;  // 2 x 30 / 36 KB (NP = 2)
+  constexpr int LDSV0 = (GEO == 2 ? 2 * 6 * 10 * 128 * 2 : 2 * 6 * 6 * 256 * 2) * NP;  // 2 x 30 / 36 KB (NP = 2)
+  const int LDSV = LDSV0 + 4 * p.Cout_pad * 4;                                         // + the epilogue's coefficients
   static std::atomic<bool> attr_done[64];
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
-    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43vh_kernel<POOL, GEO, NP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSV));
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43vh_kernel<POOL, GEO, NP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSV0 + W4_COEF_BYTES_MAX));
     attr_done[dev] = true;
   }
   static std::atomic<int> n_cus[64];
@@ -1280,8 +1304,15 @@ static int w4vh_launch(kocr_ctx* ctx, W4Params& p) {
   }
   const int n_cu = n_cus[dev];
   const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;  // persistent: one block per CU
+  PROBE_RESET(ctx);
   hipLaunchKernelGGL((conv_w43vh_kernel<POOL, GEO, NP, DBG>), dim3(grid), dim3(256), LDSV, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
+  {
+    char what[80];
+    snprintf(what, sizeof what, "conv_w43vh<%d,%d,%d> tiles %d steps %d cout %d", POOL, GEO, NP, p.total_tiles, p.nsteps, p.Cout);
+    (void)what;
+    PROBE_REPORT(ctx, what, grid);
+  }
   return KOCR_OK;
 }
 
@@ -1322,11 +1353,12 @@ int launch_w43vh(kocr_ctx* ctx, W4Params& p, bool fuse, int geo, int pieces) {
 
 template <int POOL, int NP>
 static int w4rh_launch(kocr_ctx* ctx, W4Params& p) {
-  constexpr int LDSR = 6 * NP * 6 * 256 * 2 + 4 * 16 * 64 * 16;  // one 36 KB buffer + the epilogue's 64 KB exchange area
+  constexpr int LDSR0 = 6 * NP * 6 * 256 * 2 + 4 * 16 * 64 * 16;  // one 36 KB buffer + the epilogue's 64 KB exchange area
+  const int LDSR = LDSR0 + 4 * p.Cout_pad * 4;                    // + the epilogue's coefficients
   static std::atomic<bool> attr_done[64];
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
-    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43rh_kernel<POOL, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSR));
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43rh_kernel<POOL, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSR0 + W4_COEF_BYTES_MAX));
     attr_done[dev] = true;
   }
   static std::atomic<int> n_cus[64];
@@ -1356,7 +1388,7 @@ static int w4fh_launch(kocr_ctx* ctx, W4Params& p) {
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
     KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43fh_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      2 * 6 * NP * 2 * 2 * 256 * 2 + 4 * 1024 * 4));
+                                      2 * 6 * NP * 2 * 2 * 256 * 2 + W4_COEF_BYTES_MAX));
     attr_done[dev] = true;
   }
   static std::atomic<int> n_cus[64];

@@ -103,6 +103,20 @@ __device__ __forceinline__ void w4_decode(const W4Params& p, int tile, int nblk_
   mp = mf ? rem : quot;
 }
 
+// The epilogue's per-channel coefficients [pre_a | pre_b | post_a | post_b][Cout_pad] staged in LDS once per block (the
+// padding channels repeat the last one; post = identity without one): fetched from global memory in every tile's epilogue
+// they cost a persistent block one full memory latency per tile.  The caller's next block barrier publishes them.
+__device__ __forceinline__ void w4_stage_coef(const W4Params& p, float* coef, int tid) {
+  for (int i = tid; i < p.Cout_pad; i += 256) {
+    const int c = i < p.Cout ? i : p.Cout - 1;
+    coef[i] = p.pre_a[c];
+    coef[p.Cout_pad + i] = p.pre_b[c];
+    coef[2 * p.Cout_pad + i] = p.post_a ? p.post_a[c] : 1.f;
+    coef[3 * p.Cout_pad + i] = p.post_a ? p.post_b[c] : 0.f;
+  }
+}
+constexpr int W4_COEF_BYTES_MAX = 4 * 1024 * 4;  // what the launchers reserve: Cout_pad <= 1024
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t w4_rsrc(const float* base, unsigned bytes) {
   const unsigned long long bb = (unsigned long long)base;
   const unsigned long long bbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)) << 32) |

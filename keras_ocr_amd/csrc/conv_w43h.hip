@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
   const int ns = 3 * ncg;
   const int G = gridDim.x;
   constexpr unsigned OOB = 0x80000000u;
+  PROBE_T0();
 
   // ushort offset of the 16-byte slot (window row w, k half kh, quad q) inside a plane (see conv_w43v_kernel)
   auto slot = [&](int w, int kh, int q) {
@@ -370,7 +371,9 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
   __syncthreads();
   load_a(a0, As, 0, 0);
 
-  PROBE_T0();  // bins: [0] K loop  [1] next tile's geometry  [2] epilogue arithmetic + amax  [3] store issue
+  // bins: [0] K loop  [1] next tile's geometry  [2] epilogue arithmetic + amax  [3] store issue  (marks INSIDE the K loop
+  // slowed it six-fold: the probe is for per-tile phases only)
+  PROBE_RESTART();
   for (int L = blockIdx.x; L < total; L += G) {
     int mp, nt, mp_n, nt_n;
     w4_decode(p, kocr_xcd_remap(L, total), nblk_n, mp, nt);
@@ -408,12 +411,6 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
       step(I2{}, I1{}, As + BUF_R, As, w_at(3 * cg + 7), s_odd);
     }
     PROBE_T(0);
-    gc = gn;
-    lc = ln;
-    rc = rn;
-    make_geo(L + 2 * G, gn, ln, rn);
-    ld_next = false;
-    PROBE_T(1);
 
     // ---- epilogue --------------------------------------------------------------------------------------------------
     {
@@ -520,6 +517,15 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
       }
       PROBE_T(3);
     }
+    // the geometry of the tile after next, behind the stores (their drain at the head of the next K loop then has this
+    // arithmetic in front of it; same-box A/B against the order geometry -> epilogue: 26.03 vs 26.07 ms per 8 x 1536^2, no
+    // measurable difference)
+    gc = gn;
+    lc = ln;
+    rc = rn;
+    make_geo(L + 2 * G, gn, ln, rn);
+    ld_next = false;
+    PROBE_T(1);
   }
   PROBE_TEND(tid == 0, 0, 4);
 }
@@ -760,6 +766,7 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
   __syncthreads();
   load_a(a0, As, 0, 0);
 
+  PROBE_T0();  // bins: [0] K loop  [1] next tile's geometry  [2] epilogue up to the stores  [3] store issue
   for (int L = blockIdx.x; L < total; L += G) {
     const int mp = kocr_xcd_remap(L, total);
     const float s_cur = kocr_pow2(gc.e), s_nxt = kocr_pow2(gn.e);
@@ -775,12 +782,8 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
       phase(As, As + BUF_R, 3 * cg, 0, s_cur);                             // produces channel group cg + 1 (this tile's)
       phase(As + BUF_R, As, 3 * cg + 3, 1, cg + 2 < ncg ? s_cur : s_nxt);  // ... cg + 2, or the next tile's first
     }
-    gc = gn;
-    lc = ln;
-    rc = rn;
-    make_geo(L + 2 * G, gn, ln, rn);
-    ld_next = false;
 
+    PROBE_T(0);
     // ---- epilogue (conv_w43r_kernel's: partial output transforms exchanged between the point halves) -----------------
     {
       // (fresh lane id, LDS coefficients, early slot reads: see conv_w43vh_kernel's epilogue)
@@ -865,6 +868,7 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
         if (p.amax_out) kocr_amax_update_known(p.amax_out + nimg, mx, seen_out);
         if (p.amax_pool) kocr_amax_update_known(p.amax_pool + nimg, mx, seen_pool);
       }
+      PROBE_T(2);
       if (!POOL || p.write_full) {
         const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (pm * p.out_cs + p.out_co), 0x7FFFFFFFu);
         const unsigned vo = live ? (unsigned)((16 * l5e * p.out_cs + n) * 4) : OOB;
@@ -891,8 +895,17 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * pcs4, 0);
         }
       }
+      PROBE_T(3);
     }
+    // (behind the stores: see conv_w43vh_kernel)
+    gc = gn;
+    lc = ln;
+    rc = rn;
+    make_geo(L + 2 * G, gn, ln, rn);
+    ld_next = false;
+    PROBE_T(1);
   }
+  PROBE_TEND(tid == 0, 0, 4);
 }
 
 // ===================================================================================================
@@ -1114,10 +1127,6 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
     }
     PROBE_T(0);
     const int e0c = gc.e0, e1c = gc.e1;
-    gc = gn;
-    make_geo(L + 2 * G, gn);
-    ld_next = false;
-    PROBE_T(1);
 
     // ---- epilogue: 32x32 C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----------------------------
     {
@@ -1215,6 +1224,11 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
         }
       PROBE_T(3);
     }
+    // (behind the stores: see conv_w43vh_kernel)
+    gc = gn;
+    make_geo(L + 2 * G, gn);
+    ld_next = false;
+    PROBE_T(1);
   }
   PROBE_TEND(tid == 0, 0, 4);
 }
@@ -1369,8 +1383,15 @@ static int w4rh_launch(kocr_ctx* ctx, W4Params& p) {
   }
   const int n_cu = n_cus[dev];
   const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
+  PROBE_RESET(ctx);
   hipLaunchKernelGGL((conv_w43rh_kernel<POOL, NP>), dim3(grid), dim3(256), LDSR, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
+  {
+    char what[80];
+    snprintf(what, sizeof what, "conv_w43rh<%d,%d> tiles %d steps %d", POOL, NP, p.total_tiles, p.nsteps);
+    (void)what;
+    PROBE_REPORT(ctx, what, grid);
+  }
   return KOCR_OK;
 }
 

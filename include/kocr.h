@@ -178,6 +178,17 @@ int kocr_conv2d_nhwc(kocr_ctx* ctx, const float* in, int N, int H, int W, int Ci
                      const float* pre_a, const float* pre_b, int relu,
                      const float* post_a, const float* post_b, float* out);
 
+/* The same seam for a CELL GRID (round 5; the layout the recogniser's conv stack runs in, keras_ocr_amd/csrc/crnn.cpp): every
+ * image is one row of W / cellW cells of cellW columns, each holding an independent crop in its columns [0, cellWv) and rows
+ * [1, H); row 0 and the columns behind cellWv are zero gutters (the caller passes zeros there, the result has zeros there).
+ * 3x3, dilation 1, Cin % 32 == 0, Cout > 64, H % 4 == 0, W % 64 == 0, fp16 arithmetic modes only.  pool != 0: the 2x2 max
+ * pooling of cell rows (2 i, 2 i + 1) -- crop rows (2 i - 1, 2 i): the flipped 'valid' pooling of recognition.py:228, 238 -- is
+ * fused and pool_out [N][H/2][W/2][Cout] (cells of cellW / 2) is written instead of out (out may be NULL).  amax_out (or NULL):
+ * the per-cell max |x| the kernel tracked for what it wrote, N * (W / cellW) floats.  Host pointers only. */
+int kocr_conv2d_cells(kocr_ctx* ctx, const float* in, int N, int H, int W, int Cin, const float* w_hwio, int Cout,
+                      const float* pre_a, const float* pre_b, int relu, const float* post_a, const float* post_b,
+                      int cellW, int cellWv, int pool, float* out, float* pool_out, float* amax_out);
+
 /* ---- arithmetic of the wide convolutions --------------------------------------------- */
 /* The 3x3 / 1x1 / dilated convolutions with Cout > 32 run on the 16-bit matrix cores with fp32 operands split into
  * 16-bit pieces and fp32 accumulation:

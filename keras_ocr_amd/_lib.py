@@ -70,6 +70,7 @@ def load_library():
         "kocr_pipeline": (ci, [vp, ci, ctypes.POINTER(vp), _c_int_p, _c_int_p, _c_int_p, _c_int_p, ci, ci,
                                ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, ci, vp, ci, vp, ci]),
         "kocr_conv2d_nhwc": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp]),
+        "kocr_conv2d_cells": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, vp, vp, vp]),
         "kocr_set_split_mode": (ci, [vp, ci]),
         "kocr_get_split_mode": (ci, [vp]),
         "kocr_set_schedule": (ci, [vp, ci, ci]),
@@ -374,6 +375,24 @@ class Context:
                                                _ptr(vecs[0]), _ptr(vecs[1]), int(bool(relu)), _ptr(vecs[2]),
                                                _ptr(vecs[3]), _ptr(out)))
         return out
+
+    def conv2d_cells(self, x, w_hwio, cell_w, cell_wv, pool=False, need_full=True, pre_a=None, pre_b=None, relu=False,
+                     post_a=None, post_b=None):
+        """3x3 convolution of a cell grid (include/kocr.h: kocr_conv2d_cells).  Returns (out or None, pooled or None,
+        per-cell max |x| of what was written [N, W // cell_w])."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        w = np.ascontiguousarray(w_hwio, dtype=np.float32)
+        n, h, wd, cin = x.shape
+        assert w.shape[:3] == (3, 3, cin)
+        cout = w.shape[3]
+        out = np.empty((n, h, wd, cout), dtype=np.float32) if (need_full or not pool) else None
+        pooled = np.empty((n, h // 2, wd // 2, cout), dtype=np.float32) if pool else None
+        amax = np.zeros((n, wd // cell_w), dtype=np.float32)
+        vecs = [None if v is None else np.ascontiguousarray(v, dtype=np.float32) for v in (pre_a, pre_b, post_a, post_b)]
+        self._check(self._lib.kocr_conv2d_cells(self._h, _ptr(x), n, h, wd, cin, _ptr(w), cout, _ptr(vecs[0]), _ptr(vecs[1]),
+                                                int(bool(relu)), _ptr(vecs[2]), _ptr(vecs[3]), int(cell_w), int(cell_wv),
+                                                int(bool(pool)), _ptr(out), _ptr(pooled), _ptr(amax)))
+        return out, pooled, amax
 
     # -- arithmetic of the wide convolutions (include/kocr.h: KOCR_SPLIT_*) ---------------
     SPLIT_BF16X3, SPLIT_F16X2, SPLIT_F16X1 = 0, 1, 2

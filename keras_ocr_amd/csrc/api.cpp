@@ -1,6 +1,8 @@
 // api.cpp — the extern "C" surface declared in include/kocr.h (context, memory, profiler,
 // and the entry points that wrap the graphs).  No torch types: plain pointers and sizes.
 #include "common.h"
+#include <cmath>
+#include <algorithm>
 #include <algorithm>
 
 // ---------------------------------------------------------------------------------------
@@ -469,6 +471,74 @@ int kocr_conv2d_nhwc(kocr_ctx* ctx, const float* in, int N, int H, int W, int Ci
     rc = run();
   }
   // release the temporary layer's device buffers
+  hipStreamSynchronize(ctx->stream);
+  while (ctx->owned.size() > first_owned) {
+    hipFree(ctx->owned.back());
+    ctx->owned.pop_back();
+  }
+  return rc;
+}
+
+int kocr_conv2d_cells(kocr_ctx* ctx, const float* in, int N, int H, int W, int Cin, const float* w_hwio, int Cout,
+                      const float* pre_a, const float* pre_b, int relu, const float* post_a, const float* post_b,
+                      int cellW, int cellWv, int pool, float* out, float* pool_out, float* amax_out) {
+  if (!ctx || !in || !w_hwio || (!out && !pool) || (pool && !pool_out)) return KOCR_EINVAL;
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || cellW <= 0 || cellWv <= 0 || cellWv > cellW || W % cellW)
+    KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_conv2d_cells: bad shape");
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  KOCR_TRY(ctx->amax_begin());
+  const size_t first_owned = ctx->owned.size();
+  ConvLayer L;
+  L.name = "kocr_conv2d_cells";
+  int rc = prepare_conv(ctx, L, w_hwio, /*oihw=*/false, Cin, Cout, 3, 3, 1, pre_a, pre_b, relu, post_a, post_b);
+  const int cn = W / cellW;
+  const size_t nin = (size_t)N * H * W * Cin, nout = (size_t)N * H * W * Cout, npool = nout / 4;
+  if (rc == KOCR_OK) rc = ctx->ws_reserve((nin + (out ? nout : 0) + (pool ? npool : 0)) * sizeof(float) + 8192);
+  if (rc == KOCR_OK) {
+    ctx->ws_reset();
+    Tensor ti, to, tp;
+    ti.N = to.N = tp.N = N;
+    ti.H = to.H = H;
+    ti.W = to.W = W;
+    tp.H = H / 2;
+    tp.W = W / 2;
+    ti.C = ti.cs = Cin;
+    to.C = to.cs = tp.C = tp.cs = Cout;
+    ti.cellW = to.cellW = cellW;
+    ti.cellWv = to.cellWv = cellWv;
+    tp.cellW = cellW / 2;
+    tp.cellWv = cellWv / 2;
+    ti.p = (float*)ctx->ws_alloc(nin * sizeof(float));
+    to.p = out ? (float*)ctx->ws_alloc(nout * sizeof(float)) : nullptr;
+    tp.p = pool ? (float*)ctx->ws_alloc(npool * sizeof(float)) : nullptr;
+    ti.amax = ctx->amax_slots(N * cn);
+    to.amax = ctx->amax_slots(N * cn);
+    tp.amax = ctx->amax_slots(N * cn);
+    // the input's per-cell max |x| (its producer's job in the recogniser): computed here on the host
+    std::vector<float> am((size_t)N * cn, 0.f);
+    for (int n = 0; n < N; ++n)
+      for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+          const float* px = in + (((size_t)n * H + y) * W + x) * Cin;
+          float m = 0.f;
+          for (int c = 0; c < Cin; ++c) m = std::max(m, std::fabs(px[c]));
+          float& a = am[(size_t)n * cn + x / cellW];
+          a = std::max(a, m);
+        }
+    auto run = [&]() -> int {
+      if (!ti.amax || !to.amax || !tp.amax) KOCR_FAIL(ctx, KOCR_ECAPACITY, "kocr_conv2d_cells: out of max-|x| slots");
+      KOCR_HIP(ctx, hipMemcpyAsync(ti.p, in, nin * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+      KOCR_HIP(ctx, hipMemcpyAsync(ti.amax, am.data(), am.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+      KOCR_TRY(launch_conv_pool(ctx, L, ti, nullptr, nullptr, to, pool ? &tp : nullptr, /*need_full=*/out != nullptr));
+      if (out) KOCR_HIP(ctx, hipMemcpyAsync(out, to.p, nout * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+      if (pool) KOCR_HIP(ctx, hipMemcpyAsync(pool_out, tp.p, npool * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+      if (amax_out)
+        KOCR_HIP(ctx, hipMemcpyAsync(amax_out, pool && !out ? tp.amax : to.amax, am.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+      KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      return KOCR_OK;
+    };
+    rc = run();
+  }
   hipStreamSynchronize(ctx->stream);
   while (ctx->owned.size() > first_owned) {
     hipFree(ctx->owned.back());

@@ -54,6 +54,13 @@ struct Tensor {
   // whose width is not a multiple of 4 (the recogniser's 50-wide conv_6 / conv_7) run on the F(4,3) kernels at width 52.
   int Wv = 0;
   int wv() const { return Wv ? Wv : W; }
+  // Cell grid (0 = none; round 5, the recogniser's crop batch): every image is ONE ROW of W / cellW cells of cellW columns,
+  // each holding an independent crop in its columns [0, cellWv) and rows [1, H); row 0 and the columns [cellWv, cellW) of a
+  // cell are ZERO gutters that belong to the tensor (its producer writes them) -- the 'same' padding between neighbouring
+  // crops.  amax then holds one slot per CELL (image * cells() + cell).  Only conv_w43vh_kernel<.., MODE 2> takes and
+  // writes such tensors; launch_conv fails loudly for anything else.
+  int cellW = 0, cellWv = 0;
+  int cells() const { return cellW ? W / cellW : 0; }
   size_t pixels() const { return (size_t)N * H * W; }
   Tensor slice(int off, int c) const {
     Tensor t = *this;
@@ -273,10 +280,13 @@ int prepare_w43(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
 // fp16 piece, one product (KOCR_SPLIT_F16X1, the reduced-precision fast mode: 0.5).  launch_conv_w43 dispatches to it.
 struct W4Params;
 int prepare_w43h(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, const float* pre_a);
-int launch_w43vh(kocr_ctx* ctx, W4Params& p, bool fuse, int geo, int pieces);
-int launch_w43rh(kocr_ctx* ctx, W4Params& p, bool fuse, int pieces);
+// mode: 0 = the image tiles exactly, 1 = ragged (any H, W), 2 = cell grid (launch_w43vh, geo 1 only)
+int launch_w43vh(kocr_ctx* ctx, W4Params& p, bool fuse, int geo, int pieces, int mode = 0);
+int launch_w43rh(kocr_ctx* ctx, W4Params& p, bool fuse, int pieces, int mode = 0);
 int launch_w43fh(kocr_ctx* ctx, W4Params& p, int pieces);
 bool w43_applicable(const kocr_ctx* ctx, const ConvLayer& L, const Tensor& in);
+bool w43_cells_ok(const kocr_ctx* ctx, const ConvLayer& L);   // a cell-grid tensor (Tensor::cellW) can run through layer L
+bool w43_flat_h_ok(const kocr_ctx* ctx, const ConvLayer& L);  // a width-padded tensor (Tensor::Wv) can
 int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
                     bool need_full);
 // conv_dsplit.hip

@@ -661,6 +661,16 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
     mode = 1;
   const bool fuse_pool = pool && mode == 0 && variant == 0 && L.BN >= 64 && (in.H % 2 == 0) && (in.W % 64 == 0) &&
                          conv_variant() != 10;
+  // Layouts with zero padding that belongs to the tensor (cell grids, Tensor::cellW; width-padded rows, Tensor::Wv) are
+  // read and WRITTEN correctly by the fp16 F(4,3) kernels only: anything else fails here instead of silently writing
+  // convolution values into the padding
+  if (in.cellW || out.cellW || (pool && pool->cellW)) {
+    if (in_u8 || variant != 0 || conv_variant() != 0 || !w43_applicable(ctx, L, in))
+      KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": a cell-grid tensor needs the fp16 vertical-reuse F(4,3) kernel (disabled by a switch or the arithmetic mode)");
+    return launch_conv_w43(ctx, L, in, out, pool, need_full);
+  }
+  if (out.Wv && out.Wv < out.W && (in_u8 || variant != 0 || conv_variant() != 0 || !w43_applicable(ctx, L, in) || !w43_flat_h_ok(ctx, L)))
+    KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": a width-padded output (Tensor::Wv) needs the flattened fp16 F(4,3) kernel (disabled by a switch or the arithmetic mode)");
   if (!out.p) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": no output buffer");
   if (in_u8 && lut && conv_variant() == 0 && first_applicable(ctx, L, in)) {  // first layer from raw uint8 on the split path
     KOCR_TRY(launch_conv_first(ctx, L, in, in_u8, lut, out));  // maintains out.amax itself

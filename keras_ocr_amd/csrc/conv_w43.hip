@@ -1661,10 +1661,52 @@ int prepare_w43(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) {
   return KOCR_OK;
 }
 
+// Round 5: the fp16 vertical- / row-reuse kernels take any H, W (their MODE 1, "ragged": masked gather and stores) and the
+// recogniser's cell grids (MODE 2).  Which geometry a ragged image gets, or -1: `narrow` = the 64-cout row-reuse kernel
+// (4 x 64 tiles only), else the vertical-reuse kernel on 4 x 64 or 8 x 32 tiles, whichever covers the image with fewer
+// padding pixels (8 x 32 has no fused pooling).  A ragged grid is used when the image's width is not a multiple of 4 (the
+// flattened-pixel arrangements then do not apply at all) or when the padding costs less than the flattened arrangement
+// loses against vertical reuse (measured 20-30 %, plus the unfused pooling).
+static bool w43_env_off(const char* name) {
+  const char* e = getenv(name);
+  return e && atoi(e) == 0;
+}
+static int w43_ragged_geo(const kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, bool pool) {
+  static const bool no_v = w43_env_off("KOCR_W43V"), no_rr = w43_env_off("KOCR_W43R"), no_rag = w43_env_off("KOCR_W43RAG");
+  if (no_rag || ctx->split_mode == KOCR_SPLIT_BF16X3 || !ctx->sw.w43h || !L.d_w4h || L.dil != 1) return -1;
+  if ((size_t)in.H * in.W * in.cs * 4 >= ((size_t)1 << 31)) return -1;
+  const bool narrow = L.w4_cout_pad == 64;
+  if (narrow ? no_rr : no_v) return -1;
+  auto cover = [&](int rb, int tc) { return (double)((in.H + rb - 1) / rb * rb) * ((in.W + tc - 1) / tc * tc) / ((double)in.H * in.W); };
+  const double c1 = cover(4, 64), c2 = cover(8, 32);
+  const int geo = (narrow || pool || c1 <= c2 * 1.02) ? 1 : 2;
+  const double c = geo == 1 ? c1 : c2;
+  if (in.W % 4 != 0) return geo;                 // no flattened arrangement takes this width
+  if ((size_t)in.H * in.W < 256) return -1;      // tiny images stay where they were (bf16x3 flattened tiles)
+  return c <= 1.25 ? geo : -1;
+}
+
+// can layer L run on a cell grid (conv_w43vh_kernel MODE 2) in the context's current arithmetic?  KOCR_CELLS=0: never (the
+// recogniser then keeps round 4's dense crop batch on the flattened-pixel kernel)
+bool w43_cells_ok(const kocr_ctx* ctx, const ConvLayer& L) {
+  static const bool off = w43_env_off("KOCR_W43"), no_v = w43_env_off("KOCR_W43V"), no_cells = w43_env_off("KOCR_CELLS");
+  return !off && !no_v && !no_cells && ctx->split_mode != KOCR_SPLIT_BF16X3 && ctx->sw.w43h && L.d_w4h && L.w4_cout_pad > 64 &&
+         L.dil == 1 && L.Cin % 32 == 0;
+}
+// ... and the width-padded layout (Tensor::Wv) on the flattened fp16 kernel?
+bool w43_flat_h_ok(const kocr_ctx* ctx, const ConvLayer& L) {
+  static const bool off = w43_env_off("KOCR_W43");
+  return !off && ctx->split_mode != KOCR_SPLIT_BF16X3 && ctx->sw.w43h && L.d_w4h && L.w4_cout_pad > 64 && L.dil == 1 && L.Cin % 32 == 0;
+}
+
 bool w43_applicable(const kocr_ctx* ctx, const ConvLayer& L, const Tensor& in) {
   static const bool off = getenv("KOCR_W43") && atoi(getenv("KOCR_W43")) == 0;
-  return !off && L.d_w4 && in.W % (4 * L.dil) == 0 && in.cs % 4 == 0 &&
-         in.co % 4 == 0 && ((uintptr_t)in.p & 15) == 0 && L.Cin % 32 == 0 && (size_t)in.pixels() < ((size_t)1 << 29);
+  if (in.cellW) return w43_cells_ok(ctx, L);
+  if (off || !L.d_w4 || in.cs % 4 != 0 || in.co % 4 != 0 || ((uintptr_t)in.p & 15) != 0 || L.Cin % 32 != 0 ||
+      (size_t)in.pixels() >= ((size_t)1 << 29))
+    return false;
+  if (in.W % (4 * L.dil) == 0) return true;
+  return w43_ragged_geo(ctx, L, in, false) > 0;  // a width the flattened arrangements do not take
 }
 
 template <int POOL, int DBG = 0, int DIL = 0>
@@ -1756,7 +1798,20 @@ static int w4v_launch(kocr_ctx* ctx, W4Params& p) {
 }
 
 int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool, bool need_full) {
-  const bool fuse = pool && L.dil == 1 && in.H % 2 == 0 && in.W % 64 == 0;
+  // round 5: cell grids (the recogniser's crop batch) and ragged images on the fp16 vertical- / row-reuse kernels
+  const bool cells = in.cellW > 0;
+  if (cells || out.cellW || (pool && pool->cellW)) {
+    // tiles of 4 x 64 where a cell is at least 64 columns wide, else 8 x 32 (a tile may touch two cells, not three)
+    const bool cgeo_ok = in.cellW >= 64 ? (in.H % 4 == 0 && in.W % 64 == 0) : (in.cellW >= 32 && in.H % 8 == 0 && in.W % 32 == 0 && !pool);
+    const bool ok = cells && out.cellW == in.cellW && out.cellWv == in.cellWv && cgeo_ok && in.cellW % 4 == 0 &&
+                    in.W % in.cellW == 0 && in.amax && L.dil == 1 && L.w4_cout_pad > 64 && L.d_w4h && ctx->sw.w43h &&
+                    ctx->split_mode != KOCR_SPLIT_BF16X3 && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31) &&
+                    (!pool || (pool->cellW * 2 == in.cellW && pool->cellWv * 2 == in.cellWv && in.cellWv % 2 == 0 && pool->H * 2 == in.H &&
+                               pool->W * 2 == in.W));
+    if (!ok) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": a cell-grid tensor (Tensor::cellW) needs the fp16 vertical-reuse F(4,3) kernel");
+  }
+  const int rag_geo = cells ? -1 : w43_ragged_geo(ctx, L, in, pool != nullptr);
+  const bool exact_fuse = pool && L.dil == 1 && in.H % 2 == 0 && in.W % 64 == 0;
   const size_t M = in.pixels();
   W4Params p;
   p.in = in.p;
@@ -1787,37 +1842,68 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   p.amax_in = nullptr;
   p.Wv = (out.Wv && out.Wv < out.W) ? out.Wv : 0;
   w4_div_magic((unsigned)in.W, p.dv_w);
-  if (fuse) {
-    p.pool_out = pool->p;
-    p.pool_cs = pool->cs;
-    p.pool_co = pool->co;
-    p.write_full = need_full ? 1 : 0;
-    p.tiles_per_row = in.W / 64;
-  }
   const bool narrow = L.w4_cout_pad == 64;  // 64-cout arrangement: 4 M-tiles x 64 couts per tile
   // ... or, when the image tiles as 2 rows x 128 columns, the row-reuse arrangement (2 M-tiles of 2 rows x 64 columns)
   static const bool no_rr = getenv("KOCR_W43R") && atoi(getenv("KOCR_W43R")) == 0;
   static const int geo_env = getenv("KOCR_W43V_GEO") ? atoi(getenv("KOCR_W43V_GEO")) : -1;  // developer switch: force a geometry
-  const bool r_ok = narrow && !no_rr && L.dil == 1 && (!pool || fuse) && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31);
+  const bool r_ok = narrow && !no_rr && L.dil == 1 && (!pool || exact_fuse) && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31);
   const bool rgeo1_ok = r_ok && in.H % 4 == 0 && in.W % 64 == 0, rgeo0_ok = r_ok && in.H % 2 == 0 && in.W % 128 == 0;
-  const int rgeo = (rgeo1_ok && geo_env != 0) ? 1 : (rgeo0_ok && geo_env != 1) ? 0 : rgeo1_ok ? 1 : -1;
+  int rgeo = (rgeo1_ok && geo_env != 0) ? 1 : (rgeo0_ok && geo_env != 1) ? 0 : rgeo1_ok ? 1 : -1;
+  // mode of the fp16 kernels: 0 = the image tiles exactly, 1 = ragged (masked gather / stores), 2 = cell grid
+  int mode = cells ? 2 : 0;
+  if (rgeo < 0 && narrow && rag_geo == 1) {
+    rgeo = 1;
+    mode = 1;
+  }
   const bool rowreuse = rgeo >= 0;
   // Cout > 64 on the same image geometry: the vertical-reuse arrangement (conv_w43v_kernel)
   static const bool no_v = getenv("KOCR_W43V") && atoi(getenv("KOCR_W43V")) == 0;
   // geometries of conv_w43v_kernel: GEO 1 = 4 rows x 64 columns (H % 4 == 0, W % 64 == 0), GEO 2 = 8 rows x 32 columns
   // (H % 8 == 0, W % 32 == 0, no fused pooling).  KOCR_W43V_GEO=2 forces GEO 2 where both apply (developer switch; the
   // same variable = 0 / 1 picks the row-reuse kernel's 2 x 128 / 4 x 64 geometry above where both apply)
-  const bool v_ok = !narrow && !no_v && L.dil == 1 && (!pool || fuse) && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31);
+  const bool v_ok = !narrow && !no_v && L.dil == 1 && (!pool || exact_fuse) && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31);
   // 4 rows x 64 columns where the image tiles that way, else 8 rows x 32 columns (the 96-wide layers); anything else (e.g.
   // H % 4 != 0) stays on conv_w43_kernel
   const bool geo1_ok = v_ok && in.H % 4 == 0 && in.W % 64 == 0;
   const bool geo2_ok = v_ok && !pool && in.H % 8 == 0 && in.W % 32 == 0;
-  const int vgeo = geo_env == 2 ? (geo2_ok ? 2 : -1) : geo1_ok ? 1 : geo2_ok ? 2 : -1;
+  int vgeo = geo_env == 2 ? (geo2_ok ? 2 : -1) : geo1_ok ? 1 : geo2_ok ? 2 : -1;
+  if (cells) vgeo = in.cellW >= 64 ? 1 : 2;
+  if (vgeo < 0 && !narrow && rag_geo > 0) {
+    vgeo = rag_geo;
+    mode = 1;
+  }
   const bool vreuse = vgeo >= 0;
+  // the fused 2x2 pooling: images that tile exactly as 2 rows x 64 columns (any arrangement), or the 4 x 64 ragged / cell grids
+  const bool fuse = exact_fuse || (pool && mode != 0 && (vreuse ? vgeo == 1 : rgeo == 1));
+  if (fuse) {
+    if (pool->H != in.H / 2 || pool->W != in.W / 2 || pool->N != in.N) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": bad pooled shape");
+    p.pool_out = pool->p;
+    p.pool_cs = pool->cs;
+    p.pool_co = pool->co;
+    p.write_full = need_full ? 1 : 0;
+    p.tiles_per_row = in.W / 64;
+  }
+  if (!out.p && !(fuse && !need_full)) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": no output buffer");
   if ((rowreuse || vreuse) && !fuse) p.tiles_per_row = in.W / 64;  // the 2-row x 64-column M-tile geometry without the pooling
   p.n_mpairs = (rowreuse || vreuse) ? p.total_mtiles / 2 : narrow ? (p.total_mtiles + 3) / 4 : (p.total_mtiles + 1) / 2;
-  p.total_tiles = p.n_mpairs * (p.Cout_pad / (narrow ? 64 : 128));
   if (vgeo == 2) p.tiles_per_row = in.W / 32;
+  p.rq_per_img = 0;
+  p.cellW = p.cellWv = p.cells_per_row = 0;
+  if (mode != 0) {  // the ragged / cell tile grid: ceil(H / 4) x ceil(W / 64) (ceil(H / 8) x ceil(W / 32)) tiles per image
+    const int rb = (vreuse && vgeo == 2) ? 8 : 4, tc = (vreuse && vgeo == 2) ? 32 : 64;
+    p.tiles_per_row = (in.W + tc - 1) / tc;
+    p.rq_per_img = (in.H + rb - 1) / rb;
+    p.n_mpairs = in.N * p.rq_per_img * p.tiles_per_row;
+    p.total_mtiles = 2 * p.n_mpairs;
+    if (cells) {
+      p.cellW = in.cellW;
+      p.cellWv = in.cellWv;
+      p.cells_per_row = in.W / in.cellW;
+    }
+  }
+  w4_div_magic((unsigned)(p.rq_per_img ? p.rq_per_img : 1), p.dv_rq);
+  w4_div_magic((unsigned)(p.cellW ? p.cellW : 1), p.dv_wc);
+  p.total_tiles = p.n_mpairs * (p.Cout_pad / (narrow ? 64 : 128));
   w4_div_magic((unsigned)p.tiles_per_row, p.dv_tpr);
   w4_div_magic((unsigned)(vgeo == 2 ? in.H / 8 : in.H / 2), p.dv_hh);
   w4_div_magic((unsigned)p.n_mpairs, p.dv_mp);
@@ -1831,6 +1917,7 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   const bool flat_h = pieces && !no_h && L.d_w4h && !narrow && !vreuse && !rowreuse && L.dil == 1 && !fuse &&
                       (size_t)in.H * in.W >= 256;
   const bool use_h = (pieces && !no_h && L.d_w4h && (vreuse || (rowreuse && rgeo == 1))) || flat_h;
+  if (mode != 0 && !use_h) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": ragged / cell grids exist in the fp16 kernels only");
   if (p.Wv && !flat_h)  // only the flattened fp16 kernel writes the zero columns of a width-padded output
     KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": a width-padded output (Tensor::Wv) needs the flattened fp16 F(4,3) kernel");
   const bool tracks = rowreuse || vreuse || flat_h;
@@ -1859,11 +1946,13 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
-    snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s:%s", use_h ? (pieces == 2 ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : (flat_h ? "f" : use_h ? "r" : "s"), rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), L.name.c_str());
+    snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s%s:%s", use_h ? ((pieces == 2 || mode) ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : (flat_h ? "f" : use_h ? "r" : "s"), rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), mode == 1 ? "g" : mode == 2 ? "c" : "", L.name.c_str());
   else
-    snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s", use_h ? (pieces == 2 ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : (flat_h ? "f" : use_h ? "r" : "s"), rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""));
-  const double flops = 2.0 * (double)M * L.Kreal * L.Cout;  // algorithmic (direct-convolution) FLOPs
-  const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
+    snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s%s", use_h ? ((pieces == 2 || mode) ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : (flat_h ? "f" : use_h ? "r" : "s"), rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""), mode == 1 ? "_rag" : mode == 2 ? "_cells" : "");
+  // algorithmic (direct-convolution) FLOPs and bytes: of the crops' own pixels in a cell grid, not of the gutters
+  const double Malg = cells ? (double)in.N * in.cells() * (in.H - 1) * in.cellWv : (double)M;
+  const double flops = 2.0 * Malg * L.Kreal * L.Cout;
+  const double bytes = 4.0 * (Malg * L.Cin + Malg * L.Cout * ((fuse && !need_full) ? 0.25 : 1.0) + (double)L.Kreal * L.Cout);
   {
     ProfScope ps(ctx, nm, flops, bytes);
 #ifdef KOCR_DEV_SWITCHES
@@ -1890,11 +1979,11 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
     }
 #endif
     if (use_h && vreuse) {
-      KOCR_TRY(launch_w43vh(ctx, p, fuse, vgeo, pieces));
+      KOCR_TRY(launch_w43vh(ctx, p, fuse, vgeo, pieces, mode));
     } else if (flat_h) {
       KOCR_TRY(launch_w43fh(ctx, p, pieces));
     } else if (use_h) {
-      KOCR_TRY(launch_w43rh(ctx, p, fuse, pieces));
+      KOCR_TRY(launch_w43rh(ctx, p, fuse, pieces, mode));
     } else if (vreuse) {
       if (vgeo == 2) {
         KOCR_TRY((w4v_launch<0, 2>(ctx, p)));

@@ -55,11 +55,29 @@ constexpr int W4H_TOP = 12;  // scaled inputs lie below 2^13: 5.28 x 2^13 < 65 5
 // DBG (developer timing experiments, WRONG results; only instantiated with -DKOCR_DEV_SWITCHES): 1 = no input transform /
 // split VALU work, 2 = no weight stream, 4 = no MFMAs, 8 = no LDS operand fetches, 16 = no raw input loads, 32 = no block
 // barrier in the K loop
-template <int POOL, int GEO, int NP, int DBG = 0>
+//
+// MODE (round 5): 0 = the image tiles exactly (H % 4 == 0, W % 64 == 0, or H % 8 == 0, W % 32 == 0): the code of round 4.
+//   1 = RAGGED: any H, W (dense layout).  The tile grid covers ceil(H / 4) x ceil(W / 64) (ceil(H / 8) x ceil(W / 32)) tiles
+//       per image; the gather masks the taps whose column lies outside the image (a bit per tap in Geo::ok -- in the dense
+//       layout "column W" is the next row's first pixel), rows outside are masked as before, the epilogue drops the stores
+//       (full-resolution and pooled) of positions outside the image.  The per-image max-|x| slot then also sees the values
+//       computed at those positions (their inputs are the image's own border pixels): still an upper bound that depends
+//       on nothing but the image.
+//   2 = CELLS: every image is one row of `cells_per_row` cells of cellW columns (cellW % 4 == 0),
+//       each holding one independent crop in its columns [0, cellWv) and rows [1, H): row 0 and the columns behind cellWv
+//       are ZERO gutters -- exactly the 'same' padding between neighbouring crops -- which this kernel reads as data and
+//       writes as zeros.  The recogniser's crop batch (crnn.cpp): 31 x 200 / 15 x 100 / 7 x 50 crops in cells of
+//       32 x 208 / 16 x 104 / 8 x 52, so that the vertical-reuse arrangement (and its fused pooling: the zero row on top makes
+//       the pooling windows of rows (2 i + 1, 2 i + 2) aligned) applies to them.  One input scale and one max-|x| slot per CELL
+//       (slot index image * cells_per_row + cell): a tile must touch at most TWO cells (the launcher takes 8 x 32 tiles where a
+//       cell is narrower than 64 columns -- a 64-column tile over 52-column cells can touch three), so a producer thread picks
+//       the scale of ITS quad's cell and the epilogue undoes it per accumulator row.
+template <int POOL, int GEO, int NP, int DBG = 0, int MODE = 0>
 __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
   static_assert(GEO == 1 || GEO == 2, "4 x 64 or 8 x 32 tiles");
   static_assert(!(POOL && GEO == 2), "no fused pooling on 8 x 32 tiles");
   static_assert(NP == 1 || NP == 2, "one or two fp16 pieces");
+  static_assert(MODE == 0 || MODE == 1 || MODE == 2, "exact tiling, ragged, cells");
   constexpr int PR = NP == 2 ? 3 : 1;        // products per point and M-tile
   constexpr int NROWS = GEO == 2 ? 10 : 6;  // input rows of the tile's window
   constexpr int QPR = GEO == 2 ? 8 : 16;    // quads per tile row
@@ -89,8 +107,16 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
       return w * ROW_STRIDE + kh * KHS + ((q * 8) ^ (kh * 32));
   };
   // first pixel of pixel tile mp (flattened (n, y, x) index), its row and column
-  auto tile_org = [&](int mp, int& y0, int& x0) -> long {
-    if constexpr (GEO == 2) {
+  auto tile_org = [&](int mp, int& y0, int& x0, int& nimg_o) -> long {
+    if constexpr (MODE != 0) {
+      // ragged / cell grids: rq = (image, row block), rq_per_img = ceil(H / 4) (ceil(H / 8))
+      const int rq = (int)w4_fdiv((unsigned)mp, p.dv_tpr), cb = mp - rq * p.tiles_per_row;
+      const int nimg = (int)w4_fdiv((unsigned)rq, p.dv_rq), ro = rq - nimg * p.rq_per_img;
+      y0 = (GEO == 2 ? 8 : 4) * ro;
+      x0 = TCOLS * cb;
+      nimg_o = nimg;
+      return ((long)nimg * p.H + y0) * p.W + x0;
+    } else if constexpr (GEO == 2) {
       const int rq = (int)w4_fdiv((unsigned)mp, p.dv_tpr), cb = mp - rq * p.tiles_per_row;  // (image, row octet), column block
       const int ho = p.H >> 3;
       const int nimg = (int)w4_fdiv((unsigned)rq, p.dv_hh), ro = rq - nimg * ho;
@@ -113,15 +139,17 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
   ldst[1] = slot(r1, cp >> 2, qd1) + (cp & 3) * 2;
   struct Geo {
     unsigned off0[2];  // byte offset of raw pixel d0 of each item
-    unsigned ok;       // bit it: the item's input row lies inside the image (and the tile exists)
-    int e;             // exponent of the image's input scale 2^e
+    unsigned ok;       // bit it: the item's input row lies inside the image (and the tile exists); MODE 1: bit 2 + 6 it + k
+                       // set = tap k of item `it` lies in a column outside the image
+    int e;             // exponent of the image's input scale 2^e (MODE 2: of the tile's first cell)
+    int e1, qb;        // MODE 2: exponent of the tile's second cell; first quad of a tile row that lies in it (QPR: none)
     const float* base;
   };
   auto make_geo = [&](int L, Geo& g, bool& left, bool& right) __attribute__((always_inline)) {
     int mp, nt_unused;
     w4_decode(p, kocr_xcd_remap(L < total ? L : 0, total), nblk_n, mp, nt_unused);
-    int y0, x0;
-    const long pm = tile_org(mp, y0, x0);
+    int y0, x0, nimg = 0;
+    const long pm = tile_org(mp, y0, x0, nimg);
     g.base = p.in + (pm * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
     // the thread's item coordinates again, from a fresh lane id (kocr_fresh_lane: nothing of this per-tile code is kept
     // alive -- spilled -- across the K loop)
@@ -134,10 +162,35 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
     g.off0[1] = (unsigned)(((r1 * p.W + 4 * qd1) * p.in_cs + cp * 2) * 4);
     g.ok = ((L < total && (unsigned)(y0 - 1 + r0) < (unsigned)p.H) ? 1u : 0u) |
            ((L < total && (unsigned)(y0 - 1 + r1) < (unsigned)p.H) ? 2u : 0u);
-    g.e = kocr_scale_exp_bits(kocr_sload(p.amax_in + __builtin_amdgcn_readfirstlane((int)w4_fdiv((unsigned)pm, p.dv_hw))), W4H_TOP);
-    // d0 / d5 are column zero padding only at the image edges (W is a multiple of the tile width)
-    left = x0 == 0;
-    right = x0 + TCOLS >= p.W;
+    g.e1 = 0;
+    g.qb = QPR;
+    if constexpr (MODE == 2) {
+      const int j0 = (int)w4_fdiv((unsigned)x0, p.dv_wc);
+      const int j1 = j0 + 1 < p.cells_per_row ? j0 + 1 : j0;
+      const int c0 = __builtin_amdgcn_readfirstlane(nimg * p.cells_per_row + j0), c1 = __builtin_amdgcn_readfirstlane(nimg * p.cells_per_row + j1);
+      g.e = kocr_scale_exp_bits(kocr_sload(p.amax_in + c0), W4H_TOP);
+      g.e1 = kocr_scale_exp_bits(kocr_sload(p.amax_in + c1), W4H_TOP);
+      const int qb = ((j0 + 1) * p.cellW - x0) >> 2;
+      g.qb = qb < QPR ? qb : QPR;
+    } else if constexpr (MODE == 1) {
+      g.e = kocr_scale_exp_bits(kocr_sload(p.amax_in + __builtin_amdgcn_readfirstlane(nimg)), W4H_TOP);
+    } else {
+      g.e = kocr_scale_exp_bits(kocr_sload(p.amax_in + __builtin_amdgcn_readfirstlane((int)w4_fdiv((unsigned)pm, p.dv_hw))), W4H_TOP);
+    }
+    if constexpr (MODE == 1) {
+      // the taps' columns one by one: x0 - 1 + 4 qd + k must lie in [0, W)
+      const int c0 = x0 - 1 + 4 * qd0, c1 = x0 - 1 + 4 * qd1;
+      unsigned cm = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        cm |= ((unsigned)(c0 + k) < (unsigned)p.W ? 0u : (4u << k)) | ((unsigned)(c1 + k) < (unsigned)p.W ? 0u : (256u << k));
+      g.ok |= cm;
+      left = right = false;
+    } else {
+      // d0 / d5 are column zero padding only at the image edges (W is a multiple of the tile width)
+      left = x0 == 0;
+      right = x0 + TCOLS >= p.W;
+    }
   };
   Geo gc, gn;
   bool lc, rc, ln, rn;
@@ -146,14 +199,16 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
   auto load_item0 = [&](v4f (&raw)[6]) __attribute__((always_inline)) {
     if constexpr (DBG & 16) return;
     const int soff = ld_cg * 64;
-    const bool ok = (ld_next ? gn.ok : gc.ok) & 1u;
+    const unsigned okb = ld_next ? gn.ok : gc.ok;
+    const bool ok = okb & 1u;
     const unsigned off0 = (ld_next ? gn.off0[0] : gc.off0[0]) | (ok ? 0u : OOB);
     const bool left = (ld_next ? ln : lc) && qd0 == 0, right = (ld_next ? rn : rc) && qd0 == QPR - 1;
     const unsigned stride = (unsigned)(p.in_cs * 4);
     const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const unsigned padk = (k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u);
+      const unsigned padk = MODE == 1 ? ((okb << (29 - k)) & OOB)  // bit 2 + k -> bit 31
+                                      : ((k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u));
       if constexpr (DBG & 128)  // the same instructions and bytes, lane-contiguous (1 KB per instruction), cache-resident
         raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(w4_rsrc(p.in, 0x80000000u), (unsigned)((tid & 63) * 16 + (tid >> 6) * 8192 + k * 1024), soff & 0xFFF, 0));
       else if constexpr (DBG & 64)  // the same instructions and bytes, but from a 256 KB cache-resident window
@@ -165,14 +220,16 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
   auto load_item1 = [&](v2f (&raw)[6]) __attribute__((always_inline)) {
     if constexpr (DBG & 16) return;
     const int soff = ld_cg * 64;
-    const bool ok = ((ld_next ? gn.ok : gc.ok) >> 1) & 1u;
+    const unsigned okb = ld_next ? gn.ok : gc.ok;
+    const bool ok = (okb >> 1) & 1u;
     const unsigned off0 = (ld_next ? gn.off0[1] : gc.off0[1]) | (ok ? 0u : OOB);
     const bool left = (ld_next ? ln : lc) && qd1 == 0, right = (ld_next ? rn : rc) && qd1 == QPR - 1;
     const unsigned stride = (unsigned)(p.in_cs * 4);
     const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const unsigned padk = (k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u);
+      const unsigned padk = MODE == 1 ? ((okb << (23 - k)) & OOB)  // bit 8 + k -> bit 31
+                                      : ((k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u));
       if constexpr (DBG & 128)
         raw[k] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(w4_rsrc(p.in, 0x80000000u), (unsigned)((tid & 63) * 8 + (tid >> 6) * 8192 + 6144 + k * 512), soff & 0xFFF, 0));
       else if constexpr (DBG & 64)
@@ -186,8 +243,11 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
     ld_cg = wrap ? 0 : ld_cg + 1;
     ld_next = ld_next || wrap;
   };
-  // sk = 2^e of the channel group being PRODUCED (it may already belong to the next tile's image)
-  auto produce4 = [&](const v4f (&d)[6], unsigned short* bufp, int xi, int it, float sk) __attribute__((always_inline)) {
+  // sc = the scale(s) 2^e of the channel group being PRODUCED (it may already belong to the next tile's image): one per tile,
+  // or (MODE 2) those of the tile's two cells and the first quad of the second one -- a thread takes its quad's
+  // (plain scalars: a struct of them captured by these lambdas ends up in scratch memory)
+  auto produce4 = [&](const v4f (&d)[6], unsigned short* bufp, int xi, int it, float sc0, float sc1, int scq) __attribute__((always_inline)) {
+    const float sk = MODE == 2 ? (qd0 < scq ? sc0 : sc1) : sc0;
     unsigned short* dst = bufp + xi * NP * PLANE_R + ldst[it];
     if constexpr (DBG & 1) {
       const u2v r = __builtin_bit_cast(u2v, __builtin_shufflevector(d[xi], d[xi], 0, 1));
@@ -195,8 +255,15 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
       if constexpr (NP == 2) *reinterpret_cast<u2v*>(dst + PLANE_R) = r;
       return;
     }
-    W4H_SCALED_CONSTANTS(sk);
-    const v4f V = w4h_transform(d, xi, k_s, k_sA, k_sB, k_sA2, k_sB2, k_sA2B2, k_sA2PB2);
+    v4f V;
+    if constexpr (MODE == 2) {
+      // a per-THREAD scale: folded into the constants it would hold seven more registers across the step (they spill);
+      // scaling the transformed value costs one multiply per component and gives the same bits (a power of two)
+      V = w4_transform(d, xi) * sk;
+    } else {
+      W4H_SCALED_CONSTANTS(sk);
+      V = w4h_transform(d, xi, k_s, k_sA, k_sB, k_sA2, k_sB2, k_sA2B2, k_sA2PB2);
+    }
     if constexpr (NP == 2) {
       u2v h, l;
       kocr_split4_h(V, h, l);
@@ -207,7 +274,8 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
                                          __builtin_bit_cast(unsigned, hf2{(_Float16)V[2], (_Float16)V[3]})};
     }
   };
-  auto produce2 = [&](const v2f (&d)[6], unsigned short* bufp, int xi, float sk) __attribute__((always_inline)) {
+  auto produce2 = [&](const v2f (&d)[6], unsigned short* bufp, int xi, float sc0, float sc1, int scq) __attribute__((always_inline)) {
+    const float sk = MODE == 2 ? (qd1 < scq ? sc0 : sc1) : sc0;
     unsigned short* dst = bufp + xi * NP * PLANE_R + ldst[1];
     if constexpr (DBG & 1) {
       const unsigned r = __float_as_uint(d[xi][0]);
@@ -215,8 +283,13 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
       if constexpr (NP == 2) *reinterpret_cast<unsigned*>(dst + PLANE_R) = r;
       return;
     }
-    W4H_SCALED_CONSTANTS(sk);
-    const v2f V = w4h_transform(d, xi, k_s, k_sA, k_sB, k_sA2, k_sB2, k_sA2B2, k_sA2PB2);
+    v2f V;
+    if constexpr (MODE == 2) {
+      V = w4_transform(d, xi) * sk;
+    } else {
+      W4H_SCALED_CONSTANTS(sk);
+      V = w4h_transform(d, xi, k_s, k_sA, k_sB, k_sA2, k_sB2, k_sA2B2, k_sA2PB2);
+    }
     if constexpr (NP == 2) {
       unsigned h, l;
       kocr_split2_h(V, h, l);
@@ -282,7 +355,7 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
   // the weights; the weights of the step after next (byte offset w_next) replace them point by point.  a0 holds point 0 of this step on entry and point 0 of the next step on
   // exit; for KY = 2 the next step lives in `bufn`, published by the block barrier before the last point's MFMAs.
   hf8 a0[2][NP], a1[2][NP];
-  auto step = [&](auto ky_c, auto slot_c, const unsigned short* bufc, unsigned short* bufn, unsigned w_next, float sk) __attribute__((always_inline)) {
+  auto step = [&](auto ky_c, auto slot_c, const unsigned short* bufc, unsigned short* bufn, unsigned w_next, float sc0, float sc1, int scq) __attribute__((always_inline)) {
     constexpr int KY = decltype(ky_c)::value;
     constexpr int SLOT = decltype(slot_c)::value;
     auto load_b = [&](int xi) __attribute__((always_inline)) {
@@ -292,8 +365,8 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
         bw[SLOT][xi][s] = __builtin_bit_cast(hf8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (int)(w_next + (unsigned)(xi * 2 + s) * 1024u), 0));
     };
     auto produce = [&](int xi) __attribute__((always_inline)) {
-      if constexpr (KY == 0) produce4(raw0, bufn, xi, 0, sk);
-      if constexpr (KY == 1) produce2(raw1, bufn, xi, sk);
+      if constexpr (KY == 0) produce4(raw0, bufn, xi, 0, sc0, sc1, scq);
+      if constexpr (KY == 1) produce2(raw1, bufn, xi, sc0, sc1, scq);
     };
     auto interleave = [&]() __attribute__((always_inline)) {
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);  // the LDS fetches of the next point first
@@ -362,8 +435,8 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
   }
 #pragma unroll
   for (int xi = 0; xi < 6; ++xi) {
-    produce4(raw0, As, xi, 0, kocr_pow2(gc.e));
-    produce2(raw1, As, xi, kocr_pow2(gc.e));
+    produce4(raw0, As, xi, 0, kocr_pow2(gc.e), kocr_pow2(gc.e1), gc.qb);
+    produce2(raw1, As, xi, kocr_pow2(gc.e), kocr_pow2(gc.e1), gc.qb);
   }
   load_item0(raw0);
   load_item1(raw1);
@@ -382,7 +455,11 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
     // byte offset of step s of this tile; steps ns, ns + 1 are the next tile's first two
     auto w_at = [&](int s) { return s < ns ? w_ptr + (unsigned)s * w_step : w_after + (unsigned)(s - ns) * w_step; };
     const float s_cur = kocr_pow2(gc.e), s_nxt = kocr_pow2(gn.e);
+    const float s_cur1 = kocr_pow2(gc.e1), s_nxt1 = kocr_pow2(gn.e1);  // MODE 2: the second cell's
+    const int qb_nxt = gn.qb;
     const float unscale = kocr_pow2(-gc.e);  // this tile's accumulators carry 2^(e + wexp[o]); wexp is folded into pre_a
+    const float unscale1 = kocr_pow2(-gc.e1);  // MODE 2: ... of the quads in the tile's second cell
+    const int qb_cur = gc.qb;
 #pragma unroll
     for (int x = 0; x < 6; ++x)
 #pragma unroll
@@ -395,20 +472,22 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>;
-      step(I0{}, I0{}, As, As + BUF_R, w_at(3 * cg + 2), s_cur);
+      step(I0{}, I0{}, As, As + BUF_R, w_at(3 * cg + 2), s_cur, s_cur1, qb_cur);
       load_item0(raw0);
-      step(I1{}, I1{}, As, As + BUF_R, w_at(3 * cg + 3), s_cur);
+      step(I1{}, I1{}, As, As + BUF_R, w_at(3 * cg + 3), s_cur, s_cur1, qb_cur);
       load_item1(raw1);
       advance();
-      step(I2{}, I0{}, As, As + BUF_R, w_at(3 * cg + 4), s_cur);
+      step(I2{}, I0{}, As, As + BUF_R, w_at(3 * cg + 4), s_cur, s_cur1, qb_cur);
       // odd channel group: consume buffer 1, produce the next even one (the next tile's first after the last pair) into 0
-      const float s_odd = cg + 2 < ncg ? s_cur : s_nxt;
-      step(I0{}, I1{}, As + BUF_R, As, w_at(3 * cg + 5), s_odd);
+      const bool same = cg + 2 < ncg;
+      const float s_odd = same ? s_cur : s_nxt, s_odd1 = same ? s_cur1 : s_nxt1;
+      const int qb_odd = same ? qb_cur : qb_nxt;
+      step(I0{}, I1{}, As + BUF_R, As, w_at(3 * cg + 5), s_odd, s_odd1, qb_odd);
       load_item0(raw0);
-      step(I1{}, I0{}, As + BUF_R, As, w_at(3 * cg + 6), s_odd);
+      step(I1{}, I0{}, As + BUF_R, As, w_at(3 * cg + 6), s_odd, s_odd1, qb_odd);
       load_item1(raw1);
       advance();
-      step(I2{}, I1{}, As + BUF_R, As, w_at(3 * cg + 7), s_odd);
+      step(I2{}, I1{}, As + BUF_R, As, w_at(3 * cg + 7), s_odd, s_odd1, qb_odd);
     }
     PROBE_T(0);
 
@@ -419,28 +498,54 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
       const int lane_e = kocr_fresh_lane();
       const int l31e = lane_e & 31, l5e = lane_e >> 5;
       const int n = (nt * 4 + wn) * 32 + l31e;
-      int ty0, tx0;
-      const long tpm = tile_org(mp, ty0, tx0);
-      const int nimg = __builtin_amdgcn_readfirstlane((int)w4_fdiv((unsigned)tpm, p.dv_hw));  // the tile lies inside one image
+      int ty0, tx0, timg = 0;
+      const long tpm = tile_org(mp, ty0, tx0, timg);
+      // slot index of the tile's image (MODE 2: of its first cell, nimg1 = of its second one)
+      int nimg, nimg1 = 0, cell0_x = 0;
+      if constexpr (MODE == 2) {
+        const int j0 = (int)w4_fdiv((unsigned)tx0, p.dv_wc);
+        const int j1 = j0 + 1 < p.cells_per_row ? j0 + 1 : j0;
+        nimg = __builtin_amdgcn_readfirstlane(timg * p.cells_per_row + j0);
+        nimg1 = __builtin_amdgcn_readfirstlane(timg * p.cells_per_row + j1);
+        cell0_x = j0 * p.cellW;
+      } else if constexpr (MODE == 1) {
+        nimg = __builtin_amdgcn_readfirstlane(timg);
+      } else {
+        nimg = __builtin_amdgcn_readfirstlane((int)w4_fdiv((unsigned)tpm, p.dv_hw));  // the tile lies inside one image
+      }
       const unsigned seen_out = p.amax_out ? kocr_amax_peek(p.amax_out + nimg) : 0u;
       const unsigned seen_pool = p.amax_pool ? kocr_amax_peek(p.amax_pool + nimg) : 0u;
+      unsigned seen_out1 = 0u, seen_pool1 = 0u;
+      if constexpr (MODE == 2) {
+        seen_out1 = p.amax_out ? kocr_amax_peek(p.amax_out + nimg1) : 0u;
+        seen_pool1 = p.amax_pool ? kocr_amax_peek(p.amax_pool + nimg1) : 0u;
+      }
       const float pa = coef[n] * unscale, pb = coef[p.Cout_pad + n];  // pre_a here = pre_a 2^-wexp[o] (ConvLayer::d_pre_a_h)
+      const float pa1 = coef[n] * unscale1;                             // MODE 2: for the quads of the tile's second cell
       const bool has_post = p.post_a != nullptr;
       const float qa = coef[2 * p.Cout_pad + n], qb = coef[3 * p.Cout_pad + n];
       const bool live = n < p.Cout;
       const float lo = p.relu ? 0.f : -INFINITY;
-      auto act = [&](float v) { return fmaxf(v * pa + pb, lo); };
+      auto act = [&](float v, float a) { return fmaxf(v * a + pb, lo); };
+      // MODE 2: quad column (inside the tile row) of accumulator register r of M-tile m, and whether it lies in the tile's
+      // first row: 4 x 64 tiles: M-tile = 2 rows x 16 quads, quad (r & 3) + 8 ((r >> 2) & 1) + 4 l5 of row r >> 3;
+      // 8 x 32 tiles: M-tile = 4 rows x 8 quads, quad (r & 3) + 4 l5 of row r >> 2
+      const int l5q = 4 * l5e;
+      auto qx_of = [&](int r) { return GEO == 2 ? (r & 3) + l5q : (r & 3) + 8 * ((r >> 2) & 1) + l5q; };
+      auto first_row = [&](int m, int r) { return m == 0 && (GEO == 2 ? (r >> 2) == 0 : r < 8); };
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          float par = pa;
+          if constexpr (MODE == 2) par = qx_of(r) < qb_cur ? pa : pa1;
           const float m0 = acc[0][m][r], m1 = acc[1][m][r], m2 = acc[2][m][r], m3 = acc[3][m][r], m4 = acc[4][m][r],
                       m5 = acc[5][m][r];
           const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-          acc[0][m][r] = act((m0 + s12) + s34);
-          acc[1][m][r] = act(W4_A * d12 + W4_B * d34);
-          acc[2][m][r] = act(W4_A2 * s12 + W4_B2 * s34);
-          acc[3][m][r] = act((W4_A3 * d12 + W4_B3 * d34) + m5);
+          acc[0][m][r] = act((m0 + s12) + s34, par);
+          acc[1][m][r] = act(W4_A * d12 + W4_B * d34, par);
+          acc[2][m][r] = act(W4_A2 * s12 + W4_B2 * s34, par);
+          acc[3][m][r] = act((W4_A3 * d12 + W4_B3 * d34) + m5, par);
         }
       if (has_post) {
 #pragma unroll
@@ -450,35 +555,77 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][m][r] = acc[j][m][r] * qa + qb;
       }
+      if constexpr (MODE == 2) {
+        // the gutters are written as zeros: row 0 of the image (every cell's top row) and the columns behind cellWv
+        const bool top = ty0 == 0;  // uniform
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qx = qx_of(r);
+          const int cx = tx0 + 4 * qx - (qx < qb_cur ? cell0_x : cell0_x + p.cellW);  // column inside the quad's cell
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool v = cx + j < p.cellWv;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[j][m][r] = (v && !(top && first_row(m, r))) ? acc[j][m][r] : 0.f;
+          }
+        }
+      }
       int ocs4 = p.out_cs * 4;
       asm volatile("" : "+s"(ocs4));
       int pcs4 = p.pool_cs * 4;
       asm volatile("" : "+s"(pcs4));
       if (p.amax_out || p.amax_pool) {
-        float mx = 0.f;
+        if constexpr (MODE == 2) {
+          float mx0 = 0.f, mx1 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+          for (int r = 0; r < 16; ++r) {
+            float mq = 0.f;
 #pragma unroll
-          for (int m = 0; m < 2; ++m)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[j][m][r]));
-        mx = live ? mx : 0.f;
-        if (p.amax_out) kocr_amax_update_known(p.amax_out + nimg, mx, seen_out);
-        if (p.amax_pool) kocr_amax_update_known(p.amax_pool + nimg, mx, seen_pool);
+              for (int m = 0; m < 2; ++m) mq = fmaxf(mq, fabsf(acc[j][m][r]));
+            const bool first = qx_of(r) < qb_cur;
+            mx0 = fmaxf(mx0, first ? mq : 0.f);
+            mx1 = fmaxf(mx1, first ? 0.f : mq);
+          }
+          mx0 = live ? mx0 : 0.f;
+          mx1 = live ? mx1 : 0.f;
+          if (p.amax_out) kocr_amax_update_known(p.amax_out + nimg, mx0, seen_out);
+          if (p.amax_pool) kocr_amax_update_known(p.amax_pool + nimg, mx0, seen_pool);
+          if (qb_cur < QPR) {  // uniform: the tile has a second cell
+            if (p.amax_out) kocr_amax_update_known(p.amax_out + nimg1, mx1, seen_out1);
+            if (p.amax_pool) kocr_amax_update_known(p.amax_pool + nimg1, mx1, seen_pool1);
+          }
+        } else {
+          float mx = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[j][m][r]));
+          mx = live ? mx : 0.f;
+          if (p.amax_out) kocr_amax_update_known(p.amax_out + nimg, mx, seen_out);
+          if (p.amax_pool) kocr_amax_update_known(p.amax_pool + nimg, mx, seen_pool);
+        }
       }
       PROBE_T(2);
       if constexpr (GEO == 2) {
         // M-tile m = rows 4 m .. 4 m + 3 x 8 quads: accumulator register r of lane half l5 is row r >> 2, quad (r & 3) + 4 l5
         const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (tpm * p.out_cs + p.out_co), 0x7FFFFFFFu);
         const unsigned vo = live ? (unsigned)((16 * l5e * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
+        const int wlim = p.W - tx0 - 16 * l5e;  // MODE 1: columns of the image right of this lane half's first one
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int px = (4 * m + (r >> 2)) * p.W + 4 * (r & 3);
+            if (MODE == 1 && ty0 + 4 * m + (r >> 2) >= p.H) continue;  // uniform: the row lies below the image
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vo, (px + j) * ocs4, 0);
+            for (int j = 0; j < 4; ++j) {
+              const unsigned vom = MODE == 1 ? (4 * (r & 3) + j < wlim ? vo : OOB) : vo;
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vom, (px + j) * ocs4, 0);
+            }
           }
       } else {
 #pragma unroll
@@ -489,28 +636,55 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
           if (!POOL || p.write_full) {
             const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (pm * p.out_cs + p.out_co), 0x7FFFFFFFu);
             const unsigned vo = live ? (unsigned)((16 * l5e * p.out_cs + n) * 4) : OOB;  // 4 quads = 16 px per l5
+            if constexpr (MODE == 1) {
+              const int wlim = p.W - tx0 - 16 * l5e;  // columns of the image right of this lane half's first one
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-              const int px = 4 * ((r & 3) + 8 * (r >> 2));  // quad column (r&3) + 8 (r>>2) [+ 4 l5] of row y
+              for (int h = 0; h < 2; ++h) {
+                if (ty0 + 2 * m + h >= p.H) continue;  // uniform: the row lies below the image
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vo, (px + j) * ocs4, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r + 8]), ro, vo, (px + j + p.W) * ocs4, 0);
+                for (int r = 0; r < 8; ++r) {
+                  const int px = 4 * ((r & 3) + 8 * (r >> 2));
+#pragma unroll
+                  for (int j = 0; j < 4; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r + 8 * h]), ro, px + j < wlim ? vo : OOB,
+                                                          (px + j + h * p.W) * ocs4, 0);
+                }
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {
+                const int px = 4 * ((r & 3) + 8 * (r >> 2));  // quad column (r&3) + 8 (r>>2) [+ 4 l5] of row y
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vo, (px + j) * ocs4, 0);
+                  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r + 8]), ro, vo, (px + j + p.W) * ocs4, 0);
+                }
               }
             }
           }
           if constexpr (POOL) {
             // 2x2 max: rows y (r) and y+1 (r+8), columns (0,1) and (2,3) of the quad
-            const long pp0 = ((pm - x0) >> 2) + (x0 >> 1);  // (nimg H/2 + y0/2) W/2 + x0/2: H, W even
+            long pp0;
+            if constexpr (MODE == 1)  // floor pooling of any H, W: (nimg (H >> 1) + y0 / 2 + m) (W >> 1) + x0 / 2
+              pp0 = ((long)timg * (p.H >> 1) + (ty0 >> 1) + m) * (p.W >> 1) + (x0 >> 1);
+            else
+              pp0 = ((pm - x0) >> 2) + (x0 >> 1);  // (nimg H/2 + y0/2) W/2 + x0/2: H, W even
             const __amdgpu_buffer_rsrc_t rp = w4_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
             const unsigned vp = live ? (unsigned)((8 * l5e * p.pool_cs + n) * 4) : OOB;  // 4 quads = 8 pooled px per l5
+            if (MODE == 1 && (ty0 >> 1) + m >= (p.H >> 1)) continue;  // uniform: no pooled row here
+            const int plim = (p.W >> 1) - (x0 >> 1) - 8 * l5e;        // MODE 1: pooled columns right of this lane half's first
+            const bool ztop = MODE == 2 && ty0 == 0 && m == 0;        // MODE 2: pooled row 0 is the pooled cells' zero row
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
               const int pq = 2 * ((r & 3) + 8 * (r >> 2));
-              const float v0 = fmaxf(fmaxf(acc[0][m][r], acc[1][m][r]), fmaxf(acc[0][m][r + 8], acc[1][m][r + 8]));
-              const float v1 = fmaxf(fmaxf(acc[2][m][r], acc[3][m][r]), fmaxf(acc[2][m][r + 8], acc[3][m][r + 8]));
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * pcs4, 0);
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * pcs4, 0);
+              float v0 = fmaxf(fmaxf(acc[0][m][r], acc[1][m][r]), fmaxf(acc[0][m][r + 8], acc[1][m][r + 8]));
+              float v1 = fmaxf(fmaxf(acc[2][m][r], acc[3][m][r]), fmaxf(acc[2][m][r + 8], acc[3][m][r + 8]));
+              if constexpr (MODE == 2) {
+                v0 = ztop ? 0.f : v0;
+                v1 = ztop ? 0.f : v1;
+              }
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, (MODE != 1 || pq < plim) ? vp : OOB, pq * pcs4, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, (MODE != 1 || pq + 1 < plim) ? vp : OOB, (pq + 1) * pcs4, 0);
             }
           }
         }
@@ -537,8 +711,10 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
 // products, the per-image power-of-two scale folded into the input transform, the per-cout weight scale into pre_a.
 // CRAFT's slice1.3 (64 -> 64 at full resolution) and upconv3.conv.3.
 // ===================================================================================================
-template <int POOL, int NP>
+// MODE 1 (round 5) = RAGGED, any H, W: see conv_w43vh_kernel (column bits in Geo::ok, masked stores).
+template <int POOL, int NP, int MODE = 0>
 __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
+  static_assert(MODE == 0 || MODE == 1, "exact tiling or ragged");
   constexpr int PR = NP == 2 ? 3 : 1;
   constexpr int NROWS = 6, QPR = 16, KHS = QPR * 8, ROW_STRIDE = 2 * KHS, PLANE_R = NROWS * ROW_STRIDE;
   constexpr int BUF_R = 6 * NP * PLANE_R;  // one channel group: 36 KB (NP = 2)
@@ -558,6 +734,21 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
     const int rq = (int)w4_fdiv((unsigned)mp, p.dv_tpr), cb = mp - rq * p.tiles_per_row;  // rq: (image, row quad)
     return (2 * rq + m) * p.tiles_per_row + cb;
   };
+  // first pixel of M-tile m (2 rows x 64 columns) of pixel tile mp, its row, column and image
+  auto mtile_org = [&](int mp, int m, int& y0, int& x0, int& nimg_o) -> long {
+    if constexpr (MODE == 1) {
+      const int rq = (int)w4_fdiv((unsigned)mp, p.dv_tpr), cb = mp - rq * p.tiles_per_row;
+      const int nimg = (int)w4_fdiv((unsigned)rq, p.dv_rq), ro = rq - nimg * p.rq_per_img;  // rq_per_img = ceil(H / 4)
+      y0 = 4 * ro + 2 * m;
+      x0 = TCOLS * cb;
+      nimg_o = nimg;
+      return ((long)nimg * p.H + y0) * p.W + x0;
+    } else {
+      const long pm = w4_mtile_pm0<1>(p, tile_mt(mp, m), y0, x0);
+      nimg_o = (int)w4_fdiv((unsigned)pm, p.dv_hw);
+      return pm;
+    }
+  };
 
   // ---- producer state (conv_w43r_kernel GEO 1) ------------------------------------------------------------------
   const int q4 = tid & 3, qd0 = (tid >> 2) & (QPR - 1), r0 = tid >> 6;
@@ -573,8 +764,8 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
   };
   auto make_geo = [&](int L, Geo& g, bool& left, bool& right) __attribute__((always_inline)) {
     const int mp = kocr_xcd_remap(L < total ? L : 0, total);
-    int y0, x0;
-    const long pm = w4_mtile_pm0<1>(p, tile_mt(mp, 0), y0, x0);
+    int y0, x0, nimg;
+    const long pm = mtile_org(mp, 0, y0, x0, nimg);
     g.base = p.in + (pm * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
     const int tid = wave * 64 + kocr_fresh_lane();  // see conv_w43vh_kernel's make_geo
     const int q4 = tid & 3, qd0 = (tid >> 2) & (QPR - 1), r0 = tid >> 6;
@@ -583,9 +774,19 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
     g.off0[1] = (unsigned)(((r1 * p.W + 4 * qd1) * p.in_cs + cp * 2) * 4);
     g.ok = ((L < total && (unsigned)(y0 - 1 + r0) < (unsigned)p.H) ? 1u : 0u) |
            ((L < total && (unsigned)(y0 - 1 + r1) < (unsigned)p.H) ? 2u : 0u);
-    g.e = kocr_scale_exp_bits(kocr_sload(p.amax_in + __builtin_amdgcn_readfirstlane((int)w4_fdiv((unsigned)pm, p.dv_hw))), W4H_TOP);
-    left = x0 == 0;
-    right = x0 + TCOLS >= p.W;
+    g.e = kocr_scale_exp_bits(kocr_sload(p.amax_in + __builtin_amdgcn_readfirstlane(nimg)), W4H_TOP);
+    if constexpr (MODE == 1) {
+      const int c0 = x0 - 1 + 4 * qd0, c1 = x0 - 1 + 4 * qd1;
+      unsigned cm = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        cm |= ((unsigned)(c0 + k) < (unsigned)p.W ? 0u : (4u << k)) | ((unsigned)(c1 + k) < (unsigned)p.W ? 0u : (256u << k));
+      g.ok |= cm;
+      left = right = false;
+    } else {
+      left = x0 == 0;
+      right = x0 + TCOLS >= p.W;
+    }
   };
   Geo gc, gn;
   bool lc, rc, ln, rn;
@@ -593,27 +794,29 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
   bool ld_next = false;
   auto load_item0 = [&](v4f (&raw)[6]) __attribute__((always_inline)) {
     const int soff = ld_cg * 64;
-    const bool ok = (ld_next ? gn.ok : gc.ok) & 1u;
+    const unsigned okb = ld_next ? gn.ok : gc.ok;
+    const bool ok = okb & 1u;
     const unsigned off0 = (ld_next ? gn.off0[0] : gc.off0[0]) | (ok ? 0u : OOB);
     const bool left = (ld_next ? ln : lc) && qd0 == 0, right = (ld_next ? rn : rc) && qd0 == QPR - 1;
     const unsigned stride = (unsigned)(p.in_cs * 4);
     const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const unsigned padk = (k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u);
+      const unsigned padk = MODE == 1 ? ((okb << (29 - k)) & OOB) : ((k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u));
       raw[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (off0 + k * stride) | padk, soff, 0));
     }
   };
   auto load_item1 = [&](v2f (&raw)[6]) __attribute__((always_inline)) {
     const int soff = ld_cg * 64;
-    const bool ok = ((ld_next ? gn.ok : gc.ok) >> 1) & 1u;
+    const unsigned okb = ld_next ? gn.ok : gc.ok;
+    const bool ok = (okb >> 1) & 1u;
     const unsigned off0 = (ld_next ? gn.off0[1] : gc.off0[1]) | (ok ? 0u : OOB);
     const bool left = (ld_next ? ln : lc) && qd1 == 0, right = (ld_next ? rn : rc) && qd1 == QPR - 1;
     const unsigned stride = (unsigned)(p.in_cs * 4);
     const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      const unsigned padk = (k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u);
+      const unsigned padk = MODE == 1 ? ((okb << (23 - k)) & OOB) : ((k == 0 ? (left ? OOB : 0u) : 0u) | (k == 5 ? (right ? OOB : 0u) : 0u));
       raw[k] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (off0 + k * stride) | padk, soff, 0));
     }
   };
@@ -790,9 +993,9 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
       const int lane_e = kocr_fresh_lane();
       const int l31e = lane_e & 31, l5e = lane_e >> 5;
       const int n = wn * 32 + l31e;
-      int y0, x0;
-      const long pm = w4_mtile_pm0<1>(p, tile_mt(mp, ph), y0, x0);
-      const int nimg = __builtin_amdgcn_readfirstlane((int)w4_fdiv((unsigned)pm, p.dv_hw));
+      int y0, x0, timg;
+      const long pm = mtile_org(mp, ph, y0, x0, timg);
+      const int nimg = __builtin_amdgcn_readfirstlane(timg);
       const unsigned seen_out = p.amax_out ? kocr_amax_peek(p.amax_out + nimg) : 0u;
       const unsigned seen_pool = p.amax_pool ? kocr_amax_peek(p.amax_pool + nimg) : 0u;
       const float pa = coef[n] * unscale, pb = coef[p.Cout_pad + n];  // pre_a = pre_a 2^-wexp[o] (ConvLayer::d_pre_a_h)
@@ -872,27 +1075,50 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
       if (!POOL || p.write_full) {
         const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + (pm * p.out_cs + p.out_co), 0x7FFFFFFFu);
         const unsigned vo = live ? (unsigned)((16 * l5e * p.out_cs + n) * 4) : OOB;
+        if constexpr (MODE == 1) {
+          const int wlim = p.W - x0 - 16 * l5e;  // columns of the image right of this lane half's first one
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int px = 4 * ((r & 3) + 8 * (r >> 2));
+          for (int h = 0; h < 2; ++h) {
+            if (y0 + h >= p.H) continue;  // uniform: the row lies below the image
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out[j][r]), ro, vo, (px + j) * ocs4, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out[j][r + 8]), ro, vo, (px + j + p.W) * ocs4, 0);
+            for (int r = 0; r < 8; ++r) {
+              const int px = 4 * ((r & 3) + 8 * (r >> 2));
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out[j][r + 8 * h]), ro, px + j < wlim ? vo : OOB, (px + j + h * p.W) * ocs4, 0);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int px = 4 * ((r & 3) + 8 * (r >> 2));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out[j][r]), ro, vo, (px + j) * ocs4, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out[j][r + 8]), ro, vo, (px + j + p.W) * ocs4, 0);
+            }
           }
         }
       }
       if constexpr (POOL) {
-        const long pp0 = ((pm - x0) >> 2) + (x0 >> 1);
+        long pp0;
+        if constexpr (MODE == 1)  // floor pooling of any H, W
+          pp0 = ((long)timg * (p.H >> 1) + (y0 >> 1)) * (p.W >> 1) + (x0 >> 1);
+        else
+          pp0 = ((pm - x0) >> 2) + (x0 >> 1);
         const __amdgpu_buffer_rsrc_t rp = w4_rsrc(p.pool_out + (pp0 * p.pool_cs + p.pool_co), 0x7FFFFFFFu);
         const unsigned vp = live ? (unsigned)((8 * l5e * p.pool_cs + n) * 4) : OOB;
+        const bool prow = MODE != 1 || (y0 >> 1) < (p.H >> 1);  // uniform: a pooled row exists here
+        const int plim = (p.W >> 1) - (x0 >> 1) - 8 * l5e;
+        if (prow) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int pq = 2 * ((r & 3) + 8 * (r >> 2));
-          const float v0 = fmaxf(fmaxf(out[0][r], out[1][r]), fmaxf(out[0][r + 8], out[1][r + 8]));
-          const float v1 = fmaxf(fmaxf(out[2][r], out[3][r]), fmaxf(out[2][r + 8], out[3][r + 8]));
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, vp, pq * pcs4, 0);
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, vp, (pq + 1) * pcs4, 0);
+          for (int r = 0; r < 8; ++r) {
+            const int pq = 2 * ((r & 3) + 8 * (r >> 2));
+            const float v0 = fmaxf(fmaxf(out[0][r], out[1][r]), fmaxf(out[0][r + 8], out[1][r + 8]));
+            const float v1 = fmaxf(fmaxf(out[2][r], out[3][r]), fmaxf(out[2][r + 8], out[3][r + 8]));
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rp, (MODE != 1 || pq < plim) ? vp : OOB, pq * pcs4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rp, (MODE != 1 || pq + 1 < plim) ? vp : OOB, (pq + 1) * pcs4, 0);
+          }
         }
       }
       PROBE_T(3);
@@ -1300,14 +1526,14 @@ int prepare_w43h(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, co
   return KOCR_OK;
 }
 
-template <int POOL, int GEO, int NP, int DBG = 0>
+template <int POOL, int GEO, int NP, int DBG = 0, int MODE = 0>
 static int w4vh_launch(kocr_ctx* ctx, W4Params& p) {
   constexpr int LDSV0 = (GEO == 2 ? 2 * 6 * 10 * 128 * 2 : 2 * 6 * 6 * 256 * 2) * NP;  // 2 x 30 / 36 KB (NP = 2)
   const int LDSV = LDSV0 + 4 * p.Cout_pad * 4;                                         // + the epilogue's coefficients
   static std::atomic<bool> attr_done[64];
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
-    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43vh_kernel<POOL, GEO, NP, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSV0 + W4_COEF_BYTES_MAX));
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43vh_kernel<POOL, GEO, NP, DBG, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSV0 + W4_COEF_BYTES_MAX));
     attr_done[dev] = true;
   }
   static std::atomic<int> n_cus[64];
@@ -1319,11 +1545,11 @@ static int w4vh_launch(kocr_ctx* ctx, W4Params& p) {
   const int n_cu = n_cus[dev];
   const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;  // persistent: one block per CU
   PROBE_RESET(ctx);
-  hipLaunchKernelGGL((conv_w43vh_kernel<POOL, GEO, NP, DBG>), dim3(grid), dim3(256), LDSV, ctx->stream, p);
+  hipLaunchKernelGGL((conv_w43vh_kernel<POOL, GEO, NP, DBG, MODE>), dim3(grid), dim3(256), LDSV, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   {
     char what[80];
-    snprintf(what, sizeof what, "conv_w43vh<%d,%d,%d> tiles %d steps %d cout %d", POOL, GEO, NP, p.total_tiles, p.nsteps, p.Cout);
+    snprintf(what, sizeof what, "conv_w43vh<%d,%d,%d,%d> tiles %d steps %d cout %d", POOL, GEO, NP, MODE, p.total_tiles, p.nsteps, p.Cout);
     (void)what;
     PROBE_REPORT(ctx, what, grid);
   }
@@ -1332,7 +1558,16 @@ static int w4vh_launch(kocr_ctx* ctx, W4Params& p) {
 
 // the vertical-reuse arrangement in fp16 arithmetic: p as launch_conv_w43 filled it for conv_w43v_kernel, with wgt =
 // ConvLayer::d_w4h, pre_a = d_pre_a_h and amax_in set.  geo 1 / 2, pieces 2 / 1.
-int launch_w43vh(kocr_ctx* ctx, W4Params& p, bool fuse, int geo, int pieces) {
+// mode 1 / 2 (ragged images, cell grids) exist with two pieces only: the one-piece fast mode runs those layers in fp16x2
+int launch_w43vh(kocr_ctx* ctx, W4Params& p, bool fuse, int geo, int pieces, int mode) {
+  if (mode == 2) {
+    if (geo == 2) return w4vh_launch<0, 2, 2, 0, 2>(ctx, p);
+    return fuse ? w4vh_launch<1, 1, 2, 0, 2>(ctx, p) : w4vh_launch<0, 1, 2, 0, 2>(ctx, p);
+  }
+  if (mode == 1) {
+    if (geo == 2) return w4vh_launch<0, 2, 2, 0, 1>(ctx, p);
+    return fuse ? w4vh_launch<1, 1, 2, 0, 1>(ctx, p) : w4vh_launch<0, 1, 2, 0, 1>(ctx, p);
+  }
 #ifdef KOCR_DEV_SWITCHES
   static const int dbg = getenv("KOCR_W43H_DBG") ? atoi(getenv("KOCR_W43H_DBG")) : 0;
   if (dbg && !fuse && geo == 1 && pieces == 2) {
@@ -1365,14 +1600,14 @@ int launch_w43vh(kocr_ctx* ctx, W4Params& p, bool fuse, int geo, int pieces) {
   return fuse ? w4vh_launch<1, 1, 1>(ctx, p) : w4vh_launch<0, 1, 1>(ctx, p);
 }
 
-template <int POOL, int NP>
+template <int POOL, int NP, int MODE = 0>
 static int w4rh_launch(kocr_ctx* ctx, W4Params& p) {
   constexpr int LDSR0 = 6 * NP * 6 * 256 * 2 + 4 * 16 * 64 * 16;  // one 36 KB buffer + the epilogue's 64 KB exchange area
   const int LDSR = LDSR0 + 4 * p.Cout_pad * 4;                    // + the epilogue's coefficients
   static std::atomic<bool> attr_done[64];
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
-    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43rh_kernel<POOL, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSR0 + W4_COEF_BYTES_MAX));
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43rh_kernel<POOL, NP, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSR0 + W4_COEF_BYTES_MAX));
     attr_done[dev] = true;
   }
   static std::atomic<int> n_cus[64];
@@ -1384,7 +1619,7 @@ static int w4rh_launch(kocr_ctx* ctx, W4Params& p) {
   const int n_cu = n_cus[dev];
   const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
   PROBE_RESET(ctx);
-  hipLaunchKernelGGL((conv_w43rh_kernel<POOL, NP>), dim3(grid), dim3(256), LDSR, ctx->stream, p);
+  hipLaunchKernelGGL((conv_w43rh_kernel<POOL, NP, MODE>), dim3(grid), dim3(256), LDSR, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   {
     char what[80];
@@ -1397,7 +1632,8 @@ static int w4rh_launch(kocr_ctx* ctx, W4Params& p) {
 
 // the 64-cout row-reuse arrangement (4 x 64 tiles) in fp16 arithmetic: p as launch_conv_w43 filled it for
 // conv_w43r_kernel<POOL, 1>, with wgt = d_w4h, pre_a = d_pre_a_h and amax_in set
-int launch_w43rh(kocr_ctx* ctx, W4Params& p, bool fuse, int pieces) {
+int launch_w43rh(kocr_ctx* ctx, W4Params& p, bool fuse, int pieces, int mode) {
+  if (mode == 1) return fuse ? w4rh_launch<1, 2, 1>(ctx, p) : w4rh_launch<0, 2, 1>(ctx, p);
   if (pieces == 2) return fuse ? w4rh_launch<1, 2>(ctx, p) : w4rh_launch<0, 2>(ctx, p);
   return fuse ? w4rh_launch<1, 1>(ctx, p) : w4rh_launch<0, 1>(ctx, p);
 }

@@ -22,6 +22,8 @@
 
 int launch_crnn_input(kocr_ctx* ctx, const float* d_crops, float* d_x, int M, int Hc, int Wc);
 int launch_crnn_to_keras(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
+int launch_crnn_conv1_cells(kocr_ctx* ctx, const ConvLayer& L, const float* d_crops, int M, int Hc, int Wc, const Tensor& out);
+int launch_crnn_cells_to_keras(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
 int launch_stn_sample(kocr_ctx* ctx, const Tensor& x, const float* d_theta, const Tensor& out);
 int launch_lstm(kocr_ctx* ctx, const float* d_xp, const float* d_Uf, const float* d_Ub, float* d_out, int M, int T);
 size_t dense_splitk_workspace(int M, int K);
@@ -37,6 +39,10 @@ struct CrnnNet {
 
 namespace {
 constexpr int HC = 31, WC = 200, UNITS = 128, T = 50, DISCARD = 2;
+// the crop batch as a cell grid (Tensor::cellW): CN crops side by side per image; cell = (HC + 1) x 208 at full resolution
+// (one zero row on top, eight zero columns behind the crop), 16 x 104 and 8 x 52 after the two poolings.  208 CN, 104 CN and
+// 52 CN are multiples of 64: the grid tiles as 4 rows x 64 columns at every level.
+constexpr int CN = 16, CELL_W = 208;
 const int kFilters[7] = {64, 128, 256, 256, 512, 512, 512};
 
 struct Blob {
@@ -169,6 +175,14 @@ size_t crnn_workspace_bytes(int M, int n_classes) {
   const size_t m = (size_t)M, f = sizeof(float);
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   size_t t = 0;
+  {  // the cell-grid schedule instead of the dense conv stack below (whichever is larger): whole rows of CN cells
+    const size_t mc = (m + CN - 1) / CN * CN;
+    const size_t cells = al(mc * (HC + 1) * CELL_W * 64 * f) + al(mc * (HC + 1) * CELL_W * 128 * f) +
+                         al(mc * 16 * (CELL_W / 2) * 256 * f) * 2 + al(mc * 8 * (CELL_W / 4) * 512 * f) * 3;
+    const size_t dense = al(m * WC * HC * 64 * f) + al(m * WC * HC * 128 * f) + al(m * WC * HC * 256 * f) +
+                         al(m * 100 * 15 * 256 * f) * 2 + al(m * 100 * 15 * 512 * f) + al(m * 52 * 7 * 512 * f) * 3;
+    if (cells > dense) t += cells - dense;
+  }
   t += al(m * WC * HC * 64 * f) + al(m * WC * HC * 128 * f) + al(m * WC * HC * 256 * f);
   t += al(m * 100 * 15 * 256 * f) * 2 + al(m * 100 * 15 * 512 * f);
   t += al(m * 52 * 7 * 512 * f) * 5;                              // p5, c6, c7 (both layouts; width padded to 52), stn
@@ -223,6 +237,48 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
     return launch_conv(ctx, net->L[name], in, nullptr, nullptr, out);
   };
   Tensor x0, c1, c2, c3, p3, c4, c5, p5, c6, c7n, c7, s1, s2, d1, th, st, f9, xp, r1, r2, lg;
+  // Round 5: in the fp16 arithmetic the conv stack runs on a CELL GRID (Tensor::cellW): the crops side by side, CN per image,
+  // with zero gutters, so that conv_2 ... conv_7 take the vertical-reuse F(4,3) kernel (conv_w43vh_kernel MODE 2) with both
+  // poolings fused into conv_3 / conv_5 (whose full-resolution outputs are never written) and the max-|x| slots maintained
+  // per cell by every producer.  One path for every M (a crop's result must not depend on the batch it comes in).
+  bool cells = true;
+  for (int i = 2; i <= 7; ++i) cells = cells && w43_cells_ok(ctx, net->L["conv_" + std::to_string(i)]);
+  if (cells) {
+    const int R = (M + CN - 1) / CN;
+    auto mkc = [&](int hc, int wc, int wv, int c, bool alloc, Tensor* t) -> int {
+      t->N = R;
+      t->H = hc;
+      t->W = CN * wc;
+      t->C = t->cs = c;
+      t->co = 0;
+      t->cellW = wc;
+      t->cellWv = wv;
+      t->amax = ctx->amax_slots(R * CN);
+      if (!t->amax) KOCR_FAIL(ctx, KOCR_ECAPACITY, "kocr_crnn_forward: out of max-|x| slots");
+      t->p = alloc ? (float*)ctx->ws_alloc((size_t)R * hc * CN * wc * c * sizeof(float)) : nullptr;
+      if (alloc && !t->p) KOCR_FAIL(ctx, KOCR_ENOMEM, "kocr_crnn_forward: workspace exhausted");
+      return KOCR_OK;
+    };
+    KOCR_TRY(mkc(HC + 1, CELL_W, WC, 64, true, &c1));
+    KOCR_TRY(launch_crnn_conv1_cells(ctx, net->L["conv_1"], d_crops, M, HC, WC, c1));
+    KOCR_TRY(mkc(HC + 1, CELL_W, WC, 128, true, &c2));
+    KOCR_TRY(conv("conv_2", c1, c2));
+    KOCR_TRY(mkc(HC + 1, CELL_W, WC, 256, false, &c3));  // conv_3's full-resolution output is only ever pooled
+    KOCR_TRY(mkc(16, CELL_W / 2, WC / 2, 256, true, &p3));
+    KOCR_TRY(launch_conv_pool(ctx, net->L["conv_3"], c2, nullptr, nullptr, c3, &p3, /*need_full=*/false));  // ReLU, bn_3, pool
+    KOCR_TRY(mkc(16, CELL_W / 2, WC / 2, 256, true, &c4));
+    KOCR_TRY(conv("conv_4", p3, c4));
+    KOCR_TRY(mkc(16, CELL_W / 2, WC / 2, 512, false, &c5));
+    KOCR_TRY(mkc(8, CELL_W / 4, WC / 4, 512, true, &p5));
+    KOCR_TRY(launch_conv_pool(ctx, net->L["conv_5"], c4, nullptr, nullptr, c5, &p5, /*need_full=*/false));
+    KOCR_TRY(mkc(8, CELL_W / 4, WC / 4, 512, true, &c6));
+    KOCR_TRY(conv("conv_6", p5, c6));
+    KOCR_TRY(mkc(8, CELL_W / 4, WC / 4, 512, true, &c7n));
+    c7n.amax = nullptr;  // nothing downstream reads its scale
+    KOCR_TRY(conv("conv_7", c6, c7n));
+    KOCR_TRY(mk(M, WC / 4, HC / 4, 512, &c7));
+    KOCR_TRY(launch_crnn_cells_to_keras(ctx, c7n, c7));
+  } else {
   // conv stack in the crop's natural orientation (see the header): [M,31,200,C]
   x0.N = M;
   x0.H = HC;
@@ -250,7 +306,9 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
   // In the fp16 modes the three tensors around them are stored 52 wide with two zero columns (Tensor::Wv = 50): the pooling
   // kernel and the flattened fp16 F(4,3) kernel write the zeros, which are exactly the 'same' padding of column 49's right
   // neighbours -- 4 % more pixels on a kernel 1.4x faster than the F(2,3) bf16x3 one that takes the 50-wide tensors.
-  const bool pad52 = ctx->split_mode != KOCR_SPLIT_BF16X3 && ctx->sw.w43h && net->L["conv_6"].d_w4h && net->L["conv_7"].d_w4h;
+  // (the same predicate the dispatcher uses: a 52-wide tensor through any other kernel would get convolution values written
+  //  into its padding columns -- launch_conv now refuses that)
+  const bool pad52 = w43_flat_h_ok(ctx, net->L["conv_6"]) && w43_flat_h_ok(ctx, net->L["conv_7"]);
   const int W6 = pad52 ? 52 : WC / 4;
   if (pad52) c5.amax = ctx->amax_slots(M);
   KOCR_TRY(conv("conv_5", c4, c5));
@@ -268,6 +326,7 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
   // back to the Keras layout (M, 50, 7, 512) for the STN and everything after it
   KOCR_TRY(mk(M, WC / 4, HC / 4, 512, &c7));
   KOCR_TRY(launch_crnn_to_keras(ctx, c7n, c7));
+  }
   // STN (recognition.py:268-281)
   KOCR_TRY(mk(M, WC / 4, HC / 4, 16, &s1));
   KOCR_TRY(conv("stn_conv_1", c7, s1));

@@ -44,6 +44,80 @@ __global__ void crnn_to_keras_kernel(const float* __restrict__ in, float* __rest
   }
 }
 
+// ---- the recogniser's crop batch as a CELL GRID (Tensor::cellW; round 5) ------------------------------------------------------
+// conv_1 (recognition.py:217: 1 -> 64 channels, 3x3 'same', bias, ReLU; natural orientation, see crnn.cpp) straight from
+// the crop batch [M][31][200] into the level-1 cell grid out[R][32][cn * 208][64]: cell (n, j) holds crop n * cn + j in its
+// rows 1 .. 31 and columns 0 .. 199; row 0, columns 200 .. 207 and the cells behind crop M - 1 are written as zeros.  K = 9:
+// plain fp32 FMAs (9 per output; the layer is bound by its 256 bytes of output per pixel), the same fma chain order for
+// every output.  Also maintains the per-cell max-|x| slots (exact maximum, so a crop's scale does not depend on its cell).
+// grid = (cells, 32 cell rows); thread = (column slot t >> 4 of 16, channel quad t & 15), 13 column groups per row.
+__global__ __launch_bounds__(256) void crnn_conv1_cells_kernel(const float* __restrict__ crops, const float* __restrict__ w,
+                                                               const float* __restrict__ pre_a, const float* __restrict__ pre_b,
+                                                               float* __restrict__ out, unsigned* __restrict__ amax, int M, int cn,
+                                                               int Hc, int Wc, int cellH, int cellW, int cout_pad) {
+  const int cell = blockIdx.x, crow = blockIdx.y;
+  const int n = cell / cn, j = cell - n * cn;
+  const int t = threadIdx.x, cq = t & 15, xs = t >> 4;
+  float wk[9][4], pa[4], pb[4];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wk[k][c] = w[(size_t)k * cout_pad + cq * 4 + c];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    pa[c] = pre_a[cq * 4 + c];
+    pb[c] = pre_b[cq * 4 + c];
+  }
+  const int y = crow - 1;  // crop row
+  const bool live = cell < M && y >= 0 && y < Hc;
+  const float* src = crops + (size_t)(cell < M ? cell : 0) * Hc * Wc;
+  float4* dst = reinterpret_cast<float4*>(out + (((size_t)n * cellH + crow) * ((size_t)cn * cellW) + (size_t)j * cellW) * 64) + cq;
+  float mx = 0.f;
+  for (int x = xs; x < cellW; x += 16) {
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && x < Wc) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = y + ky - 1, xx = x + kx - 1;
+          const float v = ((unsigned)yy < (unsigned)Hc && (unsigned)xx < (unsigned)Wc) ? src[yy * Wc + xx] : 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = fmaf(v, wk[ky * 3 + kx][c], acc[c]);
+        }
+      o.x = fmaxf(fmaf(acc[0], pa[0], pb[0]), 0.f);
+      o.y = fmaxf(fmaf(acc[1], pa[1], pb[1]), 0.f);
+      o.z = fmaxf(fmaf(acc[2], pa[2], pb[2]), 0.f);
+      o.w = fmaxf(fmaf(acc[3], pa[3], pb[3]), 0.f);
+      mx = fmaxf(mx, fmaxf(fmaxf(o.x, o.y), fmaxf(o.z, o.w)));
+    }
+    dst[(size_t)x * 16] = o;
+  }
+  if (amax) {
+    const unsigned bits = kocr_wave_max_bits(mx);
+    if (bits != 0 && (t & 63) == 0) atomicMax(amax + cell, bits);
+  }
+}
+
+// level-3 cell grid in[R][cellH][cn * cellW][C] (crop rows at cell rows 1 .. Hn, natural orientation) -> Keras layout
+// out[M][Wn][Hn][C] with out[m][w][j] = crop_m[Hn - 1 - j][w] (the Permute((2,1,3)) + flip of recognition.py:215-216)
+__global__ void crnn_cells_to_keras_kernel(const float* __restrict__ in, float* __restrict__ out, int M, int Hn, int Wn, int C4,
+                                           int cn, int cellH, int cellW) {
+  const size_t total = (size_t)M * Hn * Wn * C4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = i % C4;
+    size_t t = i / C4;
+    const int j = t % Hn;
+    t /= Hn;
+    const int w = t % Wn;
+    const size_t m = t / Wn;
+    const size_t n = m / cn, jc = m - n * cn;
+    reinterpret_cast<float4*>(out)[i] =
+        reinterpret_cast<const float4*>(in)[((n * cellH + (size_t)(Hn - 1 - j) + 1) * ((size_t)cn * cellW) + jc * cellW + w) * C4 + c4];
+  }
+}
+
 // x: [M][H][W][C], theta: [M][6] -> out [M][H][W][C]
 __global__ void stn_sample_kernel(const float* __restrict__ x, const float* __restrict__ theta, float* __restrict__ out,
                                   int M, int H, int W, int C) {
@@ -271,6 +345,34 @@ int launch_crnn_to_keras(kocr_ctx* ctx, const Tensor& in, const Tensor& out) {
   if (b > 8192) b = 8192;
   hipLaunchKernelGGL(crnn_to_keras_kernel, dim3((unsigned)b), dim3(256), 0, ctx->stream, in.p, out.p, in.N, in.H, in.wv(),
                      in.C / 4, in.W);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
+// conv_1 of M crops [M][Hc][Wc] into the cell grid `out` (N rows of cells() cells, cell height out.H = Hc + 1)
+int launch_crnn_conv1_cells(kocr_ctx* ctx, const ConvLayer& L, const float* d_crops, int M, int Hc, int Wc, const Tensor& out) {
+  if (L.Cin != 1 || L.Cout != 64 || L.KH != 3 || L.KW != 3 || !out.cellW || out.C != 64 || out.cs != 64 || out.co || out.H != Hc + 1 ||
+      out.cellWv != Wc || out.cellW < Wc || (size_t)out.N * out.cells() < (size_t)M || L.d_post_a || !L.relu)
+    KOCR_FAIL(ctx, KOCR_EINVAL, "crnn_conv1_cells: bad layer / shapes");
+  ProfScope ps(ctx, "crnn_conv1_cells", 2.0 * M * Hc * Wc * 9 * 64, 4.0 * ((double)M * Hc * Wc + (double)out.pixels() * 64));
+  hipLaunchKernelGGL(crnn_conv1_cells_kernel, dim3((unsigned)(out.N * out.cells()), (unsigned)out.H), dim3(256), 0, ctx->stream, d_crops,
+                     L.d_w, L.d_pre_a, L.d_pre_b, out.p, out.amax, M, out.cells(), Hc, Wc, out.H, out.cellW, L.Cout_pad);
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}
+
+// `in` = cell grid (crop rows at cell rows 1 .. in.H - 1), out = [M][cellWv][in.H - 1][C]
+int launch_crnn_cells_to_keras(kocr_ctx* ctx, const Tensor& in, const Tensor& out) {
+  if (!in.cellW || in.C % 4 || in.cs != in.C || in.co || out.cs != out.C || out.co || out.H != in.cellWv || out.W != in.H - 1 || out.C != in.C ||
+      (size_t)in.N * in.cells() < (size_t)out.N)
+    KOCR_FAIL(ctx, KOCR_EINVAL, "crnn_cells_to_keras: bad shapes");
+  const size_t total = out.pixels() * (in.C / 4);
+  if (!total) return KOCR_OK;
+  ProfScope ps(ctx, "crnn_to_keras", 0, 8.0 * out.pixels() * in.C);
+  size_t b = (total + 255) / 256;
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(crnn_cells_to_keras_kernel, dim3((unsigned)b), dim3(256), 0, ctx->stream, in.p, out.p, out.N, in.H - 1, in.cellWv,
+                     in.C / 4, in.cells(), in.H, in.cellW);
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }

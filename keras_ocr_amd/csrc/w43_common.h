@@ -40,6 +40,11 @@ struct W4Params {
   const unsigned* amax_in;  // fp16 kernels: per-image max-|x| slots of the INPUT (Tensor::amax[n]), never null there
   int Wv;              // conv_w43fh_kernel: valid output width (Tensor::Wv): columns >= Wv are written as zeros; 0 = all valid
   unsigned dv_w[2];    // by W
+  // conv_w43vh / conv_w43rh MODE 1 (ragged images) and MODE 2 (cell grids): the tile grid of an image
+  int rq_per_img;      // row blocks per image: ceil(H / 4) (4 x 64 tiles) or ceil(H / 8) (8 x 32 tiles)
+  unsigned dv_rq[2];   // by rq_per_img
+  int cellW, cellWv, cells_per_row;  // MODE 2 (Tensor::cellW / cellWv): cell pitch, valid columns of a cell, W / cellW
+  unsigned dv_wc[2];   // by cellW
 };
 
 // host: multiplier / shift of the division by d (1 <= d < 2^31)

@@ -234,38 +234,55 @@ class ShardedPipeline:
         start, end = shard_bounds(n_total, world, rank)
         distributed = dist.is_available() and dist.is_initialized()
         t0 = time.perf_counter()
+        src_error = None
         if not distributed:
             mine = batch
             dev = None
         else:
             dev = _comm_device(self.group)
-            mine = torch.empty((per, h, w, 3), dtype=torch.uint8, device=dev)
+            # The source rank may fail BEFORE the collective (a missing / mis-shaped batch, an allocation error while it
+            # cuts the blocks): every other rank would already sit in the scatter and hang until the backend's timeout.
+            # So the source first tells everybody whether the scatter will happen (one int32 broadcast); on failure no
+            # rank enters it, and the error travels through the status slot of the counts all-gather like any failure of a
+            # local chain: ShardError on every rank.
             chunks = None
             if rank == src_rank:
-                if batch is None or tuple(batch.shape) != (n_total, h, w, 3) or batch.dtype != torch.uint8:
-                    raise ValueError("recognize_scattered: the source rank needs the (n_total, h, w, 3) uint8 batch")
-                batch = batch.to(dev)
-                chunks = []
-                for r in range(world):
-                    c = batch[r * per:min((r + 1) * per, n_total)]
-                    if c.shape[0] < per:  # equal blocks for the collective: the tail is zero padded (and never processed)
-                        c = torch.cat([c, torch.zeros((per - c.shape[0], h, w, 3), dtype=torch.uint8, device=dev)])
-                    chunks.append(c.contiguous())
-            dist.scatter(mine, scatter_list=chunks, src=src_rank, group=self.group)
-            if dev.type == "cuda":
-                torch.cuda.synchronize()
+                try:
+                    if batch is None or tuple(batch.shape) != (n_total, h, w, 3) or batch.dtype != torch.uint8:
+                        raise ValueError("recognize_scattered: the source rank needs the (n_total, h, w, 3) uint8 batch")
+                    batch = batch.to(dev)
+                    chunks = []
+                    for r in range(world):
+                        c = batch[r * per:min((r + 1) * per, n_total)]
+                        if c.shape[0] < per:  # equal blocks for the collective: the tail is zero padded (and never processed)
+                            c = torch.cat([c, torch.zeros((per - c.shape[0], h, w, 3), dtype=torch.uint8, device=dev)])
+                        chunks.append(c.contiguous())
+                except Exception as e:  # noqa: BLE001 -- exchanged below, never raised on this rank alone
+                    src_error, chunks = e, None
+            go = torch.tensor([0 if src_error is not None else 1], dtype=torch.int32, device=dev)
+            dist.broadcast(go, src=src_rank, group=self.group)
+            mine = None
+            if int(go.item()) == 1:
+                mine = torch.empty((per, h, w, 3), dtype=torch.uint8, device=dev)
+                dist.scatter(mine, scatter_list=chunks, src=src_rank, group=self.group)
+                if dev.type == "cuda":
+                    torch.cuda.synchronize()
         if timing is not None:
             timing["scatter_s"] = timing.get("scatter_s", 0.0) + (time.perf_counter() - t0)
-            timing["scatter_bytes_sent"] = (per * (world - 1) * h * w * 3) if (distributed and rank == src_rank) else 0
+            timing["scatter_bytes_sent"] = (per * (world - 1) * h * w * 3) if (distributed and rank == src_rank and src_error is None) else 0
         n_mine = end - start
 
         def run():
+            if src_error is not None:
+                raise src_error
             if mine.device.type == "cuda":
                 return self.pipeline.recognize_device_raw(mine.data_ptr(), n_mine, h, w, detection_kwargs)
             # host tensors (gloo): the same call as recognize(); every image has the batch's size
             _, _, _, hmax, wmax = self.pipeline._plan([(h, w, 3)] * n_total)  # pylint: disable=protected-access
             return self.pipeline.recognize_raw(mine[:n_mine].numpy(), hmax, wmax, detection_kwargs, None)
 
+        if distributed and mine is None:  # the source failed: nobody has a block; the source reports why
+            return self._run_shard(run, rank == src_rank, per, timing)
         return self._run_shard(run, n_mine > 0, per, timing)
 
     def _run_shard(self, run, has_work, per, timing):

@@ -109,3 +109,31 @@ def test_folded_linear_layers_equal_the_plain_schedule(craft_ctx, craft_weights,
     print(f"{shape}: heat-map error vs oracle {errs}; vs plain schedule {d}")
     assert max(errs.values()) <= HEAT_TOL
     assert max(d.values()) <= 5e-5
+
+
+def test_heatmap_ragged_page_on_the_fp16_kernels(craft_ctx, craft_weights):
+    """A page no pyramid level of which tiles (375 x 500: half of a 750 x 1000 photo at scale 1; levels 187 x 250, 93 x 125,
+    46 x 62, 23 x 31 -- tools.resize_image hands the detector any int(W s) x int(H s), tools.py:387-397): since round 5 the
+    vertical- / row-reuse fp16 kernels take such images through their ragged grids (masked gather, masked stores, floor
+    pooling fused) instead of dropping to the F(2,3) / fp32 kernels.  Same heat-map tolerance; the profiler must show it."""
+    import os
+
+    from oracle import craft as ocraft
+    from tests import synth
+
+    img = synth.text_page(375, 500, 12, seed=91)[None]
+    craft_ctx.profile_enable(True)
+    craft_ctx.profile_reset()
+    got = craft_ctx.craft_forward(img)
+    rows = craft_ctx.profile_report()
+    craft_ctx.profile_enable(False)
+    want = ocraft.detector_predict(craft_weights, img)
+    assert got.shape == want.shape == (1, 187, 250, 2)
+    err = float(np.abs(got - want).max())
+    print(f"ragged 375x500: heat-map error {err:.2e}; kernels {sorted(k for k in rows if k.startswith('conv'))}")
+    assert err <= HEAT_TOL, f"max abs heat-map error {err}"
+    if craft_ctx.get_split_mode() != 0 and not any(k.startswith("KOCR_") and k != "KOCR_SPLIT" for k in os.environ):
+        assert any(k.startswith("conv_w4hv_256x128") and k.endswith("_rag") for k in rows), sorted(rows)
+        assert any(k.startswith("conv_w4hr_256x64") and k.endswith("_rag") for k in rows), sorted(rows)
+        assert any(k.startswith("conv_w4hv_256x128_pool") and k.endswith("_rag") for k in rows), sorted(rows)
+        assert not any(k.startswith(("conv_ws_", "conv_wino", "conv_w4s_256x128", "conv_w4s_512x64")) and "dil" not in k for k in rows), sorted(rows)

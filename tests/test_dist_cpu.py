@@ -307,3 +307,49 @@ def test_scatter_from_one_rank_gloo_world2(n_images):
     assert res[0][2] == n_images and res[1][2] == n_images                     # everybody ends with the whole result
     assert res[0][3] == 0 and res[1][3] == per * 13 * 24 * 3                   # only the source sends: one block per peer
     assert all(r[4] and r[5] for r in res)
+
+
+def _worker_scatter_bad_source(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    import keras_ocr_amd
+
+    keras_ocr_amd.dist.init_from_env(backend="gloo")
+    sp = keras_ocr_amd.dist.ShardedPipeline(_FakePipeline())
+    # the source (rank 0) holds a batch of the WRONG shape: it must not raise alone while rank 1 sits in the scatter
+    batch = torch.zeros((3, 9, 9, 3), dtype=torch.uint8) if rank == 0 else None
+    try:
+        sp.recognize_scattered(batch, 4, 13, 24, src_rank=0)
+        q.put((rank, "no error", None))
+    except keras_ocr_amd.dist.ShardError as e:
+        q.put((rank, str(e), type(e.__cause__).__name__ if e.__cause__ else None))
+    # the group is still usable: a well-formed call right after it
+    good = torch.zeros((4, 13, 24, 3), dtype=torch.uint8) if rank == 0 else None
+    out = sp.recognize_scattered(good, 4, 13, 24, src_rank=0)
+    q.put((rank, "after", len(out)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scatter_source_failure_raises_on_every_rank_gloo_world2():
+    """a bad / missing batch on the SOURCE rank of recognize_scattered used to raise there before the scatter,
+    leaving every other rank blocked in it.  Now the source announces the failure (one int broadcast), nobody enters the
+    scatter, and every rank raises ShardError naming rank 0 and the ValueError."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_scatter_bad_source, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    errs = {r: (m, c) for r, m, c in res if m != "after"}
+    assert set(errs) == {0, 1}
+    for r in (0, 1):
+        assert "rank(s) [0]" in errs[r][0] and "ValueError" in errs[r][0], errs
+    assert errs[0][1] == "ValueError" and errs[1][1] is None
+    assert sorted((r, n) for r, m, n in res if m == "after") == [(0, 4), (1, 4)]

@@ -24,13 +24,19 @@ PROF_TO_KERNEL = {
     "conv_w4v_256x128": "void conv_w43v_kernel<0, 1", "conv_w4v_256x128_pool": "void conv_w43v_kernel<1, 1",
     "conv_w4t_256x128": "void conv_w43v_kernel<0, 2",
     # round 4: the same arrangements in fp16 arithmetic (h: two pieces, q: one piece), conv_w43vh_kernel<POOL, GEO, NP, DBG>
-    "conv_w4hv_256x128": "void conv_w43vh_kernel<0, 1, 2", "conv_w4hv_256x128_pool": "void conv_w43vh_kernel<1, 1, 2",
-    "conv_w4ht_256x128": "void conv_w43vh_kernel<0, 2, 2",
-    "conv_w4qv_256x128": "void conv_w43vh_kernel<0, 1, 1", "conv_w4qv_256x128_pool": "void conv_w43vh_kernel<1, 1, 1",
-    "conv_w4qt_256x128": "void conv_w43vh_kernel<0, 2, 1",
+    # (round 5: a fifth / third template argument MODE: 0 = exact tiling, 1 = ragged images "_rag", 2 = cell grids "_cells")
+    "conv_w4hv_256x128": "void conv_w43vh_kernel<0, 1, 2, 0, 0>", "conv_w4hv_256x128_pool": "void conv_w43vh_kernel<1, 1, 2, 0, 0>",
+    "conv_w4ht_256x128": "void conv_w43vh_kernel<0, 2, 2, 0, 0>",
+    "conv_w4hv_256x128_rag": "void conv_w43vh_kernel<0, 1, 2, 0, 1>", "conv_w4hv_256x128_pool_rag": "void conv_w43vh_kernel<1, 1, 2, 0, 1>",
+    "conv_w4ht_256x128_rag": "void conv_w43vh_kernel<0, 2, 2, 0, 1>",
+    "conv_w4hv_256x128_cells": "void conv_w43vh_kernel<0, 1, 2, 0, 2>", "conv_w4hv_256x128_pool_cells": "void conv_w43vh_kernel<1, 1, 2, 0, 2>",
+    "conv_w4ht_256x128_cells": "void conv_w43vh_kernel<0, 2, 2, 0, 2>",
+    "conv_w4qv_256x128": "void conv_w43vh_kernel<0, 1, 1, 0, 0>", "conv_w4qv_256x128_pool": "void conv_w43vh_kernel<1, 1, 1, 0, 0>",
+    "conv_w4qt_256x128": "void conv_w43vh_kernel<0, 2, 1, 0, 0>",
     "conv_w4hf_256x128": "void conv_w43fh_kernel<2", "conv_w4qf_256x128": "void conv_w43fh_kernel<1",
-    "conv_w4hr_256x64": "void conv_w43rh_kernel<0, 2", "conv_w4hr_256x64_pool": "void conv_w43rh_kernel<1, 2",
-    "conv_w4qr_256x64": "void conv_w43rh_kernel<0, 1", "conv_w4qr_256x64_pool": "void conv_w43rh_kernel<1, 1",
+    "conv_w4hr_256x64": "void conv_w43rh_kernel<0, 2, 0>", "conv_w4hr_256x64_pool": "void conv_w43rh_kernel<1, 2, 0>",
+    "conv_w4hr_256x64_rag": "void conv_w43rh_kernel<0, 2, 1>", "conv_w4hr_256x64_pool_rag": "void conv_w43rh_kernel<1, 2, 1>",
+    "conv_w4qr_256x64": "void conv_w43rh_kernel<0, 1, 0>", "conv_w4qr_256x64_pool": "void conv_w43rh_kernel<1, 1, 0>",
     "conv_w4s_256x64": "void conv_w43r_kernel<0", "conv_w4s_256x64_pool": "void conv_w43r_kernel<1",
     "conv_ws_128x128": "void conv_ws_kernel<0, 1, 4, 0", "conv_ws_128x128_pool": "void conv_ws_kernel<1, 1, 4, 0",
     "conv_ws_256x64": "void conv_ws_kernel<0, 2, 2, 0", "conv_ws_256x64_pool": "void conv_ws_kernel<1, 2, 2, 0",
@@ -52,7 +58,7 @@ def load_counters(directory):
                 k = r["Kernel_Name"]
                 agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
                 cnt[k].add(r["Dispatch_Id"])
-                if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE"):
+                if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES"):
                     agg[k]["_ns_" + r["Counter_Name"]] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return agg, {k: len(v) for k, v in cnt.items()}
 
@@ -81,10 +87,12 @@ def under_profiler():
     return "rocprof" in blob
 
 
-def measure_traffic(bench_path, prof_name, timeout=150):
-    """Run the bench command twice under `rocprofv3 --kernel-trace --pmc <one counter>` (short: 1 warm-up + 1 step, no extra
-    legs) and return the per-launch traffic of `prof_name`'s kernel, averaged over every launch of that child process,
-    next to the algorithmic bytes of the same launches (the child's `roofline.process`).  Raises on any failure."""
+def measure_traffic(bench_path, prof_name, timeout=150, clock=True):
+    """Run the bench command under `rocprofv3 --kernel-trace --pmc <one counter>` (short: 1 warm-up + 1 step, no extra legs),
+    once per counter, and return the per-launch traffic of `prof_name`'s kernel, averaged over every launch of that child
+    process, next to the algorithmic bytes of the same launches (the child's `roofline.process`).  `clock`: two more passes
+    (GRBM_GUI_ACTIVE, SQ_VALU_MFMA_BUSY_CYCLES) give the clock the chip sustained under that kernel and the share of its
+    cycles the matrix pipe was busy (scripts/pmc_clock.py's formulas).  Raises on any failure of the traffic passes."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.isfile(exe):
         raise RuntimeError("rocprofv3 not found")
@@ -122,12 +130,33 @@ def measure_traffic(bench_path, prof_name, timeout=150):
             else:
                 mp = [kk for kk in agg if kk.startswith("maxpool2x2")]
                 sums["_mp_write"] = agg[mp[0]]["WRITE_SIZE"] if mp else None
+        if clock:
+            try:
+                cyc = {}
+                for counter in ("GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES"):
+                    d = os.path.join(out, counter.lower())
+                    p = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
+                                       cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout, text=True)
+                    agg, n = load_counters(d)
+                    k = find_kernel(agg.keys(), prof_name)
+                    if p.returncode == 0 and k is not None and counter in agg[k]:
+                        cyc[counter] = (agg[k][counter], agg[k]["_ns_" + counter])
+                if len(cyc) == 2:
+                    ghz = cyc["GRBM_GUI_ACTIVE"][0] / 8 / cyc["GRBM_GUI_ACTIVE"][1]  # summed over the 8 XCDs
+                    sums["_clock_ghz"] = ghz
+                    # SQ_VALU_MFMA_BUSY_CYCLES sums over 256 CUs x 4 SIMDs
+                    sums["_mfma_busy"] = cyc["SQ_VALU_MFMA_BUSY_CYCLES"][0] / 1024 / (cyc["SQ_VALU_MFMA_BUSY_CYCLES"][1] * ghz)
+            except Exception:  # noqa: BLE001 -- the clock passes are a bonus
+                pass
     finally:
         shutil.rmtree(out, ignore_errors=True)
     res = {"fetch_bytes_per_launch": fetch_bytes(sums["FETCH_SIZE"]) / launches["FETCH_SIZE"],
            "write_bytes_per_launch": write_bytes(sums["WRITE_SIZE"]) / launches["WRITE_SIZE"],
            "launches": launches["FETCH_SIZE"]}
     res["hbm_bytes_per_launch"] = res["fetch_bytes_per_launch"] + res["write_bytes_per_launch"]
+    if "_clock_ghz" in sums:
+        res["clock_ghz"] = sums["_clock_ghz"]
+        res["mfma_pipe_busy"] = sums["_mfma_busy"]
     if sums.get("_mp_fetch") and sums.get("_mp_write"):
         res["calibration_maxpool2x2_read_over_write"] = fetch_bytes(sums["_mp_fetch"]) / write_bytes(sums["_mp_write"])
     pr = (line or {}).get("roofline", {}).get("process")

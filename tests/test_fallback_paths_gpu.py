@@ -11,6 +11,13 @@ once per process): the fp64-bounded convolution tests and the CRAFT heat-map-vs-
   KOCR_HS16=0    no 16-wide product tile    -> conv_cls.4 on conv_hs_kernel's 32-column tile
   KOCR_SPLIT=bf16  the exact bf16x3 split everywhere (round 3's default arithmetic)
   KOCR_W43H=0    no fp16 F(4,3) kernels     -> the default mode's fp16 layers on their bf16x3 kernels
+  KOCR_CELLS=0   no cell grid               -> the recogniser's conv stack on round 4's dense crop batch (flattened fp16 tiles,
+                                               conv_6 / conv_7 through the 52-wide layout, separate pooling kernels)
+  KOCR_W43RAG=0  no ragged tile grids       -> images that do not tile exactly on the flattened / F(2,3) / fp32 kernels
+
+Since round 5 every configuration also runs the recogniser against the oracle (under KOCR_W43=0 the 52-wide
+layout used to reach a kernel that does not write its padding columns; launch_conv now refuses that, and crnn.cpp asks the
+dispatcher's own predicate) and the ragged CRAFT page.
 
 (these paths were reached by the driver's suite only through the shapes that happen to select
 them.)  Each configuration is one pytest child process over the same test files, same bounds."""
@@ -35,6 +42,9 @@ CONFIGS = [
     {"KOCR_HS16": "0"},
     {"KOCR_SPLIT": "bf16"},
     {"KOCR_W43H": "0"},
+    {"KOCR_CELLS": "0"},
+    {"KOCR_W43RAG": "0"},
+    {"KOCR_CELLS": "0", "KOCR_W43": "0"},
 ]
 
 
@@ -44,7 +54,8 @@ def test_parity_suites_hold_on_the_fallback_path(switches):
     env.update(switches)
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
            os.path.join(ROOT, "tests", "test_conv_gpu.py"), os.path.join(ROOT, "tests", "test_craft_gpu.py"),
-           "-k", "fp32_class or heatmap_f32_input or heatmap_u8_input or cfg2_size"]
+           os.path.join(ROOT, "tests", "test_crnn_gpu.py"),
+           "-k", "fp32_class or heatmap_f32_input or heatmap_u8_input or cfg2_size or ragged_page or probs_and_labels"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900, check=False)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, f"{switches}: child pytest failed\n{tail}"

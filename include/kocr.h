@@ -228,6 +228,18 @@ int kocr_profile_reset(kocr_ctx* ctx);
 int kocr_profile_report(kocr_ctx* ctx, int cap, char* names /* cap x 64 */, int64_t* launches,
                         double* total_ms, double* flops, double* bytes);
 
+/* ---- range statistics of the fp16x2 arithmetic (developer instrumentation; off = no cost) ------------- */
+/* KOCR_SPLIT_F16X2 keeps fp32's 24 bits of an element only while its magnitude lies within 2^16 of its image's maximum
+ * (DESIGN.md section 3).  With the statistics enabled, every fp16-arithmetic convolution first counts, over its INPUT tensor
+ * and with the per-image scale 2^e it is about to use, the non-zero elements with |x| 2^e < 2^-4 (two-piece precision worse
+ * than 2^-21 relative to the element) and < 2^-14 (the high piece is an fp16 subnormal: worse than 2^-11), and the share
+ * of the tensor's sum |x| they carry -- one synchronising side launch per layer, so timing runs keep it off.
+ * kocr_range_stats_report fills parallel arrays (up to cap rows, one per layer name, accumulated since the last enable):
+ * values[i * 7 + k] = launches, elements, non-zero elements, elements below 2^-4, below 2^-14, sum |x|, sum |x| of the
+ * elements below 2^-4.  Returns the number of rows. */
+int kocr_range_stats_enable(kocr_ctx* ctx, int on);
+int kocr_range_stats_report(kocr_ctx* ctx, int cap, char* names /* cap x 64 */, double* values /* cap x 7 */);
+
 #ifdef __cplusplus
 }
 #endif

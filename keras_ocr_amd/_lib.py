@@ -77,6 +77,8 @@ def load_library():
         "kocr_profile_enable": (ci, [vp, ci]),
         "kocr_profile_reset": (ci, [vp]),
         "kocr_profile_report": (ci, [vp, ci, ctypes.c_char_p, _c_i64_p, _c_dbl_p, _c_dbl_p, _c_dbl_p]),
+        "kocr_range_stats_enable": (ci, [vp, ci]),
+        "kocr_range_stats_report": (ci, [vp, ci, ctypes.c_char_p, _c_dbl_p]),
     }
     for name, (res, args) in sigs.items():
         if not hasattr(lib, name):
@@ -431,6 +433,27 @@ class Context:
             nm = names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode()
             rows[nm] = {"launches": int(launches[i]), "ms": float(ms[i]), "flops": float(flops[i]),
                         "bytes": float(byts[i])}
+        return rows
+
+
+    # -- range statistics of the fp16x2 arithmetic (include/kocr.h; developer instrumentation) ----------
+    def range_stats_enable(self, on=True):
+        self._check(self._lib.kocr_range_stats_enable(self._h, int(bool(on))))
+
+    def range_stats_report(self):
+        """{layer: {launches, elements, nonzero, below_2^-4, below_2^-14, frac_below_2^-4 (of the non-zero elements),
+        frac_below_2^-14, share_of_sum_abs_below_2^-4}} accumulated since range_stats_enable(True)."""
+        cap = 256
+        names = ctypes.create_string_buffer(cap * 64)
+        vals = np.zeros(cap * 7, dtype=np.float64)
+        n = self._check(self._lib.kocr_range_stats_report(self._h, cap, names, vals.ctypes.data_as(_c_dbl_p)))
+        rows = {}
+        for i in range(min(n, cap)):
+            nm = names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode()
+            la, el, nz, b4, b14, sa, sb = vals[i * 7:i * 7 + 7]
+            rows[nm] = {"launches": int(la), "elements": el, "nonzero": nz, "below_2^-4": b4, "below_2^-14": b14,
+                        "frac_below_2^-4": b4 / nz if nz else 0.0, "frac_below_2^-14": b14 / nz if nz else 0.0,
+                        "share_of_sum_abs_below_2^-4": sb / sa if sa else 0.0}
         return rows
 
 

@@ -595,4 +595,32 @@ int kocr_profile_report(kocr_ctx* ctx, int cap, char* names, int64_t* launches, 
   return i;
 }
 
+int kocr_range_stats_enable(kocr_ctx* ctx, int on) {
+  if (!ctx) return KOCR_EINVAL;
+  if (on && !ctx->d_range) {  // allocated here, not at first use: kocr_conv2d_nhwc frees what a call allocates
+    KOCR_HIP(ctx, hipSetDevice(ctx->device));
+    void* d = nullptr;
+    KOCR_TRY(ctx->dev_alloc(&d, 64));
+    ctx->d_range = d;
+  }
+  ctx->range_on = on != 0;
+  if (on) ctx->range.clear();
+  return KOCR_OK;
+}
+
+int kocr_range_stats_report(kocr_ctx* ctx, int cap, char* names, double* values) {
+  if (!ctx) return KOCR_EINVAL;
+  int i = 0;
+  for (auto& kv : ctx->range) {
+    if (i < cap && names && values) {
+      snprintf(names + (size_t)i * 64, 64, "%s", kv.first.c_str());
+      const RangeRow& r = kv.second;
+      const double v[7] = {r.launches, r.elements, r.nonzero, r.below_m4, r.below_m14, r.sum_abs, r.sum_abs_below_m4};
+      for (int k = 0; k < 7; ++k) values[(size_t)i * 7 + k] = v[k];
+    }
+    ++i;
+  }
+  return i;
+}
+
 }  // extern "C"

@@ -116,6 +116,11 @@ struct ProfRow {
   double ms = 0, flops = 0, bytes = 0;
 };
 
+// range statistics of the fp16x2 arithmetic per convolution layer (elementwise.hip: launch_range_stats)
+struct RangeRow {
+  double launches = 0, elements = 0, nonzero = 0, below_m4 = 0, below_m14 = 0, sum_abs = 0, sum_abs_below_m4 = 0;
+};
+
 struct Arena {
   char* base = nullptr;
   size_t cap = 0, off = 0;
@@ -170,6 +175,11 @@ struct kocr_ctx {
 
   CraftNet* craft = nullptr;
   CrnnNet* crnn = nullptr;
+
+  // developer instrumentation of the fp16x2 range assumption (kocr_range_stats_enable): off = no cost
+  bool range_on = false;
+  void* d_range = nullptr;
+  std::map<std::string, RangeRow> range;
 
   // profiler
   bool prof_on = false;
@@ -315,6 +325,7 @@ int launch_copy_channels(kocr_ctx* ctx, const Tensor& in, const Tensor& out);
 // per-image max |x| of a tensor into t.N slots (atomicMax; the slots are NOT cleared), and slot-to-slot propagation
 int launch_absmax(kocr_ctx* ctx, const Tensor& t, unsigned* slots);
 int launch_amax_copy(kocr_ctx* ctx, const unsigned* from, unsigned* to, int n);
+int launch_range_stats(kocr_ctx* ctx, const std::string& name, const Tensor& t, const unsigned* slots, int top);
 // conv_cls.6 + conv_cls.8 of the CRAFT head in one pass (16 -> 16 ReLU -> 2), heat-map written densely
 int launch_head_tail(kocr_ctx* ctx, const ConvLayer& L6, const ConvLayer& L8, const Tensor& in, float* d_heat);
 

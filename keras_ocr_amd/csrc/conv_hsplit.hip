@@ -776,6 +776,7 @@ int launch_conv_hsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
       slots = tmp;
     }
     p.amax_in = slots;
+    if (ctx->range_on) KOCR_TRY(launch_range_stats(ctx, L.name, in, slots, 14));
     p.wgt = L.d_hsh;
     p.pre_a = L.d_pre_a_h;
   }

@@ -468,6 +468,15 @@ static int round_up(int a, int b) { return (a + b - 1) / b * b; }
 int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, int Cin, int Cout,
                  int KH, int KW, int dil, const float* pre_a, const float* pre_b, int relu,
                  const float* post_a, const float* post_b) {
+  // A layer object may be prepared again (kocr_load_* on a context that already holds weights): nothing derived from the
+  // previous weights may survive.  In round 4 d_pre_a_h did -- the <= 32-cout fp16 kernel's per-cout exponents were
+  // uploaded only `if (!L.d_pre_a_h)`, so a second load kept the FIRST load's exponents next to the new weights (found by
+  // tests/test_range_gpu.py's re-loaded detector: conv_cls.0 / .2 a factor 2^k off per channel).  The old device buffers
+  // stay owned by the context until it is destroyed.
+  L.d_w = L.d_pre_a = L.d_pre_b = L.d_post_a = L.d_post_b = L.d_w_rgb4 = L.d_wino = L.d_pre_a_h = nullptr;
+  L.d_ws = L.d_w4 = L.d_w4h = L.d_ds = L.d_first = L.d_hs = L.d_hs16 = L.d_hsh = L.d_k5 = nullptr;
+  L.hs_wexp.clear();
+  L.first_bound = 0.f;
   L.Cin = Cin;
   L.Cout = Cout;
   L.KH = KH;

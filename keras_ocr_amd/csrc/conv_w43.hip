@@ -1934,6 +1934,7 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
       slots = tmp;
     }
     p.amax_in = slots;
+    if (ctx->range_on) KOCR_TRY(launch_range_stats(ctx, L.name, in, slots, 12));  // W4H_TOP (conv_w43h.hip)
     p.wgt = L.d_w4h;
     p.pre_a = L.d_pre_a_h;
   }

@@ -5,7 +5,7 @@
 //                                       the channel slice of the concat buffer it feeds (detection.py:380-389)
 // All kernels move float4 (4 channels) per lane, lanes run along channels then pixels, so a
 // wave touches whole 128-B lines of both the source and the destination.
-#include "common.h"
+#include "split_common.h"
 #include <algorithm>
 
 struct EwParams {
@@ -361,8 +361,88 @@ int launch_absmax(kocr_ctx* ctx, const Tensor& t, unsigned* slots) {
   size_t b = (total + 4095) / 4096;
   const size_t cap = std::max<size_t>(1, 4096 / (size_t)t.N);
   if (b > cap) b = cap;
-  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)b, (unsigned)t.N), dim3(256), 0, ctx->stream, t.p, (size_t)t.H * t.W, t.C / 4, t.cs, t.co, slots);
+  // images are the grid's y dimension (<= 65 535 per launch: ADVICE r04 -- batches of more small images go in chunks)
+  constexpr int NCHUNK = 32768;
+  for (int n0 = 0; n0 < t.N; n0 += NCHUNK) {
+    const int nn = std::min(NCHUNK, t.N - n0);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)b, (unsigned)nn), dim3(256), 0, ctx->stream,
+                       t.p + (size_t)n0 * t.H * t.W * t.cs, (size_t)t.H * t.W, t.C / 4, t.cs, t.co, slots + n0);
+    KOCR_HIP(ctx, hipGetLastError());
+  }
+  return KOCR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Range statistics of the fp16x2 arithmetic (developer instrumentation, OFF unless kocr_range_stats_enable; VERDICT r04
+// item 5): for the INPUT tensor of an fp16-arithmetic convolution and the per-image (per-cell) scale 2^e the kernel is
+// about to derive from the max-|x| slots, how many non-zero elements fall where the two-piece split no longer carries
+// fp32's 24 bits -- s = |x| 2^e < 2^-4: the low piece is an fp16 subnormal with fewer than 20 bits below the high piece's
+// lsb ... relative precision of the element worse than 2^-21; s < 2^-14: the HIGH piece is subnormal, worse than 2^-11 -- and
+// how much of the tensor's sum |x| those elements carry.
+// out[0..2] = counts (non-zero, s < 2^-4, s < 2^-14), sums[0..1] = sum |x| (all, those with s < 2^-4)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void range_stats_kernel(const float* in, int H, int W, int C4, int cs, int co, const unsigned* slots,
+                                                          int cells, int cellW, int top, unsigned long long* cnt, double* sums) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int n = blockIdx.y;
+  const size_t img_pixels = (size_t)H * W, total = img_pixels * C4;
+  const float* base = in + (size_t)n * img_pixels * cs;
+  unsigned long long c0 = 0, c1 = 0, c2 = 0;
+  double s0 = 0, s1 = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t px = i / C4;
+    const int c4 = (int)(i - px * C4);
+    const int slot = cells ? n * cells + (int)((px % W) / cellW) : n;
+    const int e = kocr_scale_exp(slots + slot, top);
+    const float sc = kocr_pow2(e);
+    const v4f v = *reinterpret_cast<const v4f*>(base + px * cs + co + 4 * c4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float a = fabsf(v[k]), s = a * sc;
+      if (a > 0.f) {
+        ++c0;
+        s0 += a;
+        if (s < 0.0625f) {
+          ++c1;
+          s1 += a;
+        }
+        if (s < 6.103515625e-05f) ++c2;
+      }
+    }
+  }
+  atomicAdd(cnt + 0, c0);
+  atomicAdd(cnt + 1, c1);
+  atomicAdd(cnt + 2, c2);
+  atomicAdd(sums + 0, s0);
+  atomicAdd(sums + 1, s1);
+}
+
+// accumulates into ctx->range[name]; `top` = the exponent the consumer places the image's maximum at (12 for the F(4,3)
+// kernels, 14 for the <= 32-cout kernel)
+int launch_range_stats(kocr_ctx* ctx, const std::string& name, const Tensor& t, const unsigned* slots, int top) {
+  if (!ctx->range_on || !slots || t.C % 4 || t.cs % 4 || t.co % 4 || !t.pixels()) return KOCR_OK;
+  if (!ctx->d_range) KOCR_FAIL(ctx, KOCR_EINVAL, "range statistics: call kocr_range_stats_enable first");
+  unsigned long long* cnt = (unsigned long long*)ctx->d_range;
+  double* sums = (double*)((char*)ctx->d_range + 32);
+  KOCR_HIP(ctx, hipMemsetAsync(ctx->d_range, 0, 64, ctx->stream));
+  size_t b = ((size_t)t.H * t.W * (t.C / 4) + 4095) / 4096;
+  if (b > 64) b = 64;
+  hipLaunchKernelGGL(range_stats_kernel, dim3((unsigned)b, (unsigned)t.N), dim3(256), 0, ctx->stream, t.p, t.H, t.W, t.C / 4, t.cs, t.co, slots,
+                     t.cells(), t.cellW ? t.cellW : 1, top, cnt, sums);
   KOCR_HIP(ctx, hipGetLastError());
+  unsigned long long hc[4];
+  double hs[4];
+  KOCR_HIP(ctx, hipMemcpyAsync(hc, cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
+  KOCR_HIP(ctx, hipMemcpyAsync(hs, sums, 32, hipMemcpyDeviceToHost, ctx->stream));
+  KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RangeRow& r = ctx->range[name];
+  r.launches += 1;
+  r.elements += (double)t.pixels() * t.C;
+  r.nonzero += (double)hc[0];
+  r.below_m4 += (double)hc[1];
+  r.below_m14 += (double)hc[2];
+  r.sum_abs += hs[0];
+  r.sum_abs_below_m4 += hs[1];
   return KOCR_OK;
 }
 

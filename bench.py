@@ -318,6 +318,9 @@ def main(argv=None, env=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--side5", type=int, default=1536, help="page side of the configs[4] legs (1536; smaller only in tests)")
+    ap.add_argument("--cfg5-pages", type=int, default=0,
+                    help="total pages of the ONE sharded configs[4] batch (default batch x N: equal blocks); any other number "
+                         "gives ragged / empty shards (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split", choices=["bf16x3", "f16x2"], default="f16x2",
                     help="arithmetic of the wide convolutions for the headline number (include/kocr.h KOCR_SPLIT_*)")
@@ -479,7 +482,9 @@ def main(argv=None, env=None):
         p5s_host = make_pages(args.batch, side5, seed=5 + rank, words=80)
         p5s = env.to_dev(p5s_host)
         sp = k.dist.ShardedPipeline(k.pipeline.Pipeline(detector=det, recognizer=rec, scale=3))
-        n_tot = args.batch * world
+        n_tot = args.cfg5_pages if args.cfg5_pages > 0 else args.batch * world
+        if -(-n_tot // world) > args.batch:
+            raise SystemExit("bench.py --cfg5-pages: a rank's block must fit in its resident batch (ceil(pages / N) <= --batch)")
         sp.recognize_device(p5s.data_ptr(), n_tot, side5, side5)
         tm = {}
         reps = 2
@@ -497,11 +502,14 @@ def main(argv=None, env=None):
         if world > 1:
             full = torch.cat([torch.empty_like(p5s) for _ in range(world)]) if rank == 0 else None
             if rank == 0:
-                full[:args.batch] = p5s   # the other ranks' pages are rank 0's to invent: only the traffic matters here
+                # the blocks the ranks hold in the resident leg, in shard order (block r = the first ceil(n / N) pages of rank r's batch)
+                per5 = -(-n_tot // world)
+                full[:per5] = p5s[:per5]
                 for r in range(1, world):
-                    full[r * args.batch:(r + 1) * args.batch] = env.to_dev(make_pages(args.batch, side5, seed=5 + r, words=80))
+                    full[r * per5:(r + 1) * per5] = env.to_dev(make_pages(args.batch, side5, seed=5 + r, words=80))[:per5]
+                full = full[:n_tot].contiguous()
         else:
-            full = p5s
+            full = p5s[:n_tot]
         tms = {}
         sp.recognize_scattered(full, n_tot, side5, side5, src_rank=0)
         dt5s, o5c = timed(lambda: sp.recognize_scattered(full, n_tot, side5, side5, src_rank=0, timing=tms), reps)

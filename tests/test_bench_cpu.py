@@ -5,6 +5,7 @@ import sys
 import os
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -200,7 +201,7 @@ class _HostEnv:
         return False
 
 
-def _bench_worker(rank, world, port, q):
+def _bench_worker(rank, world, port, q, extra_args=()):
     import time as _t
 
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
@@ -208,8 +209,8 @@ def _bench_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import bench
 
-    res = bench.main(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch", "4", "--side5", "64", "--no-live-traffic"],
-                     env=_HostEnv())
+    res = bench.main(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch", "4", "--side5", "64", "--no-live-traffic"]
+                     + list(extra_args), env=_HostEnv())
     q.put((rank, _t.time(), res))
 
 
@@ -243,3 +244,38 @@ def test_bench_main_runs_at_world_2_over_gloo_with_a_mocked_library(capfd):
     assert "cpu_baseline" not in res and res["crnn_only"]["value"] > 0
     out = capfd.readouterr().out
     assert sum(ln.startswith('{"metric"') for ln in out.splitlines()) == 1   # exactly one JSON line on stdout
+
+
+@pytest.mark.parametrize("pages,blocks", [(14, [4, 4, 4, 2]), (5, [2, 2, 1, 0])], ids=["ragged_last_block", "an_empty_rank"])
+def test_bench_main_at_world_4_with_uneven_shards(pages, blocks, capfd):
+    """the sharded / scattered legs of bench.main() at world size 4 when the ONE batch does not divide
+    evenly -- a short last block, and a rank that gets nothing at all (it must still take part in every collective and end
+    with the whole result).  `--cfg5-pages` sets the total; blocks are ceil(n / N) contiguous pages (dist.shard_bounds)."""
+    import socket
+    import torch.multiprocessing as mp
+    import keras_ocr_amd
+
+    assert [e - s_ for s_, e in (keras_ocr_amd.dist.shard_bounds(pages, 4, r) for r in range(4))] == blocks
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 4, port, q, ("--cfg5-pages", str(pages)))) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res = got[0][2]
+    assert all(g[2] is None for g in got[1:]) and isinstance(res, dict)
+    assert res["n_gpus"] == 4 and res["ranks_seen"] == 4 and res["config"]["global_batch"] == 16
+    sh, sc = res["cfg5_sharded"], res["cfg5_scattered"]
+    assert sh["pages_returned_on_every_rank"] == pages                       # every page, on every rank, whatever its block was
+    per = -(-pages // 4)
+    assert sc["scatter_bytes_sent_by_rank0"] == per * 3 * 64 * 64 * 3        # equal (zero-padded) blocks to the three peers
+    assert sc["same_strings_as_resident_blocks"]
+    assert abs(sh["value"] - pages * 2 / (sh["ms_per_batch"] * 2 / 1e3)) < 1e-6 * sh["value"]
+    out = capfd.readouterr().out
+    assert sum(ln.startswith('{"metric"') for ln in out.splitlines()) == 1

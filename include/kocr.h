@@ -169,6 +169,14 @@ int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, const int32_
                   int size_threshold, int micro_batch, float* boxes, int32_t* counts, int cap,
                   int32_t* labels, int max_crops, int32_t* n_crops, int on_device);
 
+/* The same results where kocr_pipeline left them in HBM (round 5): d_boxes [N][cap][4][2] float32 (rows >= counts[i] of an
+ * image undefined), d_counts [N] int32, d_labels [M][48] int32 (M = sum of the counts; NULL when M == 0).  Valid only until
+ * the next libkocr call on this context that processes images (the buffers live in the context's arenas); KOCR_EINVAL when
+ * no result is resident.  For callers that hand the results to another device-side consumer -- keras_ocr_amd.dist packs
+ * them on the device and all-gathers them over RCCL without a host round trip. */
+int kocr_pipeline_device_results(kocr_ctx* ctx, const float** d_boxes, const int32_t** d_counts, const int32_t** d_labels,
+                                 int32_t* N, int32_t* cap, int32_t* M);
+
 /* ---- single fused-epilogue convolution (unit-test seam for the MFMA kernel) ---------- */
 /* out = post_a * act(pre_a * conv(in, w) + pre_b) + post_b, NHWC, stride 1, 'same'
  * padding; w is HWIO (the Keras kernel layout, detection.py:461).  pre_a/pre_b/post_a/

@@ -69,6 +69,7 @@ def load_library():
         "kocr_resize_pad": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci]),
         "kocr_pipeline": (ci, [vp, ci, ctypes.POINTER(vp), _c_int_p, _c_int_p, _c_int_p, _c_int_p, ci, ci,
                                ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, ci, vp, ci, vp, ci]),
+        "kocr_pipeline_device_results": (ci, [vp, vp, vp, vp, vp, vp, vp]),
         "kocr_conv2d_nhwc": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp]),
         "kocr_conv2d_cells": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, vp, vp, vp]),
         "kocr_set_split_mode": (ci, [vp, ci]),
@@ -364,6 +365,16 @@ class Context:
             break
         m = int(n_crops[0])
         return [boxes[i, :counts[i]].copy() if counts[i] else np.array([]) for i in range(n)], labels[:m].copy()
+
+    def pipeline_device_results(self):
+        """Device pointers of the last `pipeline()` call's results (include/kocr.h: kocr_pipeline_device_results):
+        {"boxes": ptr of [n][cap][4][2] f32, "counts": ptr of [n] i32, "labels": ptr of [m][48] i32 or 0, "n", "cap", "m"};
+        valid until the next call on this context."""
+        pb, pc, pl = ctypes.c_void_p(0), ctypes.c_void_p(0), ctypes.c_void_p(0)
+        n, cap, m = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        self._check(self._lib.kocr_pipeline_device_results(self._h, ctypes.byref(pb), ctypes.byref(pc), ctypes.byref(pl),
+                                                           ctypes.byref(n), ctypes.byref(cap), ctypes.byref(m)))
+        return {"boxes": pb.value or 0, "counts": pc.value or 0, "labels": pl.value or 0, "n": n.value, "cap": cap.value, "m": m.value}
 
     def conv2d_nhwc(self, x, w_hwio, dilation=1, pre_a=None, pre_b=None, relu=False, post_a=None, post_b=None):
         x = np.ascontiguousarray(x, dtype=np.float32)

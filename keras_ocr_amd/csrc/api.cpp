@@ -9,6 +9,7 @@
 // ctx internals
 // ---------------------------------------------------------------------------------------
 int arena_reserve(kocr_ctx* ctx, Arena& a, size_t bytes) {
+  ctx->last_pl.valid = false;  // whoever sizes an arena is about to overwrite it (kocr_pipeline re-validates at its end)
   if (bytes <= a.cap) return KOCR_OK;
   if (a.base) {
     KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));

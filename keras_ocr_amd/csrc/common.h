@@ -176,6 +176,17 @@ struct kocr_ctx {
   CraftNet* craft = nullptr;
   CrnnNet* crnn = nullptr;
 
+  // the device-resident results of the last successful kocr_pipeline call (kocr_pipeline_device_results): boxes in the pl
+  // arena, counts in the post-processing scratch, label rows in the io arena -- all valid until the next call that uses
+  // those arenas, which clears `valid` first
+  struct LastPipeline {
+    const float* d_boxes = nullptr;
+    const int32_t* d_counts = nullptr;
+    const int32_t* d_labels = nullptr;
+    int N = 0, cap = 0, M = 0;
+    bool valid = false;
+  } last_pl;
+
   // developer instrumentation of the fp16x2 range assumption (kocr_range_stats_enable): off = no cost
   bool range_on = false;
   void* d_range = nullptr;

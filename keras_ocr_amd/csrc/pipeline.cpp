@@ -11,6 +11,7 @@ extern "C" int kocr_resize_pad(kocr_ctx* ctx, const uint8_t* src, int n, int sh,
   if (!ctx) return KOCR_EINVAL;
   if (n < 0 || (n > 0 && (!src || !dst))) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_resize_pad: null buffer");
   if (n == 0) return KOCR_OK;
+  ctx->last_pl.valid = false;
   KOCR_HIP(ctx, hipSetDevice(ctx->device));
   const size_t sb = (size_t)n * sh * sw * 3, db = (size_t)n * Hmax * Wmax * 3;
   const size_t tb = (size_t)(4 * (Wmax + Hmax) + 64) * sizeof(int);
@@ -41,6 +42,7 @@ extern "C" int kocr_detect(kocr_ctx* ctx, const void* img, int dtype, int N, int
   if (dtype != KOCR_U8 && dtype != KOCR_F32) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_detect: bad dtype");
   if (N == 0) return KOCR_OK;
   if (cap <= 0) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_detect: cap must be positive");
+  ctx->last_pl.valid = false;
   KOCR_HIP(ctx, hipSetDevice(ctx->device));
   const int h2 = H / 2, w2 = W / 2;
   const size_t esz = dtype == KOCR_U8 ? 1 : 4;
@@ -95,6 +97,7 @@ extern "C" int kocr_recognize_boxes(kocr_ctx* ctx, const uint8_t* img_rgb, int N
   }
   if (M == 0) return KOCR_OK;
   if (!boxes || !labels) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_recognize_boxes: null buffer");
+  ctx->last_pl.valid = false;
   KOCR_HIP(ctx, hipSetDevice(ctx->device));
   std::vector<WarpParam> prm((size_t)M);
   long m = 0;
@@ -142,6 +145,7 @@ extern "C" int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, c
   if (n_crops) *n_crops = 0;
   if (N < 0 || (N > 0 && (!imgs || !hs || !ws || !dhs || !dws || !boxes || !counts)))
     KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_pipeline: null buffer");
+  ctx->last_pl.valid = false;
   if (N == 0) return KOCR_OK;
   if (!ctx->craft) KOCR_FAIL(ctx, KOCR_ENOWEIGHTS, "kocr_pipeline: call kocr_load_craft first");
   if (crnn_classes(ctx) == 0) KOCR_FAIL(ctx, KOCR_ENOWEIGHTS, "kocr_pipeline: call kocr_load_crnn first");
@@ -212,7 +216,11 @@ extern "C" int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, c
     if (host_flags[4] != 0) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_pipeline: singular perspective transform");
     return KOCR_OK;
   };
-  if (M == 0) return finish();
+  if (M == 0) {
+    KOCR_TRY(finish());
+    ctx->last_pl = {d_boxes, dv.d_counts, nullptr, N, cap, 0, true};
+    return KOCR_OK;
+  }
   if (!labels || M > max_crops) {
     KOCR_TRY(finish());  // an empty contour list (the reference's IndexError) takes precedence over the capacity error
     KOCR_FAIL(ctx, KOCR_ECAPACITY, "kocr_pipeline: more crops than max_crops");
@@ -239,5 +247,21 @@ extern "C" int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, c
   }
   KOCR_HIP(ctx, hipMemcpyAsync(labels, d_lab, lab_b, hipMemcpyDeviceToHost, ctx->stream));
   KOCR_HIP(ctx, hipMemcpyAsync(&host_flags[4], d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  return finish();
+  KOCR_TRY(finish());
+  ctx->last_pl = {d_boxes, dv.d_counts, d_lab, N, cap, (int)M, true};
+  return KOCR_OK;
+}
+
+// The results of the last successful kocr_pipeline call as they lie in HBM (see include/kocr.h)
+extern "C" int kocr_pipeline_device_results(kocr_ctx* ctx, const float** d_boxes, const int32_t** d_counts, const int32_t** d_labels,
+                                            int32_t* N, int32_t* cap, int32_t* M) {
+  if (!ctx) return KOCR_EINVAL;
+  if (!ctx->last_pl.valid) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_pipeline_device_results: no kocr_pipeline result is resident (call it right after kocr_pipeline)");
+  if (d_boxes) *d_boxes = ctx->last_pl.d_boxes;
+  if (d_counts) *d_counts = ctx->last_pl.d_counts;
+  if (d_labels) *d_labels = ctx->last_pl.d_labels;
+  if (N) *N = ctx->last_pl.N;
+  if (cap) *cap = ctx->last_pl.cap;
+  if (M) *M = ctx->last_pl.M;
+  return KOCR_OK;
 }

@@ -100,13 +100,45 @@ def _status_of(error):
     return 1
 
 
-def gather_packed(box_groups, labels, per_rank_images, group=None, error=None, timing=None):
+class _DeviceArray:
+    """A device buffer libkocr owns, as something ``torch.as_tensor(..., device="cuda")`` takes without a copy."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), True), "version": 2}
+
+
+def _pack_on_device(dev_res, cap, dev):
+    """The (cap, 8) box tensor and the (cap, 48) label tensor of gather_packed built IN HBM from what kocr_pipeline left
+    there (boxes [n][cap_local][4][2], counts [n], label rows [m][48]): the payload RCCL moves never visits the host."""
+    import torch
+
+    n, cl, m = dev_res["n"], dev_res["cap"], dev_res["m"]
+    b = torch.zeros((cap, 8), dtype=torch.float32, device=dev)
+    l = torch.full((cap, LABEL_WIDTH), -1, dtype=torch.int32, device=dev)
+    if m:
+        counts = torch.as_tensor(_DeviceArray(dev_res["counts"], (n,), "<i4"), device=dev)
+        boxes = torch.as_tensor(_DeviceArray(dev_res["boxes"], (n, cl, 8), "<f4"), device=dev)
+        mask = torch.arange(cl, device=dev)[None, :] < counts[:, None]
+        b[:m] = boxes[mask]                      # image-major, box order: the order of the label rows
+        l[:m] = torch.as_tensor(_DeviceArray(dev_res["labels"], (m, LABEL_WIDTH), "<i4"), device=dev)
+    return b, l
+
+
+def gather_packed(box_groups, labels, per_rank_images, group=None, error=None, timing=None, device_results=None,
+                  device_scale=None):
     """all-gather of the per-image box counts, then of fixed-capacity packed results.
 
     Every rank contributes ``per_rank_images`` count slots (its shard, zero padded), a (cap, 8) float32
     box tensor and a (cap, 48) int32 label tensor, where cap = the largest crop count of any rank (known
     after the counts exchange).  Three collectives, no pickling; on the nccl backend the tensors stay in
     HBM and travel over xGMI.  Returns (box_groups, labels) of the whole batch in image order.
+
+    ``device_scale`` (nccl backend, the SAME value on every rank or None on every rank) switches the box / label gathers to
+    device-originated payloads: a rank that had work passes ``device_results`` (``Pipeline.recognize_device_raw``: where its
+    results still lie in HBM, boxes in detector-input pixels) and its packed tensors are built on the device from those
+    buffers (`_pack_on_device`) -- nothing is copied up from the host; every rank then divides the gathered boxes by the
+    scale exactly as the host path does before its gather (``tools.adjust_boxes``: the same float32 product), so the result
+    is identical bit for bit.
 
     ``error``: the exception the local chain raised, if any.  The counts exchange carries a status slot, so a
     data-dependent failure on one rank (the reference raises IndexError at detection.py:272 on an empty contour
@@ -152,16 +184,32 @@ def gather_packed(box_groups, labels, per_rank_images, group=None, error=None, t
         raise exc
     cap = max(int(all_c[:, :-2].sum(axis=1).max()), 1)
     # 2. + 3. packed boxes and label rows, capacity = the busiest rank's crop count
-    b = torch.zeros((cap, 8), dtype=torch.float32)
-    b[:m_local] = torch.from_numpy(boxes_local)
-    l = torch.full((cap, LABEL_WIDTH), -1, dtype=torch.int32)
-    l[:m_local] = torch.from_numpy(labels)
+    # every rank must take the same branch below: the scale travels with the decision (all ranks of a device-resident batch
+    # have it or none has: recognize_device / recognize_scattered pass it on every rank that had work)
+    on_device = device_scale is not None and dev.type == "cuda"
+    if on_device and m_local:
+        if not device_results or device_results.get("m") != m_local:
+            raise RuntimeError("gather_packed: device-originated gather without this rank's device results")
+        b, l = _pack_on_device(device_results, cap, dev)
+    elif on_device:
+        b = torch.zeros((cap, 8), dtype=torch.float32, device=dev)
+        l = torch.full((cap, LABEL_WIDTH), -1, dtype=torch.int32, device=dev)
+    else:
+        b = torch.zeros((cap, 8), dtype=torch.float32)
+        b[:m_local] = torch.from_numpy(boxes_local)
+        l = torch.full((cap, LABEL_WIDTH), -1, dtype=torch.int32)
+        l[:m_local] = torch.from_numpy(labels)
+        b, l = b.to(dev), l.to(dev)
     all_b = torch.empty((world * cap, 8), dtype=torch.float32, device=dev)
     all_l = torch.empty((world * cap, LABEL_WIDTH), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(all_b, b.to(dev), group=group)
-    dist.all_gather_into_tensor(all_l, l.to(dev), group=group)
+    dist.all_gather_into_tensor(all_b, b, group=group)
+    dist.all_gather_into_tensor(all_l, l, group=group)
     all_b = all_b.cpu().numpy().reshape(world, cap, 4, 2)
     all_l = all_l.cpu().numpy().reshape(world, cap, LABEL_WIDTH)
+    if on_device and device_scale != 1:
+        all_b = all_b * (1 / device_scale)  # tools.adjust_boxes (pipeline.py:66-71), as Pipeline._adjust does on the host path
+    if timing is not None:
+        timing["gather_packed_on_device"] = on_device
     if timing is not None:
         timing["gather_s"] = timing.get("gather_s", 0.0) + (time.perf_counter() - t0)
         timing["gather_payload_bytes_per_rank"] = packed_payload_bytes(per_rank_images, cap)["total"]
@@ -214,8 +262,20 @@ class ShardedPipeline:
         whole batch's padded size is the shard's."""
         rank, world = self._rank_world()
         start, end = shard_bounds(n_total, world, rank)
-        return self._run_shard(lambda: self.pipeline.recognize_device_raw(d_ptr, end - start, h, w, detection_kwargs),
-                               end > start, -(-n_total // world), timing)
+        dev_res, scale = self._device_gather(n_total, h, w)
+        return self._run_shard(lambda: self.pipeline.recognize_device_raw(d_ptr, end - start, h, w, detection_kwargs, dev_res),
+                               end > start, -(-n_total // world), timing, dev_res, scale)
+
+    def _device_gather(self, n_total, h, w):
+        """(dict to receive the device results, scale) when the result gathers can be device-originated -- RCCL group, the
+        real Pipeline (one image size, hence one scale, known on every rank from the plan) -- else (None, None)."""
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "nccl" and n_total > 0 and
+                hasattr(self.pipeline, "recognize_device_raw") and getattr(getattr(self.pipeline, "detector", None), "_ctx", None) is not None):
+            return None, None
+        scales = self.pipeline._plan([(h, w, 3)] * n_total)[0]  # pylint: disable=protected-access
+        return {}, scales[0]
 
     def recognize_scattered(self, batch, n_total, h, w, src_rank=0, detection_kwargs=None, timing=None):
         """the WHOLE (n_total, h, w, 3) uint8 batch starts on ONE rank -- ``batch`` is a torch tensor
@@ -272,20 +332,22 @@ class ShardedPipeline:
             timing["scatter_bytes_sent"] = (per * (world - 1) * h * w * 3) if (distributed and rank == src_rank and src_error is None) else 0
         n_mine = end - start
 
+        dev_res, scale = self._device_gather(n_total, h, w)
+
         def run():
             if src_error is not None:
                 raise src_error
             if mine.device.type == "cuda":
-                return self.pipeline.recognize_device_raw(mine.data_ptr(), n_mine, h, w, detection_kwargs)
+                return self.pipeline.recognize_device_raw(mine.data_ptr(), n_mine, h, w, detection_kwargs, dev_res)
             # host tensors (gloo): the same call as recognize(); every image has the batch's size
             _, _, _, hmax, wmax = self.pipeline._plan([(h, w, 3)] * n_total)  # pylint: disable=protected-access
             return self.pipeline.recognize_raw(mine[:n_mine].numpy(), hmax, wmax, detection_kwargs, None)
 
         if distributed and mine is None:  # the source failed: nobody has a block; the source reports why
-            return self._run_shard(run, rank == src_rank, per, timing)
-        return self._run_shard(run, n_mine > 0, per, timing)
+            return self._run_shard(run, rank == src_rank, per, timing, dev_res, scale)
+        return self._run_shard(run, n_mine > 0, per, timing, dev_res, scale)
 
-    def _run_shard(self, run, has_work, per, timing):
+    def _run_shard(self, run, has_work, per, timing, device_results=None, device_scale=None):
         box_groups, labels, err = [], np.zeros((0, LABEL_WIDTH), np.int32), None
         try:
             if has_work:
@@ -298,5 +360,6 @@ class ShardedPipeline:
                         np.asarray(b, np.float32).reshape(-1, 8)
         except Exception as e:  # noqa: BLE001 -- exchanged as a status flag so that no rank is left in a collective
             box_groups, labels, err = [], np.zeros((0, LABEL_WIDTH), np.int32), e
-        box_groups, labels = gather_packed(box_groups, labels, per, self.group, error=err, timing=timing)
+        box_groups, labels = gather_packed(box_groups, labels, per, self.group, error=err, timing=timing,
+                                           device_results=device_results, device_scale=device_scale)
         return self.pipeline.assemble(box_groups, labels)

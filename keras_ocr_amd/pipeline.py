@@ -119,8 +119,11 @@ class Pipeline:
         (n,h,w,3) uint8 tensor (e.g. ``torch.Tensor.data_ptr()``)."""
         return self.assemble(*self.recognize_device_raw(d_ptr, n, h, w, detection_kwargs))
 
-    def recognize_device_raw(self, d_ptr, n, h, w, detection_kwargs=None):
-        """recognize_device up to (but not including) string assembly: ``(box_groups, label_rows)`` as recognize_raw."""
+    def recognize_device_raw(self, d_ptr, n, h, w, detection_kwargs=None, device_results=None):
+        """recognize_device up to (but not including) string assembly: ``(box_groups, label_rows)`` as recognize_raw.
+        ``device_results`` (a dict, optional) receives where the same results still lie in HBM (``Context.
+        pipeline_device_results``: boxes in DETECTOR-input pixels, before the division by the scale) plus ``scale``, for a
+        caller that packs them on the device (``dist.gather_packed``); valid until the next call on the context."""
         detection_kwargs = dict(detection_kwargs or {})
         ctx = self.detector._ctx  # pylint: disable=protected-access
         scales, dhs, dws, hmax, wmax = self._plan([(h, w, 3)] * n)
@@ -128,6 +131,9 @@ class Pipeline:
         stride = h * w * 3
         box_groups, labels = ctx.pipeline([int(d_ptr) + i * stride for i in range(n)], [h] * n, [w] * n, dhs, dws,
                                           hmax, wmax, micro_batch=micro_batch, on_device=True, **detection_kwargs)
+        if device_results is not None and n:
+            device_results.update(ctx.pipeline_device_results())
+            device_results["scale"] = scales[0]  # one size, one scale
         return self._adjust(box_groups, scales), labels
 
     @staticmethod

@@ -75,8 +75,36 @@ def test_sharded_device_resident_batch_over_rccl(nccl_group, pipe):
     pages = np.stack([synth.text_page(96, 128, 5, seed=s) for s in (31, 32, 33)])
     want = pipe.recognize(pages)
     d = torch.from_numpy(pages).cuda()
-    got = keras_ocr_amd.dist.ShardedPipeline(pipe).recognize_device(d.data_ptr(), 3, 96, 128)
+    timing = {}
+    got = keras_ocr_amd.dist.ShardedPipeline(pipe).recognize_device(d.data_ptr(), 3, 96, 128, timing=timing)
     _same(got, want)
+    # round 5: the packed tensors RCCL moved were built in HBM from the buffers kocr_pipeline left there (no host staging),
+    # and the result is bit-identical to the host-packed one
+    assert timing["gather_packed_on_device"] is True
+
+
+def test_device_results_of_the_last_pipeline_call(nccl_group, pipe, ctx):
+    """kocr_pipeline_device_results: the same boxes / counts / label rows kocr_pipeline returned, still resident in HBM."""
+    import torch
+    from keras_ocr_amd.dist import _DeviceArray
+
+    pages = np.stack([synth.text_page(96, 128, 5, seed=s) for s in (31, 32, 33)])
+    d = torch.from_numpy(pages).cuda()
+    res = {}
+    boxes, labels = pipe.recognize_device_raw(d.data_ptr(), 3, 96, 128, device_results=res)
+    assert res["n"] == 3 and res["m"] == labels.shape[0] == sum(len(b) for b in boxes) > 0 and res["scale"] == 2
+    counts = torch.as_tensor(_DeviceArray(res["counts"], (3,), "<i4"), device="cuda").cpu().numpy()
+    assert list(counts) == [len(b) for b in boxes]
+    lab = torch.as_tensor(_DeviceArray(res["labels"], (res["m"], 48), "<i4"), device="cuda").cpu().numpy()
+    assert np.array_equal(lab, labels)
+    bx = torch.as_tensor(_DeviceArray(res["boxes"], (3, res["cap"], 4, 2), "<f4"), device="cuda").cpu().numpy()
+    for i, b in enumerate(boxes):
+        if len(b):
+            assert np.array_equal(bx[i, :len(b)] * np.float32(0.5), np.asarray(b))
+    # nothing resident after a call that reuses the arenas
+    ctx.craft_forward(pages[:1])
+    with pytest.raises(Exception, match="no kocr_pipeline result"):
+        ctx.pipeline_device_results()
 
 
 def test_gather_packed_on_hbm_tensors_empty_rank(nccl_group):
@@ -100,5 +128,8 @@ def test_scattered_batch_over_rccl(nccl_group, pipe):
                                                                        timing=timing)
     _same(got, want)
     assert timing["scatter_s"] > 0 and timing["scatter_bytes_sent"] == 0 and timing["gather_s"] > 0
-    with pytest.raises(ValueError, match="source rank needs"):
+    assert timing["gather_packed_on_device"] is True
+    # a missing batch on the source rank: announced to every rank before the scatter, raised as ShardError everywhere (round 5)
+    with pytest.raises(keras_ocr_amd.dist.ShardError, match="ValueError") as ei:
         keras_ocr_amd.dist.ShardedPipeline(pipe).recognize_scattered(None, 3, 96, 128, src_rank=0)
+    assert isinstance(ei.value.__cause__, ValueError) and "source rank needs" in str(ei.value.__cause__)

@@ -112,6 +112,17 @@ int kocr_get_boxes(kocr_ctx* ctx, const float* heat, int N, int h, int w, float 
 int kocr_warp_crops(kocr_ctx* ctx, const uint8_t* img_rgb, int N, int H, int W, const float* boxes,
                     const int32_t* counts, int target_h, int target_w, float* crops, int on_device);
 
+/* ---- float images (round 5) --------------------------------------------------------------------------------------------
+ * The reference hands cv2 whatever dtype it is given: a float image is resized, converted to gray and warped IN FLOAT
+ * (tools.py:394, recognition.py:507-526).  These are the float forms of kocr_resize_pad / kocr_warp_crops: bilinear with
+ * half-pixel centres and replicated border, float32 arithmetic (horizontal then vertical pass); gray = 0.299 R + 0.587 G +
+ * 0.114 B, perspective warp with 1/32-pixel source coordinates, float weights and constant-0 border, the crop NOT divided by
+ * 255 (the caller's, recognition.py:524).  channels = 3 (RGB) or 1 (gray) for the warp, any for the resize.  Host pointers. */
+int kocr_resize_pad_f32(kocr_ctx* ctx, const float* src, int n, int sh, int sw, int channels, int dh, int dw, int Hmax, int Wmax,
+                        float cval, float* dst);
+int kocr_warp_crops_f32(kocr_ctx* ctx, const float* img, int N, int H, int W, int channels, const float* boxes,
+                        const int32_t* counts, int target_h, int target_w, float* crops);
+
 /* The general form of tools.warpBox (tools.py:61-117: margin, skip_rotate, target size taken from the box,
  * return_transform): the caller states the ordered source quad and the destination quad of each of the M crops;
  * cv2.getPerspectiveTransform (8x8 float64 LU, on the device) + cv2.warpPerspective as above.  All buffers are HOST

@@ -70,6 +70,8 @@ def load_library():
         "kocr_pipeline": (ci, [vp, ci, ctypes.POINTER(vp), _c_int_p, _c_int_p, _c_int_p, _c_int_p, ci, ci,
                                ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, ci, vp, ci, vp, ci]),
         "kocr_pipeline_device_results": (ci, [vp, vp, vp, vp, vp, vp, vp]),
+        "kocr_resize_pad_f32": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ctypes.c_float, vp]),
+        "kocr_warp_crops_f32": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp]),
         "kocr_conv2d_nhwc": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp]),
         "kocr_conv2d_cells": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, vp, vp, vp]),
         "kocr_set_split_mode": (ci, [vp, ci]),
@@ -326,6 +328,37 @@ class Context:
         hmax, wmax = (dh, dw) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
         out = np.empty((n, hmax, wmax, 3), dtype=np.uint8)
         self._check(self._lib.kocr_resize_pad(self._h, _ptr(x), n, sh, sw, dh, dw, hmax, wmax, int(cval), _ptr(out), 0))
+        return out
+
+    def resize_pad_f32(self, images, dsize, out_hw=None, cval=255.0):
+        """float images: (n,sh,sw,c) float32; dsize=(dw,dh) as cv2.resize (bilinear, in float); out_hw=(Hmax,Wmax) canvas."""
+        x = np.ascontiguousarray(images, dtype=np.float32)
+        n, sh, sw, c = x.shape
+        dw, dh = int(dsize[0]), int(dsize[1])
+        hmax, wmax = (dh, dw) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
+        out = np.empty((n, hmax, wmax, c), dtype=np.float32)
+        self._check(self._lib.kocr_resize_pad_f32(self._h, _ptr(x), n, sh, sw, c, dh, dw, hmax, wmax, float(cval), _ptr(out)))
+        return out
+
+    def warp_crops_f32(self, images, box_groups, target_height=31, target_width=200):
+        """float images: (N,H,W,3 or 1) float32; box_groups: list of (n_i,4,2).  Returns (M,th,tw) float32 gray crops in the
+        image's own value range (NOT divided by 255)."""
+        x = np.ascontiguousarray(images, dtype=np.float32)
+        n, h, w, c = x.shape
+        if c not in (1, 3):
+            raise ValueError("images must be RGB or gray")
+        counts = np.array([len(b) for b in box_groups], dtype=np.int32)
+        m = int(counts.sum())
+        out = np.zeros((m, target_height, target_width), dtype=np.float32)
+        if m == 0:
+            return out
+        flat = np.ascontiguousarray(
+            np.concatenate([np.asarray(b, dtype=np.float32).reshape(-1, 4, 2) for b in box_groups if len(b)]))
+        rc = self._lib.kocr_warp_crops_f32(self._h, _ptr(x), n, h, w, c, _ptr(flat), _ptr(counts), int(target_height),
+                                           int(target_width), _ptr(out))
+        if rc == -7:
+            raise ZeroDivisionError("division by zero")  # tools.py:95
+        self._check(rc)
         return out
 
     # -- fused Pipeline.recognize ----------------------------------------------------------------

@@ -388,6 +388,63 @@ int kocr_warp_crops(kocr_ctx* ctx, const uint8_t* img_rgb, int N, int H, int W, 
   return KOCR_OK;
 }
 
+// float images (round 5): the same two image operations in float, see imgproc.hip / warp.hip.  Host pointers.
+int kocr_resize_pad_f32(kocr_ctx* ctx, const float* src, int n, int sh, int sw, int channels, int dh, int dw, int Hmax, int Wmax,
+                        float cval, float* dst) {
+  if (!ctx) return KOCR_EINVAL;
+  if (n < 0 || channels <= 0 || (n > 0 && (!src || !dst))) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_resize_pad_f32: bad argument");
+  if (n == 0) return KOCR_OK;
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t sb = (size_t)n * sh * sw * channels * sizeof(float), db = (size_t)n * Hmax * Wmax * channels * sizeof(float);
+  const size_t tb = (size_t)(3 * (Wmax + Hmax) + 64) * sizeof(int);
+  KOCR_TRY(arena_reserve(ctx, ctx->io, tb + sb + db + 4096));
+  ctx->io.off = 0;
+  float* ds = (float*)arena_alloc(ctx->io, sb);
+  float* dd = (float*)arena_alloc(ctx->io, db);
+  KOCR_HIP(ctx, hipMemcpyAsync(ds, src, sb, hipMemcpyHostToDevice, ctx->stream));
+  KOCR_TRY(launch_resize_pad_f32(ctx, ds, n, sh, sw, channels, dd, dh, dw, Hmax, Wmax, cval, ctx->io));
+  KOCR_HIP(ctx, hipMemcpyAsync(dst, dd, db, hipMemcpyDeviceToHost, ctx->stream));
+  KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KOCR_OK;
+}
+
+int kocr_warp_crops_f32(kocr_ctx* ctx, const float* img, int N, int H, int W, int channels, const float* boxes, const int32_t* counts,
+                        int target_h, int target_w, float* crops) {
+  if (!ctx) return KOCR_EINVAL;
+  if (N < 0 || target_h <= 0 || target_w <= 0 || (channels != 1 && channels != 3) || (N > 0 && (!img || !counts)))
+    KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_warp_crops_f32: bad argument");
+  long M = 0;
+  for (int i = 0; i < N; ++i) {
+    if (counts[i] < 0) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_warp_crops_f32: negative count");
+    M += counts[i];
+  }
+  if (M == 0) return KOCR_OK;
+  if (!boxes || !crops) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_warp_crops_f32: null buffer");
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<WarpParam> prm((size_t)M);
+  long m = 0;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < counts[i]; ++j, ++m) {
+      const int rc = warp_prepare(boxes + m * 8, target_h, target_w, &prm[m], nullptr);
+      if (rc == 1) KOCR_FAIL(ctx, KOCR_EZERODIV, "kocr_warp_crops_f32: box with zero width or height (ZeroDivisionError at tools.py:95)");
+      if (rc != 0) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_warp_crops_f32: singular perspective transform");
+      prm[m].img = i;
+    }
+  const size_t ib = (size_t)N * H * W * channels * sizeof(float), cb = (size_t)M * target_h * target_w * sizeof(float);
+  const size_t pb = (size_t)M * sizeof(WarpParam);
+  KOCR_TRY(arena_reserve(ctx, ctx->io, pb + ib + cb + 4096));
+  ctx->io.off = 0;
+  WarpParam* d_prm = (WarpParam*)arena_alloc(ctx->io, pb);
+  float* di = (float*)arena_alloc(ctx->io, ib);
+  float* d_crops = (float*)arena_alloc(ctx->io, cb);
+  KOCR_HIP(ctx, hipMemcpyAsync(d_prm, prm.data(), pb, hipMemcpyHostToDevice, ctx->stream));
+  KOCR_HIP(ctx, hipMemcpyAsync(di, img, ib, hipMemcpyHostToDevice, ctx->stream));
+  KOCR_TRY(launch_warp_f32(ctx, di, H, W, channels, d_prm, (int)M, target_h, target_w, d_crops));
+  KOCR_HIP(ctx, hipMemcpyAsync(crops, d_crops, cb, hipMemcpyDeviceToHost, ctx->stream));
+  KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return KOCR_OK;
+}
+
 int kocr_warp_quads(kocr_ctx* ctx, const uint8_t* img_rgb, int N, int H, int W, int M, const float* src_quads,
                     const float* dst_quads, const int32_t* image_index, const int32_t* crop_w, const int32_t* crop_h,
                     int target_h, int target_w, float* crops, double* transforms) {

@@ -385,5 +385,8 @@ int launch_warp_quads(kocr_ctx* ctx, const float* d_src, const float* d_dst, con
                       const int* d_ch, int M, WarpParam* d_prm, double* d_mfwd, int* d_status);
 
 // imgproc.hip
+int launch_resize_pad_f32(kocr_ctx* ctx, const float* d_src, int n, int sh, int sw, int C, float* d_dst, int dh, int dw, int Hmax,
+                          int Wmax, float cval, Arena& tab_arena);
+int launch_warp_f32(kocr_ctx* ctx, const float* d_img, int H, int W, int C, const WarpParam* d_prm, int M, int th, int tw, float* d_crops);
 int launch_resize_pad(kocr_ctx* ctx, const uint8_t* d_src, int n, int sh, int sw, uint8_t* d_dst, int dh, int dw,
                       int Hmax, int Wmax, int cval, Arena& tab_arena);

@@ -366,3 +366,54 @@ int launch_warp(kocr_ctx* ctx, const uint8_t* d_img, int H, int W, const WarpPar
   KOCR_HIP(ctx, hipGetLastError());
   return KOCR_OK;
 }
+
+
+// Float images (round 5): cvtColor(RGB2GRAY) + warpPerspective of a float32 image work in float (recognition.py:507-526 hands
+// cv2 the image's own type): gray = (0.299 R + 0.587 G) + 0.114 B per tap in float32, the same 1/32-pixel source coordinates
+// as the uint8 kernel (OpenCV's remap tables), FLOAT weights a / 32, four products summed in the order
+// t00 w00 + t01 w01 + t10 w10 + t11 w11, constant-0 border; NO division by 255 (the caller's, recognition.py:524).
+// C = 3 (RGB) or 1 (already gray).  -ffp-contract=off: equals oracle/tools.py::warp_box_float's arithmetic.
+__global__ void warp_f32_kernel(const float* __restrict__ img, int H, int W, int C, const WarpParam* __restrict__ prm, int th, int tw,
+                                float* __restrict__ crops) {
+  const int m = blockIdx.y;
+  const WarpParam p = prm[m];
+  const float* im = img + (size_t)p.img * H * W * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < th * tw; i += gridDim.x * blockDim.x) {
+    const int y = i / tw, x = i - y * tw;
+    float v = 0.f;
+    if (x < p.cw && y < p.ch) {
+      const double xd = (double)x, yd = (double)y;
+      const double X0 = (p.mi[0] * xd + p.mi[1] * yd) + p.mi[2];
+      const double Y0 = (p.mi[3] * xd + p.mi[4] * yd) + p.mi[5];
+      const double W0 = (p.mi[6] * xd + p.mi[7] * yd) + p.mi[8];
+      const double Wi = W0 != 0.0 ? 32.0 / W0 : 0.0;
+      const double fX = fmax(-2147483648.0, fmin(2147483647.0, X0 * Wi));
+      const double fY = fmax(-2147483648.0, fmin(2147483647.0, Y0 * Wi));
+      const long X = (long)rint(fX), Y = (long)rint(fY);
+      const long sx = X >> 5, sy = Y >> 5;
+      const float ax = (float)((double)(X & 31) / 32.0), ay = (float)((double)(Y & 31) / 32.0);
+      auto tap = [&](long yy, long xx) -> float {
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) return 0.f;
+        const float* q = im + ((size_t)yy * W + xx) * C;
+        return C == 3 ? (q[0] * 0.299f + q[1] * 0.587f) + q[2] * 0.114f : q[0];
+      };
+      const float one = 1.f;
+      v = ((tap(sy, sx) * ((one - ax) * (one - ay)) + tap(sy, sx + 1) * (ax * (one - ay))) + tap(sy + 1, sx) * ((one - ax) * ay)) +
+          tap(sy + 1, sx + 1) * (ax * ay);
+    }
+    crops[(size_t)m * th * tw + i] = v;
+  }
+}
+
+int launch_warp_f32(kocr_ctx* ctx, const float* d_img, int H, int W, int C, const WarpParam* d_prm, int M, int th, int tw, float* d_crops) {
+  if (M <= 0) return KOCR_OK;
+  ProfScope ps(ctx, "warp_crops_f32", 0, (double)M * th * tw * (4.0 + 16.0 * C));
+  const int bx = (th * tw + 255) / 256;
+  for (int s = 0; s < M; s += 65535) {
+    const int mb = std::min(65535, M - s);
+    hipLaunchKernelGGL(warp_f32_kernel, dim3(bx, mb), dim3(256), 0, ctx->stream, d_img, H, W, C, d_prm + s, th, tw,
+                       d_crops + (size_t)s * th * tw);
+  }
+  KOCR_HIP(ctx, hipGetLastError());
+  return KOCR_OK;
+}

@@ -104,7 +104,7 @@ class _DeviceArray:
     """A device buffer libkocr owns, as something ``torch.as_tensor(..., device="cuda")`` takes without a copy."""
 
     def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), True), "version": 2}
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
 def _pack_on_device(dev_res, cap, dev):

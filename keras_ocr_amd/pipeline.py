@@ -80,8 +80,8 @@ class Pipeline:
         ctx = getattr(self.detector, "_ctx", None)
         if any(im.dtype != np.uint8 for im in images):
             # float (or any non-uint8) images: the reference's cv2 calls interpolate them in float (tools.py:394, :107);
-            # the stage-wise path does the same on the host (tools.resize_linear_float / warp_box_float) -- off the fused
-            # fixed-point GPU path, which is defined for uint8 pixels only
+            # the stage-wise path does the same with the float kernels (kocr_resize_pad_f32 / kocr_warp_crops_f32, round 5) --
+            # off the fused fixed-point path, which is defined for uint8 pixels only
             return self._recognize_stagewise([im.astype(np.float32) for im in images], detection_kwargs, hmax, wmax)
         if ctx is None or getattr(self.recognizer, "_ctx", None) is not ctx:
             # duck-typed / separately-placed stages: the reference's stage-wise path (pipeline.py:44-75)
@@ -99,7 +99,9 @@ class Pipeline:
         """pipeline.py:44-75 with the public stage APIs only (any object with ``detect`` /
         ``recognize_from_boxes``); strings are mapped back to label rows through the recognizer's alphabet.
         ``hmax`` / ``wmax``: padded size imposed by the caller (a sharded batch pads to the WHOLE batch's size)."""
-        resized = [tools.resize_image(image, max_scale=self.scale, max_size=self.max_size) for image in images]
+        own = getattr(self.detector, "_ctx", None)  # a libkocr-backed detector: its context also resizes (else the default one)
+        resized = [tools.resize_image(image, max_scale=self.scale, max_size=self.max_size, **({"ctx": own} if own is not None else {}))
+                   for image in images]
         max_height, max_width = np.array([image.shape[:2] for image, _ in resized]).max(axis=0)
         max_height = max(int(max_height), int(hmax or 0))
         max_width = max(int(max_width), int(wmax or 0))

@@ -129,12 +129,13 @@ class Recognizer:
         images = [np.asarray(image) for image in images]
         if any(im.dtype != np.uint8 for im in images):
             # float images (recognition.py:507-526 works in the image's own type): gray conversion and the crop warp in
-            # float on the host (tools.rgb2gray_float / warp_box_float), the recogniser itself on the GPU
+            # float ON THE GPU (kocr_warp_crops_f32, round 5), the division by 255 of :524, the recogniser
             crops = []
             for image, boxes in zip(images, box_groups):
-                gray = tools.rgb2gray_float(image) if image.ndim == 3 and image.shape[-1] == 3 else np.asarray(image, np.float32)
-                crops += [tools.warp_box_float(gray, box, 31, 200) for box in boxes]
-            labels = self._ctx.crnn_forward(np.stack(crops) / np.float32(255))
+                if len(boxes):
+                    im = np.asarray(image, np.float32)
+                    crops.append(self._ctx.warp_crops_f32((im if im.ndim == 3 else im[..., np.newaxis])[np.newaxis], [boxes], 31, 200))
+            labels = self._ctx.crnn_forward(np.concatenate(crops) / np.float32(255))
             predictions = self._decode(labels)
             return [predictions[start:end] for start, end in start_end]
         if len({im.shape for im in images}) == 1:

@@ -350,3 +350,86 @@ def warp_box(image, box, target_height, target_width):
     full = np.zeros((target_height, target_width), dtype=np.uint8)
     full[: crop.shape[0], : crop.shape[1]] = crop
     return full
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Float images (any dtype but uint8): the reference's cv2 calls work in the image's own type -- cv2.resize interpolates in
+# float (tools.py:394), cvtColor / warpPerspective likewise (recognition.py:510, tools.py:107).  This is the numpy
+# restatement of those three operations (round 4's host path of the product; since round 5 the product runs them on the GPU
+# and these are the ORACLE its kernels are compared with, tests/test_float_gpu.py).  NOT pinned to OpenCV, which is absent
+# from this image: checked against torch's half-pixel bilinear interpolation and against the fixed-point uint8 warp only
+# (tests/test_oracle_cpu.py) -- "parity unpinned" for the float path.
+# ---------------------------------------------------------------------------------------------------------------------
+def resize_linear_float(image, dsize):
+    """cv2.resize(image, dsize=(width, height)) for a float image, INTER_LINEAR: source coordinate
+    (d + 0.5) * (src / dst) - 0.5, taps clamped to the image (replicated border), horizontal pass then vertical
+    pass, float32 coefficients."""
+    src = np.asarray(image, dtype=np.float32)
+    dw, dh = int(dsize[0]), int(dsize[1])
+    sh, sw = src.shape[:2]
+    if (dw, dh) == (sw, sh):
+        return src.copy()
+
+    def taps(dst_n, src_n):
+        f = (np.arange(dst_n, dtype=np.float64) + 0.5) * (src_n / dst_n) - 0.5
+        i0 = np.floor(f).astype(np.int64)
+        a = (f - i0).astype(np.float32)
+        a[i0 < 0] = 0
+        i0 = np.clip(i0, 0, src_n - 1)
+        i1 = np.clip(i0 + 1, 0, src_n - 1)
+        return i0, i1, a
+
+    x0, x1, ax = taps(dw, sw)
+    y0, y1, ay = taps(dh, sh)
+    ax = ax.reshape((1, dw) + (1,) * (src.ndim - 2))
+    ay = ay.reshape((dh, 1) + (1,) * (src.ndim - 2))
+    rows = src[:, x0] * (np.float32(1) - ax) + src[:, x1] * ax
+    return (rows[y0] * (np.float32(1) - ay) + rows[y1] * ay).astype(np.float32)
+
+
+def rgb2gray_float(image):
+    """cv2.cvtColor(float image, COLOR_RGB2GRAY): 0.299 R + 0.587 G + 0.114 B in float32."""
+    im = np.asarray(image, dtype=np.float32)
+    return im[..., 0] * np.float32(0.299) + im[..., 1] * np.float32(0.587) + im[..., 2] * np.float32(0.114)
+
+
+def warp_box_float(gray, box, target_height=31, target_width=200):
+    """tools.warpBox (tools.py:61-117, margin 0, cval 0) of a 2-D float image: get_rotated_box, integer width / height,
+    homography box -> [[0,0],[s w,0],[s w,s h],[0,s h]], cv2.warpPerspective with INTER_LINEAR (source coordinates rounded
+    to 1/32 pixel as OpenCV's remap does, float weights, constant-0 border), pasted top-left into target_height x
+    target_width zeros."""
+    box, _ = get_rotated_box(box)
+    w, h = get_rotated_width_height(box)
+    scale = min(target_width / w, target_height / h)  # ZeroDivisionError for an empty box, as in the reference
+    dst = np.array([[0, 0], [scale * w, 0], [scale * w, scale * h], [0, scale * h]], np.float32).astype(np.float64)
+    srcq = np.asarray(box, np.float32).astype(np.float64)
+    a, b = [], []
+    for (x, y), (u, v) in zip(srcq, dst):  # getPerspectiveTransform: 8 x 8 system for M (src -> dst)
+        a.append([x, y, 1, 0, 0, 0, -x * u, -y * u])
+        a.append([0, 0, 0, x, y, 1, -x * v, -y * v])
+        b += [u, v]
+    m = np.append(np.linalg.solve(np.array(a), np.array(b)), 1.0).reshape(3, 3)
+    mi = np.linalg.inv(m)
+    cw, ch = int(scale * w), int(scale * h)
+    out = np.zeros((target_height, target_width), np.float32)
+    cw, ch = min(cw, target_width), min(ch, target_height)
+    if cw <= 0 or ch <= 0:
+        return out
+    xs, ys = np.meshgrid(np.arange(cw, dtype=np.float64), np.arange(ch, dtype=np.float64))
+    den = mi[2, 0] * xs + mi[2, 1] * ys + mi[2, 2]
+    den = np.where(den != 0, 1.0 / den, 0.0)
+    fx = np.rint((mi[0, 0] * xs + mi[0, 1] * ys + mi[0, 2]) * den * 32).astype(np.int64)
+    fy = np.rint((mi[1, 0] * xs + mi[1, 1] * ys + mi[1, 2]) * den * 32).astype(np.int64)
+    x0, y0 = fx >> 5, fy >> 5
+    ax, ay = ((fx & 31) / 32.0).astype(np.float32), ((fy & 31) / 32.0).astype(np.float32)
+    g = np.asarray(gray, np.float32)
+    hh, ww = g.shape
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < hh) & (xx >= 0) & (xx < ww)
+        return np.where(ok, g[np.clip(yy, 0, hh - 1), np.clip(xx, 0, ww - 1)], np.float32(0))
+
+    one = np.float32(1)
+    out[:ch, :cw] = (tap(y0, x0) * ((one - ax) * (one - ay)) + tap(y0, x0 + 1) * (ax * (one - ay))
+                     + tap(y0 + 1, x0) * ((one - ax) * ay) + tap(y0 + 1, x0 + 1) * (ax * ay))
+    return out

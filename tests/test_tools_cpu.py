@@ -69,18 +69,18 @@ def test_read_depth_and_alpha_follow_the_two_cv2_calls(tmp_path):
 
 
 def test_float_resize_is_half_pixel_bilinear():
+    """the ORACLE's statement of cv2.resize on a float image (the product runs it on the GPU: tests/test_float_gpu.py)"""
     import torch
+    from oracle import tools as otools
 
     rng = np.random.default_rng(0)
     im = (rng.random((37, 53, 3)) * 255).astype(np.float32)
     for dw, dh in ((106, 74), (80, 55), (53, 37), (71, 60)):
-        got = tools.resize_linear_float(im, (dw, dh))
+        got = otools.resize_linear_float(im, (dw, dh))
         want = torch.nn.functional.interpolate(torch.from_numpy(im).permute(2, 0, 1)[None], size=(dh, dw), mode="bilinear",
                                                align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
         assert got.shape == (dh, dw, 3) and got.dtype == np.float32
         assert float(np.abs(got - want).max()) <= 2e-3
-    out, scale = tools.resize_image(im, max_scale=2, max_size=2048)                   # the float branch of resize_image
-    assert scale == 2 and out.shape == (74, 106, 3) and out.dtype == np.float32
 
 
 def test_float_warp_agrees_with_the_fixed_point_warp_to_one_level():
@@ -91,11 +91,11 @@ def test_float_warp_agrees_with_the_fixed_point_warp_to_one_level():
     for box in (np.array([[20, 15], [110, 15], [110, 40], [20, 40]], np.float32),
                 np.array([[30, 20], [100, 38], [94, 62], [24, 44]], np.float32)):
         want = otools.warp_box(gray, box, 31, 200).astype(np.float32)
-        got = tools.warp_box_float(gray.astype(np.float32), box, 31, 200)
+        got = otools.warp_box_float(gray.astype(np.float32), box, 31, 200)
         assert got.shape == (31, 200) and got.dtype == np.float32
         d = np.abs(got - want)
         assert float(d.max()) <= 1.0 + 1e-3 and float((d > 0.51).mean()) <= 0.02     # rounding of the uint8 result only
-    assert np.array_equal(tools.rgb2gray_float(np.full((2, 2, 3), 100, np.float32)), np.full((2, 2), 100, np.float32))
+    assert np.array_equal(otools.rgb2gray_float(np.full((2, 2, 3), 100, np.float32)), np.full((2, 2), 100, np.float32))
 
 
 def test_draw_helpers_smoke():

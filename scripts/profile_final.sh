@@ -11,6 +11,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- p
 grep '^{"metric"' $OUT/trace.log | tail -1 > $OUT/bench_under_rocprof.json
 KOCR_PROF_LAYERS=1 python $REPO/scripts/perf_craft.py 8 1536 1536 5 > $OUT/craft_layers.txt 2>&1
 KOCR_PROF_LAYERS=1 python $REPO/scripts/perf_crnn.py 512 > $OUT/crnn_layers.txt 2>&1
+# round 5: the recogniser without the cell grid (round 4's dense crop batch), and the detector on a page size no level of which tiles
+KOCR_CELLS=0 KOCR_PROF_LAYERS=1 python $REPO/scripts/perf_crnn.py 512 > $OUT/crnn_layers_no_cells.txt 2>&1
+KOCR_PROF_LAYERS=1 python $REPO/scripts/perf_craft.py 8 1500 2000 5 > $OUT/craft_layers_1500x2000.txt 2>&1
+KOCR_W43RAG=0 KOCR_PROF_LAYERS=1 python $REPO/scripts/perf_craft.py 8 1500 2000 3 > $OUT/craft_layers_1500x2000_no_ragged.txt 2>&1
+(cd $REPO && python -m pytest tests/test_range_gpu.py -q -m gpu -s 2>&1 | grep -E "lognormal|one_outlier|99pct|ordinary:|heavy_tailed:|passed|failed" > $OUT/range_stats.txt)
 CMD="python $REPO/scripts/perf_craft.py 8 1536 1536 1"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/p1 -o p1 -- $CMD > $OUT/p1.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/p2 -o p2 -- $CMD > $OUT/p2.log 2>&1

@@ -19,8 +19,9 @@ host-array input (`value_host_arrays`, PCIe inclusive), CRNN only (configs[2]),
 CRAFT only (configs[1]), one rank's share of configs[4], and -- on every rank, also at N = 1 -- `cfg5_sharded`:
 ONE configs[4] batch of 32 x N pages of 1536x1536 (256 pages at N = 8) through `dist.ShardedPipeline`, each rank's block
 resident in its HBM, with the three RCCL result all-gathers INSIDE the timed region (`gather_ms`).  `parity` compares
-pages 0, 9, 18 and 31 of the timed batch with the CPU oracle (page 0 is the `cpu_baseline` run), counting the heat-map
-pixels that sit on the other side of a getBoxes threshold (oracle/parity.py).
+eight pages of the timed batch with the CPU oracle (page 0 is the `cpu_baseline` run), in both fp32-class arithmetic modes, counting the heat-map
+pixels that sit on the other side of a getBoxes threshold (oracle/parity.py).  `odd_sizes` (rank 0, never `value`): the same
+pipeline on 32 pages of 750 x 1000 (detector input 1500 x 2000: no pyramid level tiles), images/s and the convolutions' TFLOP/s.
 """
 import argparse
 import json

@@ -1901,6 +1901,9 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
       p.cells_per_row = in.W / in.cellW;
     }
   }
+  w4_div_magic((unsigned)(p.qpr > 0 ? p.qpr : 1), p.dv_qpr);
+  w4_div_magic((unsigned)L.dil, p.dv_dil);
+  w4_div_magic((unsigned)in.H, p.dv_h);
   w4_div_magic((unsigned)(p.rq_per_img ? p.rq_per_img : 1), p.dv_rq);
   w4_div_magic((unsigned)(p.cellW ? p.cellW : 1), p.dv_wc);
   p.total_tiles = p.n_mpairs * (p.Cout_pad / (narrow ? 64 : 128));
@@ -1914,7 +1917,9 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   const int pieces = ctx->split_mode == KOCR_SPLIT_F16X2 ? 2 : ctx->split_mode == KOCR_SPLIT_F16X1 ? 1 : 0;
   const bool no_h = !ctx->sw.w43h;
   // ... the flattened-pixel arrangement too (no fused pooling, dilation 1; a 256-pixel tile must not span three images)
-  const bool flat_h = pieces && !no_h && L.d_w4h && !narrow && !vreuse && !rowreuse && L.dil == 1 && !fuse &&
+  // (round 5: dilated layers too -- the comb tiles of conv_w43fh_kernel<.., DIL = 1>; KOCR_W43DILH=0: bf16x3 as before)
+  static const bool no_dilh = w43_env_off("KOCR_W43DILH");
+  const bool flat_h = pieces && !no_h && L.d_w4h && !narrow && !vreuse && !rowreuse && (L.dil == 1 || !no_dilh) && !fuse &&
                       (size_t)in.H * in.W >= 256;
   const bool use_h = (pieces && !no_h && L.d_w4h && (vreuse || (rowreuse && rgeo == 1))) || flat_h;
   if (mode != 0 && !use_h) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": ragged / cell grids exist in the fp16 kernels only");

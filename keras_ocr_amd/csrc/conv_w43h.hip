@@ -1143,7 +1143,11 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
 // in; a tile of 256 pixels touches at most two images (the launcher requires H W >= 256), so the epilogue undoes the
 // scale with a per-accumulator-row select between two factors and maintains the two images' max-|x| slots separately.
 // ===================================================================================================
-template <int NP>
+// DIL = 1 (round 5): a dilated 3x3 convolution (taps p.dil pixels apart in x and y; CRAFT's composite slice5 layer, dilation 6,
+// W % (4 dil) == 0) through the same algebra on the comb of pixels of conv_w43_kernel<.., DIL = 1>: the quads of a row are its
+// W / 4 residue-class quads (quad q covers x0 + dil j, j = 0 .. 3, x0 = (q / dil) 4 dil + q % dil), a tile = 64 consecutive
+// quads over the rows of the batch; everything per quad (image, scale, padding) follows from its row.
+template <int NP, int DIL = 0>
 __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
   constexpr int PR = NP == 2 ? 3 : 1;
   constexpr int PLANE_F = PLANE;          // one (xi, piece) plane: 2 M-tiles x 2 k halves x 256 ushorts (w43_common.h)
@@ -1173,13 +1177,43 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
     int e0, e1;  // (uniform) scale exponents of the tile's first image and of the next one (the tile's second, if it has one)
     const float* base;
   };
+  const int dd = DIL ? p.dil : 1;
   auto make_geo = [&](int L, Geo& g) __attribute__((always_inline)) {
     int mp, nt_unused;
     w4_decode(p, kocr_xcd_remap(L < total ? L : 0, total), nblk_n, mp, nt_unused);
-    const long pm_a = (long)mp * 256;
-    g.base = p.in + (pm_a * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
     const int tid_f = wn * 64 + kocr_fresh_lane();  // see kocr_fresh_lane
     const int qi = tid_f >> 2, q4 = tid_f & 3;
+    if constexpr (DIL) {
+      // quad index over all rows of the batch -> (row, quad of the row) -> comb position; offsets relative to the first
+      // pixel of the tile's first row (Mtotal / 4 quads in all: < 2^29)
+      const unsigned q0 = (unsigned)mp * 64u;
+      const unsigned nq = (unsigned)(p.Mtotal >> 2);
+      const unsigned row_a = w4_fdiv(q0 < nq ? q0 : nq - 1, p.dv_qpr);
+      g.base = p.in + ((long)row_a * p.W * p.in_cs + p.in_co) - (long)(dd * p.W + dd) * p.in_cs;
+      const unsigned qg = q0 + (unsigned)qi;
+      g.gok = L < total && qg < nq;
+      const unsigned qc = qg < nq ? qg : nq - 1;
+      const unsigned row = w4_fdiv(qc, p.dv_qpr);
+      const int qr = (int)(qc - row * (unsigned)p.qpr);
+      const int qd = (int)w4_fdiv((unsigned)qr, p.dv_dil);
+      const int x0 = qd * 4 * dd + (qr - qd * dd);
+      const unsigned nimg = w4_fdiv(row, p.dv_h);
+      g.gy = (int)(row - nimg * (unsigned)p.H);
+      const int n0 = __builtin_amdgcn_readfirstlane((int)w4_fdiv(row_a, p.dv_h));
+      const int n1 = (n0 + 1 < p.Mtotal / (p.H * p.W)) ? n0 + 1 : n0;
+      g.e0 = kocr_scale_exp_bits(kocr_sload(p.amax_in + n0), W4H_TOP);
+      g.e1 = kocr_scale_exp_bits(kocr_sload(p.amax_in + n1), W4H_TOP);
+      g.s = kocr_pow2((int)nimg == n0 ? g.e0 : g.e1);
+      const int rel = (int)(row - row_a) * p.W + x0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const bool pad = (k == 0 && x0 < dd) || (k == 5 && x0 + 4 * dd >= p.W);  // column zero padding
+        g.goff[k] = pad ? OOB : (unsigned)(((rel + k * dd) * p.in_cs + q4 * 4) * 4);
+      }
+      return;
+    }
+    const long pm_a = (long)mp * 256;
+    g.base = p.in + (pm_a * p.in_cs + p.in_co) - (long)(p.W + 1) * p.in_cs;
     const int rel = 4 * qi;
     const long gp = pm_a + rel;
     g.gok = L < total && gp < p.Mtotal;
@@ -1207,9 +1241,9 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
   bool ld_next = false;      // ... and whether that tile is already the next one
   const int ncg = p.Cin >> 4;
   auto load_raw = [&](v4f (&raw)[6]) __attribute__((always_inline)) {
-    const int soff = (ld_ky * p.W * p.in_cs + ld_cg * 16) * 4;
+    const int soff = (ld_ky * dd * p.W * p.in_cs + ld_cg * 16) * 4;
     const int gy = ld_next ? gn.gy : gc.gy;
-    const bool ok = (ld_next ? gn.gok : gc.gok) & ((unsigned)(gy + (ld_ky - 1)) < (unsigned)p.H);
+    const bool ok = (ld_next ? gn.gok : gc.gok) & ((unsigned)(gy + dd * (ld_ky - 1)) < (unsigned)p.H);
     const unsigned kill = ok ? 0u : OOB;
     const __amdgpu_buffer_rsrc_t rsrc = w4_rsrc(ld_next ? gn.base : gc.base, 0x80000000u);
 #pragma unroll
@@ -1405,7 +1439,7 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][m][r] = acc[j][m][r] * qa + qb_;
       }
-      if (p.Wv) {  // width-padded output (Tensor::Wv): the columns behind the valid width are zero padding
+      if (!DIL && p.Wv) {  // width-padded output (Tensor::Wv): the columns behind the valid width are zero padding
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1434,6 +1468,28 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
       PROBE_T(2);
       int ocs4 = p.out_cs * 4;
       asm volatile("" : "+s"(ocs4));
+      if constexpr (DIL) {
+        // quad (m, r, l5) of the tile -> (row, comb position), relative to the first pixel of the tile's first row; the quad's
+        // four outputs are p.dil pixels apart
+        const unsigned q0 = (unsigned)mp * 64u;
+        const unsigned row_a = w4_fdiv(q0, p.dv_qpr);
+        const __amdgpu_buffer_rsrc_t ro = w4_rsrc(p.out + ((long)row_a * p.W * p.out_cs + p.out_co), 0x7FFFFFFFu);
+        const int dstep = dd * ocs4;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int q = m * 32 + (r & 3) + 8 * (r >> 2) + l5q;
+            const unsigned qg = q0 + (unsigned)q;
+            const unsigned row = w4_fdiv(qg, p.dv_qpr);
+            const int qr = (int)(qg - row * (unsigned)p.qpr);
+            const int qd = (int)w4_fdiv((unsigned)qr, p.dv_dil);
+            const int x0 = qd * 4 * dd + (qr - qd * dd);
+            const unsigned vo = (live && q < qlim) ? (unsigned)((((int)(row - row_a) * p.W + x0) * p.out_cs + n) * 4) : OOB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vo, j * dstep, 0);
+          }
+      } else {
       // bytes from the tile's first pixel to the end of the tensor: stores past it are dropped
       const long rem = ((long)p.Mtotal - pm0) * ocs4;
       const __amdgpu_buffer_rsrc_t ro =
@@ -1448,6 +1504,7 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
           for (int j = 0; j < 4; ++j)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[j][m][r]), ro, vo, (px + j) * ocs4, 0);
         }
+      }
       PROBE_T(3);
     }
     // (behind the stores: see conv_w43vh_kernel)
@@ -1466,7 +1523,7 @@ __global__ __launch_bounds__(256) void conv_w43fh_kernel(W4Params p) {
 // scaled per output channel by 2^wexp[o] (max |U 2^wexp| over the channel's 18 Cin values in [2^14, 2^15)), rounded once to
 // fp32, split into two fp16 pieces by round-to-nearest, packed in conv_w43's B-operand order with two pieces per point.
 int prepare_w43h(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, const float* pre_a) {
-  if (!L.d_w4 || L.dil != 1) return KOCR_OK;
+  if (!L.d_w4 || (L.dil != 1 && L.w4_cout_pad == 64)) return KOCR_OK;  // dilated: the flattened 128-cout arrangement only
   const int Cin = L.Cin, Cout = L.Cout;
   const int cp = L.w4_cout_pad;
   const int nt32 = cp / 32;
@@ -1638,13 +1695,13 @@ int launch_w43rh(kocr_ctx* ctx, W4Params& p, bool fuse, int pieces, int mode) {
   return fuse ? w4rh_launch<1, 1>(ctx, p) : w4rh_launch<0, 1>(ctx, p);
 }
 
-template <int NP>
+template <int NP, int DIL = 0>
 static int w4fh_launch(kocr_ctx* ctx, W4Params& p) {
   const int LDSF = 2 * 6 * NP * 2 * 2 * 256 * 2 + 4 * p.Cout_pad * 4;  // 2 x 24 KB (NP = 2) + the epilogue's coefficients
   static std::atomic<bool> attr_done[64];
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
-    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43fh_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43fh_kernel<NP, DIL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       2 * 6 * NP * 2 * 2 * 256 * 2 + W4_COEF_BYTES_MAX));
     attr_done[dev] = true;
   }
@@ -1657,7 +1714,7 @@ static int w4fh_launch(kocr_ctx* ctx, W4Params& p) {
   const int n_cu = n_cus[dev];
   const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
   PROBE_RESET(ctx);
-  hipLaunchKernelGGL((conv_w43fh_kernel<NP>), dim3(grid), dim3(256), LDSF, ctx->stream, p);
+  hipLaunchKernelGGL((conv_w43fh_kernel<NP, DIL>), dim3(grid), dim3(256), LDSF, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   {
     char what[64];
@@ -1670,4 +1727,8 @@ static int w4fh_launch(kocr_ctx* ctx, W4Params& p) {
 
 // the flattened-pixel arrangement (no fused pooling, dilation 1, H W >= 256) in fp16 arithmetic: p as launch_conv_w43
 // filled it for conv_w43_kernel<0>, with wgt = d_w4h, pre_a = d_pre_a_h, amax_in set and amax_out = out.amax (per image)
-int launch_w43fh(kocr_ctx* ctx, W4Params& p, int pieces) { return pieces == 2 ? w4fh_launch<2>(ctx, p) : w4fh_launch<1>(ctx, p); }
+// ... p.dil != 1: the dilated comb tiles (two pieces only: the one-piece fast mode runs dilated layers in fp16x2)
+int launch_w43fh(kocr_ctx* ctx, W4Params& p, int pieces) {
+  if (p.dil != 1) return w4fh_launch<2, 1>(ctx, p);
+  return pieces == 2 ? w4fh_launch<2>(ctx, p) : w4fh_launch<1>(ctx, p);
+}

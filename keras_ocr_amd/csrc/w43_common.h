@@ -43,6 +43,7 @@ struct W4Params {
   // conv_w43vh / conv_w43rh MODE 1 (ragged images) and MODE 2 (cell grids): the tile grid of an image
   int rq_per_img;      // row blocks per image: ceil(H / 4) (4 x 64 tiles) or ceil(H / 8) (8 x 32 tiles)
   unsigned dv_rq[2];   // by rq_per_img
+  unsigned dv_qpr[2], dv_dil[2], dv_h[2];  // conv_w43fh_kernel<.., DIL>: by qpr (quads per row), by dil, by H
   int cellW, cellWv, cells_per_row;  // MODE 2 (Tensor::cellW / cellWv): cell pitch, valid columns of a cell, W / cellW
   unsigned dv_wc[2];   // by cellW
 };

@@ -33,7 +33,8 @@ PROF_TO_KERNEL = {
     "conv_w4ht_256x128_cells": "void conv_w43vh_kernel<0, 2, 2, 0, 2>",
     "conv_w4qv_256x128": "void conv_w43vh_kernel<0, 1, 1, 0, 0>", "conv_w4qv_256x128_pool": "void conv_w43vh_kernel<1, 1, 1, 0, 0>",
     "conv_w4qt_256x128": "void conv_w43vh_kernel<0, 2, 1, 0, 0>",
-    "conv_w4hf_256x128": "void conv_w43fh_kernel<2", "conv_w4qf_256x128": "void conv_w43fh_kernel<1",
+    "conv_w4hf_256x128": "void conv_w43fh_kernel<2, 0>", "conv_w4qf_256x128": "void conv_w43fh_kernel<1, 0>",
+    "conv_w4hf_256x128_dil": "void conv_w43fh_kernel<2, 1>",
     "conv_w4hr_256x64": "void conv_w43rh_kernel<0, 2, 0>", "conv_w4hr_256x64_pool": "void conv_w43rh_kernel<1, 2, 0>",
     "conv_w4hr_256x64_rag": "void conv_w43rh_kernel<0, 2, 1>", "conv_w4hr_256x64_pool_rag": "void conv_w43rh_kernel<1, 2, 1>",
     "conv_w4qr_256x64": "void conv_w43rh_kernel<0, 1, 0>", "conv_w4qr_256x64_pool": "void conv_w43rh_kernel<1, 1, 0>",

@@ -232,14 +232,15 @@ def test_k5_kernel_is_fp32_class_against_fp64(ctx, case):
 # conv_dsplit.hip: the same bf16x3 arithmetic for 1x1 / dilated / larger kernels (>= 4096 pixels)
 DSPLIT_CASES = [
     # N, H, W, Cin, Cout, k, dil, family
-    (1, 96, 96, 512, 256, 3, 6, "conv_w4s_256x128_dil"),   # slice5.1 class: dilated, W % (4 dil) == 0 -> F(4,3) on the comb of pixels
+    (1, 96, 96, 512, 256, 3, 6, "conv_w4hf_256x128_dil"),   # slice5.1 class: dilated, W % (4 dil) == 0 -> F(4,3) on the comb of pixels
     (2, 64, 72, 1024, 128, 1, 1, "conv_ds_256x128"),       # slice5.2 class
     (1, 192, 192, 192, 64, 1, 1, "conv_ds_512x64"),        # upconv4.conv.0 class: 512x64 tiles
     (1, 70, 61, 48, 100, 1, 1, "conv_ds_256x128"),         # ragged pixels / couts, 3 K-steps
     (1, 65, 67, 32, 40, 5, 1, "conv_ds_512x64"),           # 5x5, tiles crossing rows, odd sizes
     (2, 50, 90, 64, 70, 3, 2, "conv_ds_256x128"),          # dilation 2, W % 8 != 0: direct split kernel, two images
-    (2, 48, 48, 64, 128, 3, 6, "conv_w4s_256x128_dil"),    # slice5.1 geometry at 768x768 input
-    (1, 33, 40, 32, 96, 3, 2, "conv_w4s_256x128_dil"),     # dilation 2, odd height, ragged couts, tile ends inside a row
+    (2, 48, 48, 64, 128, 3, 6, "conv_w4hf_256x128_dil"),    # slice5.1 geometry at 768x768 input
+    (1, 33, 40, 32, 96, 3, 2, "conv_w4hf_256x128_dil"),     # dilation 2, odd height, ragged couts, tile ends inside a row
+    (3, 24, 48, 64, 130, 3, 6, "conv_w4hf_256x128_dil"),    # three images of 288 quads: tiles crossing images (two scales per tile), ragged couts
 ]
 
 

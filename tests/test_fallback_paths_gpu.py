@@ -14,6 +14,7 @@ once per process): the fp64-bounded convolution tests and the CRAFT heat-map-vs-
   KOCR_CELLS=0   no cell grid               -> the recogniser's conv stack on round 4's dense crop batch (flattened fp16 tiles,
                                                conv_6 / conv_7 through the 52-wide layout, separate pooling kernels)
   KOCR_W43RAG=0  no ragged tile grids       -> images that do not tile exactly on the flattened / F(2,3) / fp32 kernels
+  KOCR_W43DILH=0 no fp16 dilated F(4,3)     -> the dilated composite slice5 on the bf16x3 comb tiles of round 2
 
 Since round 5 every configuration also runs the recogniser against the oracle (under KOCR_W43=0 the 52-wide
 layout used to reach a kernel that does not write its padding columns; launch_conv now refuses that, and crnn.cpp asks the
@@ -45,6 +46,7 @@ CONFIGS = [
     {"KOCR_CELLS": "0"},
     {"KOCR_W43RAG": "0"},
     {"KOCR_CELLS": "0", "KOCR_W43": "0"},
+    {"KOCR_W43DILH": "0"},
 ]
 
 

@@ -107,21 +107,33 @@ class _DeviceArray:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-def _pack_on_device(dev_res, cap, dev):
-    """The (cap, 8) box tensor and the (cap, 48) label tensor of gather_packed built IN HBM from what kocr_pipeline left
-    there (boxes [n][cap_local][4][2], counts [n], label rows [m][48]): the payload RCCL moves never visits the host."""
+def _pack_tensors(counts, boxes, labels, cap, dev):
+    """(cap, 8) box tensor and (cap, 48) label tensor from the per-image form kocr_pipeline produces -- counts [n], boxes
+    [n][cap_local][8] (rows >= counts[i] of image i undefined), label rows [m][48] -- on whatever device the inputs live:
+    a boolean-mask gather by the counts, image-major, which is the order of the label rows."""
     import torch
 
-    n, cl, m = dev_res["n"], dev_res["cap"], dev_res["m"]
+    n, cl = boxes.shape[0], boxes.shape[1]
+    m = int(labels.shape[0]) if labels is not None else 0
     b = torch.zeros((cap, 8), dtype=torch.float32, device=dev)
     l = torch.full((cap, LABEL_WIDTH), -1, dtype=torch.int32, device=dev)
     if m:
-        counts = torch.as_tensor(_DeviceArray(dev_res["counts"], (n,), "<i4"), device=dev)
-        boxes = torch.as_tensor(_DeviceArray(dev_res["boxes"], (n, cl, 8), "<f4"), device=dev)
         mask = torch.arange(cl, device=dev)[None, :] < counts[:, None]
-        b[:m] = boxes[mask]                      # image-major, box order: the order of the label rows
-        l[:m] = torch.as_tensor(_DeviceArray(dev_res["labels"], (m, LABEL_WIDTH), "<i4"), device=dev)
+        b[:m] = boxes.reshape(n, cl, 8)[mask]
+        l[:m] = labels
     return b, l
+
+
+def _pack_on_device(dev_res, cap, dev):
+    """The packed tensors of gather_packed built IN HBM from what kocr_pipeline left there: the payload RCCL moves never
+    visits the host."""
+    import torch
+
+    n, cl, m = dev_res["n"], dev_res["cap"], dev_res["m"]
+    counts = torch.as_tensor(_DeviceArray(dev_res["counts"], (n,), "<i4"), device=dev)
+    boxes = torch.as_tensor(_DeviceArray(dev_res["boxes"], (n, cl, 8), "<f4"), device=dev)
+    labels = torch.as_tensor(_DeviceArray(dev_res["labels"], (m, LABEL_WIDTH), "<i4"), device=dev) if m else None
+    return _pack_tensors(counts, boxes, labels, cap, dev)
 
 
 def gather_packed(box_groups, labels, per_rank_images, group=None, error=None, timing=None, device_results=None,

@@ -353,3 +353,24 @@ def test_scatter_source_failure_raises_on_every_rank_gloo_world2():
         assert "rank(s) [0]" in errs[r][0] and "ValueError" in errs[r][0], errs
     assert errs[0][1] == "ValueError" and errs[1][1] is None
     assert sorted((r, n) for r, m, n in res if m == "after") == [(0, 4), (1, 4)]
+
+
+def test_device_side_packing_equals_host_packing():
+    """dist._pack_tensors (what the RCCL path runs on HBM tensors, round 5) on host tensors: from the per-image form
+    kocr_pipeline leaves behind -- counts, boxes [n][cap][8] with undefined rows behind each image's count, label rows -- to
+    the packed (cap, 8) / (cap, 48) payload of gather_packed, identical to the host path's concatenation."""
+    import torch
+    from keras_ocr_amd import dist as kd
+
+    rng = np.random.default_rng(3)
+    counts = np.array([3, 0, 5, 1], np.int32)
+    cap_local, m = 6, int(counts.sum())
+    boxes = rng.random((4, cap_local, 8)).astype(np.float32)          # rows >= counts[i]: garbage that must not travel
+    labels = rng.integers(-1, 36, (m, 48)).astype(np.int32)
+    b, l = kd._pack_tensors(torch.from_numpy(counts), torch.from_numpy(boxes), torch.from_numpy(labels), 12, torch.device("cpu"))
+    want = np.concatenate([boxes[i, :c] for i, c in enumerate(counts) if c])
+    assert b.shape == (12, 8) and l.shape == (12, 48)
+    assert np.array_equal(b[:m].numpy(), want) and not b[m:].any()
+    assert np.array_equal(l[:m].numpy(), labels) and (l[m:].numpy() == -1).all()
+    b0, l0 = kd._pack_tensors(torch.zeros(2, dtype=torch.int32), torch.zeros((2, 4, 8)), None, 1, torch.device("cpu"))
+    assert not b0.any() and (l0.numpy() == -1).all()                   # a rank without boxes

@@ -48,12 +48,17 @@ struct DsParams {
 // probe_clock.h bins: consumer wave 0: [0] K loop  [1] up-sampled addend  [2] post + amax  [3] store issue;  producer wave 4:
 // [4] LDS fill (with the wait for its raw loads)  [5] barrier  [6] load issue
 
+// (WM, WN) = (1, 4) / (2, 2): 512 threads, one block per CU.  (1, 2) (round 6): 256 threads -- two consumer and two producer
+// waves, tile 256 pixels x 64 couts, 64 KB of LDS -- so that TWO blocks share a CU and one block's epilogue (the up-sampled
+// addend and the stores: 47 % of a tile of upconv4.conv.0, profiles/r06_ab_notes.txt) overlaps the other's K loop.
 template <int WM, int WN, int HALF, int UP>
-__global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
+__global__ __launch_bounds__(128 * WM * WN, WM * WN == 2 ? 2 : 1) void conv_ds_kernel(DsParams p) {
   constexpr int NP = HALF ? 2 : 3;            // operand pieces
+  constexpr int NCW = WM * WN;                // consumer waves = producer waves
   constexpr int NMT = 8 * WM;                 // 32-pixel M-tiles per block tile
   constexpr int TILE_PX = 256 * WM;
-  constexpr int IPT = 4 * WM;                 // gather items (pixel, channel quad) per producer thread
+  constexpr int PXI = 16 * NCW;               // pixels one gather item of all producer threads covers
+  constexpr int IPT = TILE_PX / PXI;          // gather items (pixel, channel quad) per producer thread
   constexpr int KH_STRIDE = 256;              // ushorts: 32 rows x 8 channels
   constexpr int PLANE = NMT * 2 * KH_STRIDE;  // one piece plane
   constexpr int BUF = NP * PLANE;             // one K-step: 24 KB * WM (bf16x3) / 16 KB * WM (fp16x2)
@@ -70,8 +75,8 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
   // ==================================================================================================
   // producer waves 4..7
   // ==================================================================================================
-  if (wave >= 4) {
-    const int ptid = tid - 256;
+  if (wave >= NCW) {
+    const int ptid = tid - 64 * NCW;
     const int quad = ptid & 3;
     constexpr unsigned OOB = 0x80000000u;
     const float in_scale = HALF ? kocr_pow2(kocr_scale_exp(p.amax_in, 13)) : 1.f;  // exact power of two
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
     int ldst[IPT];
 #pragma unroll
     for (int it = 0; it < IPT; ++it) {
-      const int idx = (ptid >> 2) + it * 64;
+      const int idx = (ptid >> 2) + it * PXI;
       ldst[it] = ((idx >> 5) * 2 + (quad >> 1)) * KH_STRIDE + ((((idx & 31) * 8) ^ ((quad >> 1) * 32)) + (quad & 1) * 4);
     }
     // position of the NEXT K-step to load: tile L_ld, step (ld_cg, ld_tap = (ld_ky, ld_kx))
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
       rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)bbu, 0, 0x80000000, 0x00020000);
 #pragma unroll
       for (int it = 0; it < IPT; ++it) {
-        const int idx = (ptid >> 2) + it * 64;
+        const int idx = (ptid >> 2) + it * PXI;
         const long g = pm0 + idx;
         gok[it] = g < p.Mtotal && L_ld < total;
         gx[it] = (int)(g % p.W);
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
         PROBE_T(5);
       }
     }
-    PROBE_TEND((tid & 255) == 0, 4, 7);
+    PROBE_TEND(tid == 64 * NCW, 4, 7);
 #pragma unroll
     for (int d = 0; d < D - 1; ++d)
       if (k + d < T) {
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(512) void conv_ds_kernel(DsParams p) {
     }
     if constexpr (UP != 0) load_a(a0, As + (gs & 1) * BUF, 0);  // the next tile's first fragments (see compute_step)
   }
-  PROBE_TEND((tid & 255) == 0, 0, 4);
+  PROBE_TEND(tid == 0, 0, 4);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -557,7 +562,8 @@ bool dsplit_applicable(const ConvLayer& L, const Tensor& in) { return dsplit_usa
 template <int WM, int WN, int HALF, int UP = 0>
 static int ds_launch(kocr_ctx* ctx, DsParams& p, size_t M) {
   // 48 / 96 KB (bf16x3), 32 / 64 KB (fp16x2); UP: + one 8 KB tap table per consumer wave
-  constexpr int LDS_BYTES = 2 * (HALF ? 2 : 3) * (8 * WM) * 2 * 256 * 2 + (UP ? 4 * 256 * 32 : 0);
+  constexpr int NCW = WM * WN;
+  constexpr int LDS_BYTES = 2 * (HALF ? 2 : 3) * (8 * WM) * 2 * 256 * 2 + (UP ? NCW * 256 * 32 : 0);
   static std::atomic<bool> attr_done[64];  // per device (one process may hold contexts on several GPUs); a race only repeats the call
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
@@ -573,9 +579,10 @@ static int ds_launch(kocr_ctx* ctx, DsParams& p, size_t M) {
   const int n_cu = n_cus[dev];
   const size_t mtiles = (M + 256 * WM - 1) / (256 * WM);
   p.total_tiles = (int)(mtiles * (p.Cout_pad / (32 * WN)));
-  const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
+  const int slots = n_cu * (NCW == 2 ? 2 : 1);  // (1, 2): two blocks per CU
+  const int grid = p.total_tiles < slots ? p.total_tiles : slots;
   PROBE_RESET(ctx);
-  hipLaunchKernelGGL((conv_ds_kernel<WM, WN, HALF, UP>), dim3(grid), dim3(512), LDS_BYTES, ctx->stream, p);
+  hipLaunchKernelGGL((conv_ds_kernel<WM, WN, HALF, UP>), dim3(grid), dim3(128 * NCW), LDS_BYTES, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   {
     char what[64];
@@ -648,8 +655,13 @@ int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   if (up) {
     // exactly 2x up-sampling with W % 4 == 0: the shared-tap epilogue (UP = 2)
     const bool no_up2 = !ctx->sw.up2x;
-    if (!no_up2 && in.H == 2 * up->H && in.W == 2 * up->W && in.W % 4 == 0)
+    // KOCR_DS_PAIR: 0 = one 512-thread block per CU everywhere (round 5), 1 = the 64-cout layers on two 256-thread blocks per
+    // CU, 2 (default) = every up-sampling 1x1 (A/B: profiles/r06_ab_notes.txt)
+    static const int pair = getenv("KOCR_DS_PAIR") ? atoi(getenv("KOCR_DS_PAIR")) : 2;
+    if (!no_up2 && in.H == 2 * up->H && in.W == 2 * up->W && in.W % 4 == 0) {
+      if (pair >= (wcls == 128 ? 2 : 1)) return ds_launch<1, 2, 0, 2>(ctx, p, M);
       return wcls == 128 ? ds_launch<1, 4, 0, 2>(ctx, p, M) : ds_launch<2, 2, 0, 2>(ctx, p, M);
+    }
     return wcls == 128 ? ds_launch<1, 4, 0, 1>(ctx, p, M) : ds_launch<2, 2, 0, 1>(ctx, p, M);
   }
   return wcls == 128 ? ds_launch<1, 4, 0>(ctx, p, M) : ds_launch<2, 2, 0>(ctx, p, M);

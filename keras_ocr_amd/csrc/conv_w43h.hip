@@ -712,9 +712,11 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
 // CRAFT's slice1.3 (64 -> 64 at full resolution) and upconv3.conv.3.
 // ===================================================================================================
 // MODE 1 (round 5) = RAGGED, any H, W: see conv_w43vh_kernel (column bits in Geo::ok, masked stores).
-template <int POOL, int NP, int MODE = 0>
+template <int POOL, int NP, int MODE = 0, int PF = 1>
 __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
   static_assert(MODE == 0 || MODE == 1, "exact tiling or ragged");
+  static_assert(PF == 1 || PF == 2, "prefetch depth in channel groups");
+  constexpr int NBW = PF == 2 ? 9 : 3;  // weight fragments held: one (ky, point) row of three, or a whole channel group
   constexpr int PR = NP == 2 ? 3 : 1;
   constexpr int NROWS = 6, QPR = 16, KHS = QPR * 8, ROW_STRIDE = 2 * KHS, PLANE_R = NROWS * ROW_STRIDE;
   constexpr int BUF_R = 6 * NP * PLANE_R;  // one channel group: 36 KB (NP = 2)
@@ -852,14 +854,14 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
       *reinterpret_cast<unsigned*>(dst) = __builtin_bit_cast(unsigned, hf2{(_Float16)V[0], (_Float16)V[1]});
     }
   };
-  v4f raw0[6];
-  v2f raw1[6];
+  v4f raw0[PF][6];
+  v2f raw1[PF][6];
 
   // ---- consumer state ------------------------------------------------------------------------------------------
   const size_t w_step = (size_t)2 * 12 * 64 * 8;  // ushorts per (channel group, ky) step: two 32-cout tiles, 2 pieces
   const unsigned short* w_ptr = p.wgt + ((size_t)wn * 12 * 64 + lane) * 8;
   const int ns = 3 * ncg;
-  hf8 bw[3][NP];
+  hf8 bw[NBW][NP];
   f16v acc[3][2];  // [point of this wave's half][M-tile]
   const int a_lane = (l31 >> 4) * ROW_STRIDE + l5 * KHS + (((l31 & 15) * 8) ^ (l5 * 32));
   constexpr int M_OFF = 2 * ROW_STRIDE;  // M-tile 1: two rows down
@@ -870,21 +872,28 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) a[m][s] = *reinterpret_cast<const hf8*>(base + s * PLANE_R + m * M_OFF);
   };
-  auto mfma_grp = [&](const hf8 (&a)[2][NP], int pl) __attribute__((always_inline)) {
+  auto mfma_grp = [&](const hf8 (&a)[2][NP], int pl, int bi) __attribute__((always_inline)) {
     if constexpr (NP == 2) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][1], bw[pl][0], acc[pl][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m) acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][1], bw[bi][0], acc[pl][m], 0, 0, 0);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], bw[pl][1], acc[pl][m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m) acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], bw[bi][1], acc[pl][m], 0, 0, 0);
     }
 #pragma unroll
-    for (int m = 0; m < 2; ++m) acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], bw[pl][0], acc[pl][m], 0, 0, 0);
+    for (int m = 0; m < 2; ++m) acc[pl][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m][0], bw[bi][0], acc[pl][m], 0, 0, 0);
   };
   // One channel group: nine groups (ky, point of the wave's half) of 2 PR MFMAs; the NEXT channel group is transformed
   // meanwhile (12 chunks: six points of item 0, six of the half item, spread 2,1,1 per three groups) with the scale `sk`
   // of the image it belongs to.  See conv_w43r_kernel for the a0 / a1 flip and the weight replacement.
   hf8 a0[2][NP], a1[2][NP];
   auto phase = [&](const unsigned short* bufc, unsigned short* bufn, int s0, int flip, float sk) __attribute__((always_inline)) {
+    // PF = 2: the raw pixels of TWO channel groups are in flight (register set `flip` is transformed now and refilled
+    // with the channel group after next but one), and a group's weight fragments are replaced by the NEXT channel
+    // group's right after their use -- every load is consumed at least nine MFMA groups after its issue.  vmcnt
+    // retires in order: with the weights only three groups ahead (PF = 1) a raw load had to be back within four
+    // groups of its issue, i.e. the loop ran at two exposed HBM latencies per channel group (profiles/r06_ab_notes.txt).
+    v4f(&r0)[6] = (PF == 2 && flip) ? raw0[PF - 1] : raw0[0];
+    v2f(&r1)[6] = (PF == 2 && flip) ? raw1[PF - 1] : raw1[0];
 #pragma unroll
     for (int g = 0; g < 9; ++g) {
       __builtin_amdgcn_sched_barrier(0);
@@ -897,12 +906,12 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
 #pragma unroll
       for (int c = c0; c < c0 + nchunks; ++c) {
         if (c < 6)
-          produce4(raw0, bufn, c, sk);
+          produce4(r0, bufn, c, sk);
         else
-          produce2(raw1, bufn, c - 6, sk);
+          produce2(r1, bufn, c - 6, sk);
       }
       if (g < 8) {
-        mfma_grp(cur, pp);
+        mfma_grp(cur, pp, PF == 2 ? g : pp);
         __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);  // the LDS fetches of the next group first
         // VALU per MFMA gap: a full chunk is ~22 VALU, a half chunk ~10; the group's LDS stores before its last MFMA
         auto ilv = [&](auto v_c, auto st_c) __attribute__((always_inline)) {
@@ -931,19 +940,20 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
         __syncthreads();  // the next channel group is complete in bufn, bufc is free
         load_a(nxt, bufn, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_grp(cur, pp);
+        mfma_grp(cur, pp, PF == 2 ? g : pp);
       }
       __builtin_amdgcn_sched_barrier(0);
-      {  // this point's weights of the next step
-        int sn = s0 + ky + 1;
+      {  // this point's weights of the next step (PF = 2: of the same step of the next channel group)
+        int sn = PF == 2 ? s0 + 3 + ky : s0 + ky + 1;
         sn = sn >= ns ? sn - ns : sn;
         const unsigned short* wq = w_ptr + (size_t)sn * w_step;
 #pragma unroll
-        for (int s = 0; s < NP; ++s) bw[pp][s] = *reinterpret_cast<const hf8*>(wq + (size_t)((3 * ph + pp) * 2 + s) * 64 * 8);
+        for (int s = 0; s < NP; ++s)
+          bw[PF == 2 ? g : pp][s] = *reinterpret_cast<const hf8*>(wq + (size_t)((3 * ph + pp) * 2 + s) * 64 * 8);
       }
-      if (g == 3) load_item0(raw0);
+      if (g == 3) load_item0(r0);
     }
-    load_item1(raw1);
+    load_item1(r1);
     advance();
   };
 
@@ -951,21 +961,27 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
   w4_stage_coef(p, coef, tid);
   make_geo(blockIdx.x, gc, lc, rc);
   make_geo(blockIdx.x + G, gn, ln, rn);
-  load_item0(raw0);
-  load_item1(raw1);
+  load_item0(raw0[0]);
+  load_item1(raw1[0]);
   advance();  // channel group 0 loaded
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl)
+  for (int g = 0; g < NBW; ++g)
 #pragma unroll
-    for (int s = 0; s < NP; ++s) bw[pl][s] = *reinterpret_cast<const hf8*>(w_ptr + (size_t)((3 * ph + pl) * 2 + s) * 64 * 8);
+    for (int s = 0; s < NP; ++s)
+      bw[g][s] = *reinterpret_cast<const hf8*>(w_ptr + (size_t)(g / 3) * w_step + (size_t)((3 * ph + g % 3) * 2 + s) * 64 * 8);
 #pragma unroll
   for (int xi = 0; xi < 6; ++xi) {
-    produce4(raw0, As, xi, kocr_pow2(gc.e));
-    produce2(raw1, As, xi, kocr_pow2(gc.e));
+    produce4(raw0[0], As, xi, kocr_pow2(gc.e));
+    produce2(raw1[0], As, xi, kocr_pow2(gc.e));
   }
-  load_item0(raw0);
-  load_item1(raw1);
+  load_item0(raw0[0]);
+  load_item1(raw1[0]);
   advance();  // channel group 1 loaded
+  if constexpr (PF == 2) {
+    load_item0(raw0[1]);
+    load_item1(raw1[1]);
+    advance();  // channel group 2 (of the next tile when Cin = 32: the launcher takes PF = 2 from Cin >= 64 on)
+  }
   __syncthreads();
   load_a(a0, As, 0, 0);
 
@@ -1657,14 +1673,14 @@ int launch_w43vh(kocr_ctx* ctx, W4Params& p, bool fuse, int geo, int pieces, int
   return fuse ? w4vh_launch<1, 1, 1>(ctx, p) : w4vh_launch<0, 1, 1>(ctx, p);
 }
 
-template <int POOL, int NP, int MODE = 0>
+template <int POOL, int NP, int MODE = 0, int PF = 1>
 static int w4rh_launch(kocr_ctx* ctx, W4Params& p) {
   constexpr int LDSR0 = 6 * NP * 6 * 256 * 2 + 4 * 16 * 64 * 16;  // one 36 KB buffer + the epilogue's 64 KB exchange area
   const int LDSR = LDSR0 + 4 * p.Cout_pad * 4;                    // + the epilogue's coefficients
   static std::atomic<bool> attr_done[64];
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
-    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43rh_kernel<POOL, NP, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSR0 + W4_COEF_BYTES_MAX));
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43rh_kernel<POOL, NP, MODE, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSR0 + W4_COEF_BYTES_MAX));
     attr_done[dev] = true;
   }
   static std::atomic<int> n_cus[64];
@@ -1676,11 +1692,11 @@ static int w4rh_launch(kocr_ctx* ctx, W4Params& p) {
   const int n_cu = n_cus[dev];
   const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
   PROBE_RESET(ctx);
-  hipLaunchKernelGGL((conv_w43rh_kernel<POOL, NP, MODE>), dim3(grid), dim3(256), LDSR, ctx->stream, p);
+  hipLaunchKernelGGL((conv_w43rh_kernel<POOL, NP, MODE, PF>), dim3(grid), dim3(256), LDSR, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   {
     char what[80];
-    snprintf(what, sizeof what, "conv_w43rh<%d,%d> tiles %d steps %d", POOL, NP, p.total_tiles, p.nsteps);
+    snprintf(what, sizeof what, "conv_w43rh<%d,%d,%d,pf%d> tiles %d steps %d", POOL, NP, MODE, PF, p.total_tiles, p.nsteps);
     (void)what;
     PROBE_REPORT(ctx, what, grid);
   }
@@ -1690,6 +1706,13 @@ static int w4rh_launch(kocr_ctx* ctx, W4Params& p) {
 // the 64-cout row-reuse arrangement (4 x 64 tiles) in fp16 arithmetic: p as launch_conv_w43 filled it for
 // conv_w43r_kernel<POOL, 1>, with wgt = d_w4h, pre_a = d_pre_a_h and amax_in set
 int launch_w43rh(kocr_ctx* ctx, W4Params& p, bool fuse, int pieces, int mode) {
+  // PF = 2 (two channel groups of raw pixels in flight, weights a whole channel group ahead) needs the loads of a tile to
+  // reach into the NEXT tile only: Cin >= 64.  KOCR_W43R_PF=1: round 5's one-group prefetch (A/B, profiles/r06_ab_notes.txt)
+  static const bool pf2 = !(getenv("KOCR_W43R_PF") && atoi(getenv("KOCR_W43R_PF")) == 1);
+  if (pieces == 2 && pf2 && p.Cin >= 64) {
+    if (mode == 1) return fuse ? w4rh_launch<1, 2, 1, 2>(ctx, p) : w4rh_launch<0, 2, 1, 2>(ctx, p);
+    return fuse ? w4rh_launch<1, 2, 0, 2>(ctx, p) : w4rh_launch<0, 2, 0, 2>(ctx, p);
+  }
   if (mode == 1) return fuse ? w4rh_launch<1, 2, 1>(ctx, p) : w4rh_launch<0, 2, 1>(ctx, p);
   if (pieces == 2) return fuse ? w4rh_launch<1, 2>(ctx, p) : w4rh_launch<0, 2>(ctx, p);
   return fuse ? w4rh_launch<1, 1>(ctx, p) : w4rh_launch<0, 1>(ctx, p);

@@ -143,6 +143,12 @@ int kocr_crnn_forward(kocr_ctx* ctx, const float* crops, int M, int32_t* labels,
                       int on_device);
 /* len(alphabet) + 1 of the loaded recogniser (recognition.py:323), 0 if none is loaded. */
 int kocr_crnn_classes(kocr_ctx* ctx);
+/* Non-default recogniser builds (recognition.py:187-198 build_params; round 6).  `stn=False` (recognition.py:243) needs no call:
+ * kocr_load_crnn on a weight set WITHOUT the stn_* tensors builds the model without the spatial transformer.
+ * `rnn_steps_to_discard` (recognition.py:328; default 2): every "48" in this header -- the label rows of kocr_crnn_forward,
+ * kocr_recognize_boxes, kocr_pipeline and the probability rows -- is kocr_crnn_label_width() = 50 - steps columns. */
+int kocr_crnn_set_rnn_steps_to_discard(kocr_ctx* ctx, int steps);
+int kocr_crnn_label_width(kocr_ctx* ctx);
 
 /* ---- Detector.detect (detection.py:745-785): compute_input + predict + getBoxes in one call; the
  * heat-maps stay in HBM.  Arguments as kocr_craft_forward + kocr_get_boxes; counts is a HOST array. */

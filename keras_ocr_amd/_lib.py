@@ -61,6 +61,8 @@ def load_library():
         "kocr_craft_forward": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, ci]),
         "kocr_crnn_forward": (ci, [vp, vp, ci, vp, vp, ci]),
         "kocr_crnn_classes": (ci, [vp]),
+        "kocr_crnn_label_width": (ci, [vp]),
+        "kocr_crnn_set_rnn_steps_to_discard": (ci, [vp, ci]),
         "kocr_get_boxes": (ci, [vp, vp, ci, ci, ci, ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, vp, vp, ci, ci]),
         "kocr_warp_crops": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, ci, vp, ci]),
         "kocr_warp_quads": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, vp]),
@@ -188,9 +190,17 @@ class Context:
     def crnn_classes(self):
         return self._check(self._lib.kocr_crnn_classes(self._h))
 
+    def crnn_label_width(self):
+        """columns of a label row: 50 time-steps minus rnn_steps_to_discard (48 for the default build)"""
+        return self._check(self._lib.kocr_crnn_label_width(self._h))
+
+    def crnn_set_rnn_steps_to_discard(self, steps):
+        """build_params["rnn_steps_to_discard"] (recognition.py:328) of the recogniser on this context"""
+        self._check(self._lib.kocr_crnn_set_rnn_steps_to_discard(self._h, int(steps)))
+
     def crnn_forward(self, crops, return_probs=False):
         """crops: (M,31,200[,1]) float32 in [0,1].  Returns labels (M,48) int32 (-1 padded)
-        [, probs (M,48,n_classes)]."""
+        [, probs (M,48,n_classes)] (48 = crnn_label_width())."""
         x = np.ascontiguousarray(crops, dtype=np.float32)
         if x.ndim == 4 and x.shape[-1] == 1:
             x = x[..., 0]
@@ -198,8 +208,9 @@ class Context:
             raise ValueError("crops must have shape (M,31,200[,1])")
         m = x.shape[0]
         c = self.crnn_classes()
-        labels = np.full((m, 48), -1, dtype=np.int32)
-        probs = np.zeros((m, 48, c), dtype=np.float32) if return_probs else None
+        lw = self.crnn_label_width()
+        labels = np.full((m, lw), -1, dtype=np.int32)
+        probs = np.zeros((m, lw, c), dtype=np.float32) if return_probs else None
         self._check(self._lib.kocr_crnn_forward(self._h, _ptr(x), m, _ptr(labels), _ptr(probs), 0))
         return (labels, probs) if return_probs else labels
 
@@ -263,7 +274,7 @@ class Context:
         n, h, w, _ = x.shape
         counts = np.array([len(b) for b in box_groups], dtype=np.int32)
         m = int(counts.sum())
-        labels = np.full((m, 48), -1, dtype=np.int32)
+        labels = np.full((m, self.crnn_label_width()), -1, dtype=np.int32)
         if m == 0:
             return labels
         flat = np.ascontiguousarray(
@@ -372,10 +383,11 @@ class Context:
         arr = [np.ascontiguousarray(v, dtype=np.int32) for v in (hs, ws, dhs, dws)]
         cap = int(cap)
         max_crops = int(max_crops) if max_crops else max(64, n * cap)
+        lw = self.crnn_label_width()
         while True:
             boxes = np.zeros((n, cap, 4, 2), dtype=np.float32)
             counts = np.zeros(n, dtype=np.int32)
-            labels = np.full((max_crops, 48), -1, dtype=np.int32)
+            labels = np.full((max_crops, lw), -1, dtype=np.int32)
             n_crops = np.zeros(1, dtype=np.int32)
             rc = self._lib.kocr_pipeline(
                 self._h, n, c_ptrs, *[a.ctypes.data_as(_c_int_p) for a in arr], int(hmax), int(wmax),

@@ -3,7 +3,6 @@
 #include "common.h"
 #include <cmath>
 #include <algorithm>
-#include <algorithm>
 
 // ---------------------------------------------------------------------------------------
 // ctx internals
@@ -62,6 +61,16 @@ int kocr_ctx::dev_alloc(void** out, size_t bytes) {
   owned.push_back(p);
   *out = p;
   return KOCR_OK;
+}
+
+void kocr_ctx::release(void* p) {
+  if (!p) return;
+  for (size_t i = owned.size(); i-- > 0;)
+    if (owned[i] == p) {
+      owned.erase(owned.begin() + (long)i);
+      hipFree(p);
+      return;
+    }
 }
 
 int kocr_ctx::upload(float** out, const std::vector<float>& host) {
@@ -275,6 +284,8 @@ int kocr_load_crnn(kocr_ctx* ctx, int n, const char* const* names, const float* 
 }
 
 int kocr_crnn_classes(kocr_ctx* ctx) { return ctx ? crnn_classes(ctx) : KOCR_EINVAL; }
+int kocr_crnn_label_width(kocr_ctx* ctx) { return ctx ? crnn_label_width(ctx) : KOCR_EINVAL; }
+int kocr_crnn_set_rnn_steps_to_discard(kocr_ctx* ctx, int steps) { return ctx ? crnn_set_discard(ctx, steps) : KOCR_EINVAL; }
 
 int kocr_crnn_forward(kocr_ctx* ctx, const float* crops, int M, int32_t* labels, float* probs, int on_device) {
   if (!ctx) return KOCR_EINVAL;
@@ -284,14 +295,15 @@ int kocr_crnn_forward(kocr_ctx* ctx, const float* crops, int M, int32_t* labels,
   if (M == 0) return KOCR_OK;
   KOCR_HIP(ctx, hipSetDevice(ctx->device));
   const int mb = std::min(M, 1024);
-  const size_t cb = (size_t)31 * 200 * sizeof(float), lb = 48 * sizeof(int32_t), pb = (size_t)48 * C * sizeof(float);
+  const int LW = crnn_label_width(ctx);
+  const size_t cb = (size_t)31 * 200 * sizeof(float), lb = LW * sizeof(int32_t), pb = (size_t)LW * C * sizeof(float);
   KOCR_TRY(ctx->ws_reserve(crnn_workspace_bytes(mb, C) + (on_device ? 0 : (cb + lb + pb) * mb + 2048)));
   for (int s = 0; s < M; s += mb) {
     const int nb = std::min(mb, M - s);
     ctx->ws_reset();
     const float* d_c = crops + (size_t)s * 31 * 200;
-    int32_t* d_l = labels + (size_t)s * 48;
-    float* d_p = probs ? probs + (size_t)s * 48 * C : nullptr;
+    int32_t* d_l = labels + (size_t)s * LW;
+    float* d_p = probs ? probs + (size_t)s * LW * C : nullptr;
     if (!on_device) {
       float* dc = (float*)ctx->ws_alloc(cb * nb);
       d_l = (int32_t*)ctx->ws_alloc(lb * nb);
@@ -302,9 +314,9 @@ int kocr_crnn_forward(kocr_ctx* ctx, const float* crops, int M, int32_t* labels,
     }
     KOCR_TRY(crnn_forward(ctx, d_c, nb, d_l, d_p));
     if (!on_device) {
-      KOCR_HIP(ctx, hipMemcpyAsync(labels + (size_t)s * 48, d_l, lb * nb, hipMemcpyDeviceToHost, ctx->stream));
+      KOCR_HIP(ctx, hipMemcpyAsync(labels + (size_t)s * LW, d_l, lb * nb, hipMemcpyDeviceToHost, ctx->stream));
       if (probs)
-        KOCR_HIP(ctx, hipMemcpyAsync(probs + (size_t)s * 48 * C, d_p, pb * nb, hipMemcpyDeviceToHost, ctx->stream));
+        KOCR_HIP(ctx, hipMemcpyAsync(probs + (size_t)s * LW * C, d_p, pb * nb, hipMemcpyDeviceToHost, ctx->stream));
       KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
   }
@@ -541,8 +553,19 @@ int kocr_conv2d_cells(kocr_ctx* ctx, const float* in, int N, int H, int W, int C
                       const float* pre_a, const float* pre_b, int relu, const float* post_a, const float* post_b,
                       int cellW, int cellWv, int pool, float* out, float* pool_out, float* amax_out) {
   if (!ctx || !in || !w_hwio || (!out && !pool) || (pool && !pool_out)) return KOCR_EINVAL;
-  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || cellW <= 0 || cellWv <= 0 || cellWv > cellW || W % cellW)
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || cellW <= 0 || cellWv <= 0 || W % cellW)
     KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_conv2d_cells: bad shape");
+  // the constraints include/kocr.h documents, checked here with their own messages: the columns behind cellWv are
+  // the 'same' padding between neighbouring crops -- without at least one of them a crop would read its neighbour's edge
+  if (cellWv >= cellW)
+    KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_conv2d_cells: cellWv must be smaller than cellW (at least one zero gutter column per cell)");
+  if (cellW % 4 != 0) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_conv2d_cells: cellW must be a multiple of 4 (F(4,3) quads)");
+  if (pool && (cellWv % 2 != 0 || cellW % 8 != 0 || H % 2 != 0))
+    KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_conv2d_cells: pooling needs an even cellWv, cellW % 8 == 0 and an even H");
+  if (Cin % 32 != 0 || Cout <= 64)
+    KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_conv2d_cells: the cell-grid kernel takes Cin % 32 == 0 and Cout > 64");
+  if (!((H % 4 == 0 && W % 64 == 0) || (H % 8 == 0 && W % 32 == 0)))
+    KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_conv2d_cells: the grid must tile as 4 x 64 (H % 4 == 0, W % 64 == 0) or 8 x 32");
   KOCR_HIP(ctx, hipSetDevice(ctx->device));
   KOCR_TRY(ctx->amax_begin());
   const size_t first_owned = ctx->owned.size();

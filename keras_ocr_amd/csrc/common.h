@@ -172,6 +172,7 @@ struct kocr_ctx {
   std::vector<void*> owned;
   int dev_alloc(void** out, size_t bytes);
   int upload(float** out, const std::vector<float>& host);
+  void release(void* p);  // hipFree one persistent allocation (a re-prepared layer's previous weights); nullptr is ignored
 
   CraftNet* craft = nullptr;
   CrnnNet* crnn = nullptr;
@@ -352,6 +353,8 @@ void crnn_free(kocr_ctx* ctx);
 int crnn_load(kocr_ctx* ctx, int n, const char* const* names, const float* const* data, const int64_t* shapes,
               const int* ranks);
 int crnn_classes(kocr_ctx* ctx);
+int crnn_label_width(kocr_ctx* ctx);  // 50 - rnn_steps_to_discard (48)
+int crnn_set_discard(kocr_ctx* ctx, int d);
 size_t crnn_workspace_bytes(int M, int n_classes);
 int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, float* d_probs);
 

@@ -48,10 +48,15 @@ struct DsParams {
 // probe_clock.h bins: consumer wave 0: [0] K loop  [1] up-sampled addend  [2] post + amax  [3] store issue;  producer wave 4:
 // [4] LDS fill (with the wait for its raw loads)  [5] barrier  [6] load issue
 
-// (WM, WN) = (1, 4) / (2, 2): 512 threads, one block per CU.  (1, 2) (round 6): 256 threads -- two consumer and two producer
-// waves, tile 256 pixels x 64 couts, 64 KB of LDS -- so that TWO blocks share a CU and one block's epilogue (the up-sampled
-// addend and the stores: 47 % of a tile of upconv4.conv.0, profiles/r06_ab_notes.txt) overlaps the other's K loop.
-template <int WM, int WN, int HALF, int UP>
+// (WM, WN) = (1, 4) / (2, 2): 512 threads, one block per CU.  The kernel also builds as (1, 2) -- 256 threads, two consumer and
+// two producer waves, 64 KB of LDS, TWO blocks per CU so that one block's epilogue overlaps the other's K loop; measured in
+// round 6 (profiles/r06_ab_notes.txt item 2): no faster (1.165 -> 1.150 ms, 1.076 -> 1.066 ms with PAIR), the layer is bound
+// by the memory system, not by the serial epilogue.  Not instantiated.
+// PAIR = 1 (round 6; 1x1 convolutions with an even number of 16-channel groups): the producers fetch TWO consecutive K-steps
+// with back-to-back loads per item -- the two 64-byte halves of the same 128-byte lines (a pixel's channels c .. c + 15 and
+// c + 16 .. c + 31).  Fetched a K-step (~2 us) apart, as before, the second half found its line evicted from L2 again in ~40 %
+// of the cases (PMC: upconv4.conv.0 read 3.69 GB for 2.72 GB of input + addend; profiles/r06_ab_notes.txt item 3).
+template <int WM, int WN, int HALF, int UP, int PAIR = 0>
 __global__ __launch_bounds__(128 * WM * WN, WM * WN == 2 ? 2 : 1) void conv_ds_kernel(DsParams p) {
   constexpr int NP = HALF ? 2 : 3;            // operand pieces
   constexpr int NCW = WM * WN;                // consumer waves = producer waves
@@ -112,6 +117,22 @@ __global__ __launch_bounds__(128 * WM * WN, WM * WN == 2 ? 2 : 1) void conv_ds_k
         goff[it] = (unsigned)((idx * p.in_cs + quad * 4) * 4);
       }
     };
+    // PAIR: K-steps 2 j and 2 j + 1 of a 1x1 convolution (channel groups 2 j, 2 j + 1; no taps, no padding)
+    auto load_raw2 = [&](v4f (&ra)[IPT], v4f (&rb)[IPT]) __attribute__((always_inline)) {
+      const int soff = ld_cg * 64;
+#pragma unroll
+      for (int it = 0; it < IPT; ++it) {
+        const unsigned off = gok[it] ? goff[it] : OOB;
+        ra[it] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, soff, 0));
+        rb[it] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, soff + 64, 0));
+      }
+      ld_cg += 2;
+      if (ld_cg == p.Cin / 16) {  // next tile
+        ld_cg = 0;
+        L_ld += G;
+        tile_geometry();
+      }
+    };
     auto load_raw = [&](v4f (&raw)[IPT]) __attribute__((always_inline)) {
       const int dy = ld_ky * p.dil - pad_y, dx = ld_kx * p.dil - pad_x;
       const int soff = (((dy + pad_y) * p.W + (dx + pad_x)) * p.in_cs + ld_cg * 16) * 4;
@@ -157,11 +178,38 @@ __global__ __launch_bounds__(128 * WM * WN, WM * WN == 2 ? 2 : 1) void conv_ds_k
     // D - 1 K-steps of raw input in flight ahead of the LDS fill (the LDS ring itself stays two deep): these layers are
     // HBM-bound (K = 64 .. 256 per pixel), and one 32 KB step in flight per CU is 8 MB on the chip -- half of what 8 TB/s
     // times the loaded latency asks for.  Loads past the block's last step are out-of-range buffer loads (no traffic).
-    constexpr int D = 4;
+    constexpr int D = PAIR ? 6 : 4;  // PAIR: three pairs of steps, two of them (4 steps) in flight ahead of the fill
     v4f raw[D][IPT];
+    int k = 0;
+    if constexpr (PAIR) {
+      load_raw2(raw[0], raw[1]);
+      load_raw2(raw[2], raw[3]);
+      PROBE_T0();
+      for (; k + D <= T; k += D) {
+#pragma unroll
+        for (int d = 0; d < D; d += 2) {
+          load_raw2(raw[(d + 4) % D], raw[(d + 5) % D]);
+          PROBE_T(6);
+          produce(raw[d], 0);  // k and d are even: step k + d fills buffer 0, the next one buffer 1
+          PROBE_T(4);
+          __syncthreads();
+          PROBE_T(5);
+          produce(raw[d + 1], 1);
+          PROBE_T(4);
+          __syncthreads();
+          PROBE_T(5);
+        }
+      }
+      PROBE_TEND(tid == 64 * NCW, 4, 7);
+#pragma unroll
+      for (int d = 0; d < 4; ++d)  // T is even: 0, 2 or 4 steps are left, all of them loaded
+        if (k + d < T) {
+          produce(raw[d], d & 1);
+          __syncthreads();
+        }
+    } else {
 #pragma unroll
     for (int d = 0; d < D - 1; ++d) load_raw(raw[d]);
-    int k = 0;
     PROBE_T0();
     for (; k + D <= T; k += D) {
 #pragma unroll
@@ -181,6 +229,7 @@ __global__ __launch_bounds__(128 * WM * WN, WM * WN == 2 ? 2 : 1) void conv_ds_k
         produce(raw[d], d & 1);
         __syncthreads();
       }
+    }
     __syncthreads();  // pairs with the consumers' barrier inside the last K-step
     return;
   }
@@ -559,7 +608,7 @@ bool dsplit_usable(const ConvLayer& L, const Tensor& in) {
 // gain below a few tiles
 bool dsplit_applicable(const ConvLayer& L, const Tensor& in) { return dsplit_usable(L, in) && in.pixels() >= 4096; }
 
-template <int WM, int WN, int HALF, int UP = 0>
+template <int WM, int WN, int HALF, int UP = 0, int PAIR = 0>
 static int ds_launch(kocr_ctx* ctx, DsParams& p, size_t M) {
   // 48 / 96 KB (bf16x3), 32 / 64 KB (fp16x2); UP: + one 8 KB tap table per consumer wave
   constexpr int NCW = WM * WN;
@@ -567,7 +616,7 @@ static int ds_launch(kocr_ctx* ctx, DsParams& p, size_t M) {
   static std::atomic<bool> attr_done[64];  // per device (one process may hold contexts on several GPUs); a race only repeats the call
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
-    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_ds_kernel<WM, WN, HALF, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_ds_kernel<WM, WN, HALF, UP, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_done[dev] = true;
   }
   static std::atomic<int> n_cus[64];
@@ -582,11 +631,11 @@ static int ds_launch(kocr_ctx* ctx, DsParams& p, size_t M) {
   const int slots = n_cu * (NCW == 2 ? 2 : 1);  // (1, 2): two blocks per CU
   const int grid = p.total_tiles < slots ? p.total_tiles : slots;
   PROBE_RESET(ctx);
-  hipLaunchKernelGGL((conv_ds_kernel<WM, WN, HALF, UP>), dim3(grid), dim3(128 * NCW), LDS_BYTES, ctx->stream, p);
+  hipLaunchKernelGGL((conv_ds_kernel<WM, WN, HALF, UP, PAIR>), dim3(grid), dim3(128 * NCW), LDS_BYTES, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   {
     char what[64];
-    snprintf(what, sizeof what, "conv_ds<%d,%d,%d> tiles %d steps %d", WM, WN, UP, p.total_tiles, p.nsteps);
+    snprintf(what, sizeof what, "conv_ds<%d,%d,%d,pair%d> tiles %d steps %d", WM, WN, UP, PAIR, p.total_tiles, p.nsteps);
     (void)what;
     PROBE_REPORT(ctx, what, grid);
   }
@@ -652,17 +701,21 @@ int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout + (up ? (double)up->pixels() * L.Cout : 0.0));
   ProfScope ps(ctx, nm, flops, bytes);
+  // whole 128-byte lines per fetch (PAIR): 1x1 convolutions over an even number of channel groups.  KOCR_DS_LINES=0: round 5's
+  // one K-step per fetch (A/B, profiles/r06_ab_notes.txt item 3)
+  static const bool lines_on = !(getenv("KOCR_DS_LINES") && atoi(getenv("KOCR_DS_LINES")) == 0);
+  const bool line_pairs = lines_on && L.KH == 1 && L.KW == 1 && (L.Cin / 16) % 2 == 0 && in.cs % 32 == 0 && in.co % 32 == 0;
   if (up) {
     // exactly 2x up-sampling with W % 4 == 0: the shared-tap epilogue (UP = 2)
     const bool no_up2 = !ctx->sw.up2x;
     // KOCR_DS_PAIR: 0 = one 512-thread block per CU everywhere (round 5), 1 = the 64-cout layers on two 256-thread blocks per
     // CU, 2 (default) = every up-sampling 1x1 (A/B: profiles/r06_ab_notes.txt)
-    static const int pair = getenv("KOCR_DS_PAIR") ? atoi(getenv("KOCR_DS_PAIR")) : 2;
     if (!no_up2 && in.H == 2 * up->H && in.W == 2 * up->W && in.W % 4 == 0) {
-      if (pair >= (wcls == 128 ? 2 : 1)) return ds_launch<1, 2, 0, 2>(ctx, p, M);
+      if (line_pairs) return wcls == 128 ? ds_launch<1, 4, 0, 2, 1>(ctx, p, M) : ds_launch<2, 2, 0, 2, 1>(ctx, p, M);
       return wcls == 128 ? ds_launch<1, 4, 0, 2>(ctx, p, M) : ds_launch<2, 2, 0, 2>(ctx, p, M);
     }
     return wcls == 128 ? ds_launch<1, 4, 0, 1>(ctx, p, M) : ds_launch<2, 2, 0, 1>(ctx, p, M);
   }
+  if (line_pairs) return wcls == 128 ? ds_launch<1, 4, 0, 0, 1>(ctx, p, M) : ds_launch<2, 2, 0, 0, 1>(ctx, p, M);
   return wcls == 128 ? ds_launch<1, 4, 0>(ctx, p, M) : ds_launch<2, 2, 0>(ctx, p, M);
 }

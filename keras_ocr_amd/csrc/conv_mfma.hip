@@ -472,7 +472,18 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
   // previous weights may survive.  In round 4 d_pre_a_h did -- the <= 32-cout fp16 kernel's per-cout exponents were
   // uploaded only `if (!L.d_pre_a_h)`, so a second load kept the FIRST load's exponents next to the new weights (found by
   // tests/test_range_gpu.py's re-loaded detector: conv_cls.0 / .2 a factor 2^k off per channel).  The old device buffers
-  // stay owned by the context until it is destroyed.
+  // are released here, after the stream has drained (kept until the context died, every kocr_load_* on a live
+  // context leaked the whole previous weight set -- fp32 plus every split / transformed copy).
+  {
+    void* old[] = {L.d_w, L.d_pre_a, L.d_pre_b, L.d_post_a, L.d_post_b, L.d_w_rgb4, L.d_wino, L.d_pre_a_h, L.d_ws, L.d_w4,
+                   L.d_w4h, L.d_ds, L.d_first, L.d_hs, L.d_hs16, L.d_hsh, L.d_k5};
+    bool any = false;
+    for (void* q : old) any = any || q != nullptr;
+    if (any) {
+      KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      for (void* q : old) ctx->release(q);
+    }
+  }
   L.d_w = L.d_pre_a = L.d_pre_b = L.d_post_a = L.d_post_b = L.d_w_rgb4 = L.d_wino = L.d_pre_a_h = nullptr;
   L.d_ws = L.d_w4 = L.d_w4h = L.d_ds = L.d_first = L.d_hs = L.d_hs16 = L.d_hsh = L.d_k5 = nullptr;
   L.hs_wexp.clear();

@@ -466,7 +466,9 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x][m][r] = 0.f;
+    PROBE_T(5);  // bin [5] accumulator zeroing, [4] the drain of the previous tile's stores (+ every load in flight)
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    PROBE_T(4);
     for (int cg = 0; cg < ncg; cg += 2) {
       // even channel group: consume buffer 0, produce the odd one (this tile's) into buffer 1
       using I0 = std::integral_constant<int, 0>;
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
     ld_next = false;
     PROBE_T(1);
   }
-  PROBE_TEND(tid == 0, 0, 4);
+  PROBE_TEND(tid == 0, 0, 6);
 }
 
 // ===================================================================================================
@@ -996,7 +998,9 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x][m][r] = 0.f;
+    PROBE_T(5);
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    PROBE_T(4);
     for (int cg = 0; cg < ncg; cg += 2) {
       phase(As, As + BUF_R, 3 * cg, 0, s_cur);                             // produces channel group cg + 1 (this tile's)
       phase(As + BUF_R, As, 3 * cg + 3, 1, cg + 2 < ncg ? s_cur : s_nxt);  // ... cg + 2, or the next tile's first
@@ -1147,7 +1151,7 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
     ld_next = false;
     PROBE_T(1);
   }
-  PROBE_TEND(tid == 0, 0, 4);
+  PROBE_TEND(tid == 0, 0, 6);
 }
 
 // ===================================================================================================

@@ -35,6 +35,8 @@ struct CrnnNet {
   float* U[4] = {nullptr, nullptr, nullptr, nullptr};  // recurrent kernels 10, 10_back, 11, 11_back
   int n_classes = 0;
   bool loaded = false;
+  bool stn = true;   // build_params["stn"] (recognition.py:243-281): false when the weight set carries no stn_* tensors
+  int discard = 2;   // build_params["rnn_steps_to_discard"] (recognition.py:328)
 };
 
 namespace {
@@ -52,6 +54,13 @@ struct Blob {
 }  // namespace
 
 int crnn_classes(kocr_ctx* ctx) { return ctx->crnn && ctx->crnn->loaded ? ctx->crnn->n_classes : 0; }
+int crnn_label_width(kocr_ctx* ctx) { return T - (ctx->crnn ? ctx->crnn->discard : DISCARD); }
+int crnn_set_discard(kocr_ctx* ctx, int d) {
+  if (d < 0 || d >= T) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_crnn_set_rnn_steps_to_discard: 0 <= steps < 50 (recognition.py:328)");
+  if (!ctx->crnn) ctx->crnn = new CrnnNet();
+  ctx->crnn->discard = d;
+  return KOCR_OK;
+}
 
 int crnn_load(kocr_ctx* ctx, int n, const char* const* names, const float* const* data, const int64_t* shapes,
               const int* ranks) {
@@ -108,7 +117,9 @@ int crnn_load(kocr_ctx* ctx, int n, const char* const* names, const float* const
     KOCR_TRY(add(nm, w, cin, cout, 3, b, 1, qa.empty() ? nullptr : qa.data(), qb.empty() ? nullptr : qb.data()));
     cin = cout;
   }
-  {
+  // build_params["stn"] = False (recognition.py:243): a weight set without the localisation network -> no transformer
+  net->stn = blobs.count("stn_conv_1/kernel") != 0;
+  if (net->stn) {
     const float *w, *b;
     KOCR_TRY(need("stn_conv_1/kernel", (size_t)25 * 512 * 16, &w));
     KOCR_TRY(need("stn_conv_1/bias", 16, &b));
@@ -122,6 +133,9 @@ int crnn_load(kocr_ctx* ctx, int n, const char* const* names, const float* const
     KOCR_TRY(need("stn_dense_2/kernel", (size_t)64 * 6, &w));
     KOCR_TRY(need("stn_dense_2/bias", 6, &b));
     KOCR_TRY(add("stn_dense_2", w, 64, 6, 1, b, 0, nullptr, nullptr));
+  }
+  {
+    const float *w, *b;
     KOCR_TRY(need("fc_9/kernel", (size_t)3584 * UNITS, &w));
     KOCR_TRY(need("fc_9/bias", UNITS, &b));
     KOCR_TRY(add("fc_9", w, 3584, UNITS, 1, b, 1, nullptr, nullptr));
@@ -193,7 +207,7 @@ size_t crnn_workspace_bytes(int M, int n_classes) {
   return t + 8192;
 }
 
-// d_crops: device [M][31][200]; d_labels: device [M][48]; d_probs: device [M][48][C] or null
+// d_crops: device [M][31][200]; d_labels: device [M][LW]; d_probs: device [M][LW][C] or null, LW = crnn_label_width (48)
 int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, float* d_probs) {
   CrnnNet* net = ctx->crnn;
   if (!net || !net->loaded) KOCR_FAIL(ctx, KOCR_ENOWEIGHTS, "kocr_crnn_forward: call kocr_load_crnn first");
@@ -328,6 +342,9 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
   KOCR_TRY(launch_crnn_to_keras(ctx, c7n, c7));
   }
   // STN (recognition.py:268-281)
+  if (!net->stn) {
+    st = c7;
+  } else {
   KOCR_TRY(mk(M, WC / 4, HC / 4, 16, &s1));
   KOCR_TRY(conv("stn_conv_1", c7, s1));
   KOCR_TRY(mk(M, WC / 4, HC / 4, 32, &s2));
@@ -347,6 +364,7 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
   KOCR_TRY(conv("stn_dense_2", d1, th));
   KOCR_TRY(mk(M, WC / 4, HC / 4, 512, &st));
   KOCR_TRY(launch_stn_sample(ctx, c7, th.p, st));
+  }
   // Reshape + fc_9 (recognition.py:282-290)
   KOCR_TRY(mk(M, T, 1, UNITS, &f9));
   KOCR_TRY(conv("fc_9", view(st, M, T, 1, 7 * 512), f9));
@@ -361,6 +379,6 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
   // fc_12 + softmax + decode (recognition.py:321-328, 169-184)
   KOCR_TRY(mk(M, T, 1, net->n_classes, &lg));
   KOCR_TRY(conv("fc_12", r2, lg));
-  KOCR_TRY(launch_ctc(ctx, lg.p, M, T, net->n_classes, DISCARD, d_labels, d_probs));
+  KOCR_TRY(launch_ctc(ctx, lg.p, M, T, net->n_classes, net->discard, d_labels, d_probs));
   return KOCR_OK;
 }

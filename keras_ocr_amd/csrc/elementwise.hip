@@ -382,9 +382,9 @@ int launch_absmax(kocr_ctx* ctx, const Tensor& t, unsigned* slots) {
 // out[0..2] = counts (non-zero, s < 2^-4, s < 2^-14), sums[0..1] = sum |x| (all, those with s < 2^-4)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void range_stats_kernel(const float* in, int H, int W, int C4, int cs, int co, const unsigned* slots,
-                                                          int cells, int cellW, int top, unsigned long long* cnt, double* sums) {
+                                                          int cells, int cellW, int top, unsigned long long* cnt, double* sums, int n0) {
   typedef float v4f __attribute__((ext_vector_type(4)));
-  const int n = blockIdx.y;
+  const int n = n0 + blockIdx.y;
   const size_t img_pixels = (size_t)H * W, total = img_pixels * C4;
   const float* base = in + (size_t)n * img_pixels * cs;
   unsigned long long c0 = 0, c1 = 0, c2 = 0;
@@ -427,9 +427,12 @@ int launch_range_stats(kocr_ctx* ctx, const std::string& name, const Tensor& t, 
   KOCR_HIP(ctx, hipMemsetAsync(ctx->d_range, 0, 64, ctx->stream));
   size_t b = ((size_t)t.H * t.W * (t.C / 4) + 4095) / 4096;
   if (b > 64) b = 64;
-  hipLaunchKernelGGL(range_stats_kernel, dim3((unsigned)b, (unsigned)t.N), dim3(256), 0, ctx->stream, t.p, t.H, t.W, t.C / 4, t.cs, t.co, slots,
-                     t.cells(), t.cellW ? t.cellW : 1, top, cnt, sums);
-  KOCR_HIP(ctx, hipGetLastError());
+  constexpr int NCHUNK = 32768;  // images are the grid's y dimension (<= 65 535 per launch), as in launch_absmax
+  for (int n0 = 0; n0 < t.N; n0 += NCHUNK) {
+    hipLaunchKernelGGL(range_stats_kernel, dim3((unsigned)b, (unsigned)std::min(NCHUNK, t.N - n0)), dim3(256), 0, ctx->stream, t.p, t.H,
+                       t.W, t.C / 4, t.cs, t.co, slots, t.cells(), t.cellW ? t.cellW : 1, top, cnt, sums, n0);
+    KOCR_HIP(ctx, hipGetLastError());
+  }
   unsigned long long hc[4];
   double hs[4];
   KOCR_HIP(ctx, hipMemcpyAsync(hc, cnt, 32, hipMemcpyDeviceToHost, ctx->stream));

@@ -109,7 +109,7 @@ extern "C" int kocr_recognize_boxes(kocr_ctx* ctx, const uint8_t* img_rgb, int N
       prm[m].img = i;
     }
   const size_t ib = (size_t)N * H * W * 3, crop_b = (size_t)M * 31 * 200 * sizeof(float);
-  const size_t lab_b = (size_t)M * 48 * sizeof(int32_t), pb = (size_t)M * sizeof(WarpParam);
+  const size_t lab_b = (size_t)M * crnn_label_width(ctx) * sizeof(int32_t), pb = (size_t)M * sizeof(WarpParam);
   KOCR_TRY(arena_reserve(ctx, ctx->io, pb + crop_b + lab_b + (on_device ? 0 : ib) + 4096));
   ctx->io.off = 0;
   WarpParam* d_prm = (WarpParam*)arena_alloc(ctx->io, pb);
@@ -129,7 +129,7 @@ extern "C" int kocr_recognize_boxes(kocr_ctx* ctx, const uint8_t* img_rgb, int N
   for (long s = 0; s < M; s += cmb) {
     const int nb = (int)std::min<long>(cmb, M - s);
     ctx->ws_reset();
-    KOCR_TRY(crnn_forward(ctx, d_crops + (size_t)s * 31 * 200, nb, d_lab + (size_t)s * 48, nullptr));
+    KOCR_TRY(crnn_forward(ctx, d_crops + (size_t)s * 31 * 200, nb, d_lab + (size_t)s * crnn_label_width(ctx), nullptr));
   }
   KOCR_HIP(ctx, hipMemcpyAsync(labels, d_lab, lab_b, hipMemcpyDeviceToHost, ctx->stream));
   KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -226,7 +226,7 @@ extern "C" int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, c
     KOCR_FAIL(ctx, KOCR_ECAPACITY, "kocr_pipeline: more crops than max_crops");
   }
   // ---- crops: homographies on the device (warp.hip), no host round trip ----
-  const size_t crop_b = (size_t)M * 31 * 200 * sizeof(float), lab_b = (size_t)M * 48 * sizeof(int32_t);
+  const size_t crop_b = (size_t)M * 31 * 200 * sizeof(float), lab_b = (size_t)M * crnn_label_width(ctx) * sizeof(int32_t);
   KOCR_TRY(arena_reserve(ctx, ctx->io, (size_t)M * sizeof(WarpParam) + crop_b + lab_b + 8192));
   ctx->io.off = 0;
   WarpParam* d_prm = (WarpParam*)arena_alloc(ctx->io, (size_t)M * sizeof(WarpParam));
@@ -243,7 +243,7 @@ extern "C" int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, c
   for (long s = 0; s < M; s += cmb) {
     const int nb = (int)std::min<long>(cmb, M - s);
     ctx->ws_reset();
-    KOCR_TRY(crnn_forward(ctx, d_crops + (size_t)s * 31 * 200, nb, d_lab + (size_t)s * 48, nullptr));
+    KOCR_TRY(crnn_forward(ctx, d_crops + (size_t)s * 31 * 200, nb, d_lab + (size_t)s * crnn_label_width(ctx), nullptr));
   }
   KOCR_HIP(ctx, hipMemcpyAsync(labels, d_lab, lab_b, hipMemcpyDeviceToHost, ctx->stream));
   KOCR_HIP(ctx, hipMemcpyAsync(&host_flags[4], d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

@@ -175,6 +175,13 @@ def gather_packed(box_groups, labels, per_rank_images, group=None, error=None, t
     t0 = time.perf_counter()
     world = dist.get_world_size(group)
     dev = _comm_device(group)
+    if error is None and device_scale is not None and dev.type == "cuda" and m_local and \
+            (not device_results or device_results.get("m") != m_local):
+        # found BEFORE the first collective and sent through the status slot: raised locally after the counts exchange it would
+        # leave the other ranks blocked in the box / label gathers
+        error = RuntimeError("gather_packed: device-originated gather without this rank's device results")
+        box_groups, labels = [], np.zeros((0, LABEL_WIDTH), np.int32)
+        counts_local, m_local, boxes_local = [], 0, np.zeros((0, 8), np.float32)
     # 1. counts: per_rank_images + 2 ints per rank (slot -2 = number of images this rank really had, slot -1 = status)
     c = torch.zeros(per_rank_images + 2, dtype=torch.int32)
     c[:len(counts_local)] = torch.tensor(counts_local, dtype=torch.int32)
@@ -200,8 +207,6 @@ def gather_packed(box_groups, labels, per_rank_images, group=None, error=None, t
     # have it or none has: recognize_device / recognize_scattered pass it on every rank that had work)
     on_device = device_scale is not None and dev.type == "cuda"
     if on_device and m_local:
-        if not device_results or device_results.get("m") != m_local:
-            raise RuntimeError("gather_packed: device-originated gather without this rank's device results")
         b, l = _pack_on_device(device_results, cap, dev)
     elif on_device:
         b = torch.zeros((cap, 8), dtype=torch.float32, device=dev)
@@ -275,7 +280,7 @@ class ShardedPipeline:
         rank, world = self._rank_world()
         start, end = shard_bounds(n_total, world, rank)
         dev_res, scale = self._device_gather(n_total, h, w)
-        return self._run_shard(lambda: self.pipeline.recognize_device_raw(d_ptr, end - start, h, w, detection_kwargs, dev_res),
+        return self._run_shard(lambda: self.pipeline.recognize_device_raw(d_ptr, end - start, h, w, detection_kwargs, *(() if dev_res is None else (dev_res,))),
                                end > start, -(-n_total // world), timing, dev_res, scale)
 
     def _device_gather(self, n_total, h, w):
@@ -350,7 +355,7 @@ class ShardedPipeline:
             if src_error is not None:
                 raise src_error
             if mine.device.type == "cuda":
-                return self.pipeline.recognize_device_raw(mine.data_ptr(), n_mine, h, w, detection_kwargs, dev_res)
+                return self.pipeline.recognize_device_raw(mine.data_ptr(), n_mine, h, w, detection_kwargs, *(() if dev_res is None else (dev_res,)))
             # host tensors (gloo): the same call as recognize(); every image has the batch's size
             _, _, _, hmax, wmax = self.pipeline._plan([(h, w, 3)] * n_total)  # pylint: disable=protected-access
             return self.pipeline.recognize_raw(mine[:n_mine].numpy(), hmax, wmax, detection_kwargs, None)

@@ -111,7 +111,7 @@ class Pipeline:
         texts = self.recognizer.recognize_from_boxes(images=padded, box_groups=box_groups)
         alphabet = self.recognizer.alphabet
         rows = [t for group in texts for t in group]
-        labels = np.full((len(rows), 48), -1, np.int32)
+        labels = np.full((len(rows), max([48] + [len(t) for t in rows])), -1, np.int32)
         for r, t in enumerate(rows):
             labels[r, :len(t)] = [alphabet.index(ch) for ch in t]
         return self._adjust(box_groups, scales), labels

@@ -125,8 +125,10 @@ def measure_traffic(bench_path, prof_name, timeout=150, clock=True):
             if counter == "FETCH_SIZE":
                 mp = [kk for kk in agg if kk.startswith("maxpool2x2")]
                 sums["_mp_fetch"] = agg[mp[0]]["FETCH_SIZE"] if mp else None
-                for ln in p.stdout.splitlines():
-                    if ln.startswith('{"metric"'):
+                for ln in p.stdout.splitlines():  # the child's FULL record (stderr, merged into stdout here) carries roofline.process
+                    if ln.startswith("[bench full] "):
+                        line = json.loads(ln[len("[bench full] "):])
+                    elif ln.startswith('{"metric"') and line is None:
                         line = json.loads(ln)
             else:
                 mp = [kk for kk in agg if kk.startswith("maxpool2x2")]

@@ -41,6 +41,32 @@ PRETRAINED_WEIGHTS: typing.Dict[str, typing.Any] = {  # recognition.py:27-44
 }
 
 
+# build parameters this implementation can vary (recognition.py:187-198): the transformer on / off and the number of leading
+# RNN steps dropped; everything else is the geometry the kernels are written for
+_VARIABLE_BUILD_PARAMS = ("stn", "rnn_steps_to_discard")
+
+
+def _check_build_params(build_params):
+    """DEFAULT_BUILD_PARAMS, `stn=False` and any `rnn_steps_to_discard` in [0, 50) are implemented; a different value of any
+    other parameter raises NotImplementedError naming it (recognition.py:187-198 takes them all)."""
+    unknown = sorted(set(build_params) - set(DEFAULT_BUILD_PARAMS))
+    if unknown:
+        raise TypeError(f"build_model() got unexpected build parameter(s) {unknown}")
+    merged = dict(DEFAULT_BUILD_PARAMS, **build_params)
+    for key, default in DEFAULT_BUILD_PARAMS.items():
+        value = merged[key]
+        if key in _VARIABLE_BUILD_PARAMS:
+            continue
+        if (tuple(value) if isinstance(value, (list, tuple)) else value) != default and key != "dropout":  # dropout: inference no-op
+            raise NotImplementedError(
+                f"keras-ocr_amd: build parameter {key}={value!r} is not implemented (only {key}={default!r}); "
+                f"the parameters that may differ from DEFAULT_BUILD_PARAMS are {_VARIABLE_BUILD_PARAMS} and dropout")
+    steps = int(merged["rnn_steps_to_discard"])
+    if not 0 <= steps < 50:
+        raise ValueError("rnn_steps_to_discard must lie in [0, 50): the model has 200 // 4 = 50 RNN steps")
+    return bool(merged["stn"]), steps
+
+
 class _Model:
     def __init__(self, ctx, probs):
         self._ctx = ctx
@@ -60,7 +86,9 @@ class Recognizer:
         alphabet: the alphabet the model recognises.
         weights: ``"kurapan"`` (pretrained file from the keras-ocr cache directory), ``None``
             (random initialisation: seeded synthetic weights) or a ``dict`` of Keras-named arrays.
-        build_params: only ``DEFAULT_BUILD_PARAMS`` is implemented.
+        build_params: ``DEFAULT_BUILD_PARAMS``, optionally with ``stn=False`` (no spatial transformer, recognition.py:243)
+            and / or another ``rnn_steps_to_discard`` (recognition.py:328); a different ``color`` / size / filter set raises
+            ``NotImplementedError`` naming the parameter.
     """
 
     def __init__(self, alphabet=None, weights="kurapan", build_params=None, ctx=None):
@@ -69,8 +97,7 @@ class Recognizer:
             build_params = build_params or PRETRAINED_WEIGHTS[weights]["build_params"]
             alphabet = alphabet or PRETRAINED_WEIGHTS[weights]["alphabet"]
         build_params = build_params or DEFAULT_BUILD_PARAMS
-        if dict(build_params) != DEFAULT_BUILD_PARAMS:
-            raise NotImplementedError("keras-ocr_amd implements the default CRNN build parameters only.")
+        stn, discard = _check_build_params(dict(build_params))
         if alphabet is None:
             alphabet = DEFAULT_ALPHABET
         self.alphabet = alphabet
@@ -94,7 +121,13 @@ class Recognizer:
             state = _weights.synthetic_crnn_weights(n_classes=len(alphabet) + 1)
         if state["fc_12/bias"].shape[0] != len(alphabet) + 1:
             raise ValueError("fc_12 does not match the alphabet length")
+        if not stn:  # recognition.py:243: the model is built without the localisation network; its tensors are not loaded
+            state = {k: v for k, v in state.items() if not k.startswith("stn_")}
+        elif "stn_conv_1/kernel" not in state:
+            raise ValueError("build_params['stn'] is True but the weights carry no stn_* tensors")
+        self._ctx.crnn_set_rnn_steps_to_discard(discard)
         self._ctx.load_crnn(state)
+        self.build_params = dict(DEFAULT_BUILD_PARAMS, **dict(build_params))
         self.model = _Model(self._ctx, probs=True)
         self.prediction_model = _Model(self._ctx, probs=False)
         self.backbone = None

@@ -197,7 +197,25 @@ def warpBox(image, box, target_height=None, target_width=None, margin=0, cval=No
     ctx = ctx or _lib.default_context()
     image = np.asarray(image)
     if image.dtype != np.uint8:
-        raise TypeError("warpBox expects a uint8 image")
+        # any other dtype (tools.py:61-117 hands the image to cv2.warpPerspective as it is): the float kernel
+        # (kocr_warp_crops_f32: float32 bilinear interpolation, constant-0 border), channel by channel; it derives the rotated
+        # box itself, so it serves the default geometry (margin 0, skip_rotate False) -- the one recognize_from_boxes uses
+        if margin != 0 or skip_rotate or return_transform:
+            raise NotImplementedError("warpBox on a non-uint8 image: margin != 0, skip_rotate and return_transform are "
+                                      "implemented for uint8 images only")
+        img = image.astype(np.float32)
+        planes = [img[..., None]] if img.ndim == 2 else [img[..., c:c + 1] for c in range(img.shape[2])]
+        crops = np.concatenate([ctx.warp_crops_f32(p[np.newaxis], [box[np.newaxis]], int(target_height), int(target_width))
+                                for p in planes])
+        target_shape = (target_height, target_width, 3) if len(image.shape) == 3 else (target_height, target_width)
+        full = (np.zeros(target_shape) + cval).astype("uint8")  # tools.py:109-113: a uint8 canvas whatever the image's dtype
+        ch, cw = min(dsize[1], target_height), min(dsize[0], target_width)
+        with np.errstate(invalid="ignore"):
+            if image.ndim == 2:
+                full[:ch, :cw] = crops[0, :ch, :cw]
+            else:
+                full[:ch, :cw] = np.moveaxis(crops[:, :ch, :cw], 0, -1)
+        return full
     # channel c as a gray RGB image: OpenCV's RGB->gray of (v, v, v) is v, so the crop is channel c's warp, bit for bit
     planes = [image] if image.ndim == 2 else [image[..., c] for c in range(image.shape[2])]
     stack = np.stack([np.repeat(p[..., None], 3, -1) for p in planes])

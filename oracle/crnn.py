@@ -125,14 +125,17 @@ def crnn_forward(w, X, rnn_steps_to_discard=2, return_intermediates=False):
     x = _conv(w, "conv_6", x)
     x = _bn(w, "bn_7", _conv(w, "conv_7", x))
     inter["bn_7"] = x.permute(0, 2, 3, 1)
-    # STN
-    loc = _conv(w, "stn_conv_1", x)
-    loc = _conv(w, "stn_conv_2", loc)
-    loc = loc.permute(0, 2, 3, 1).reshape(loc.shape[0], -1)  # Keras Flatten of NHWC
-    loc = F.relu(loc @ _t(w["stn_dense_1/kernel"]) + _t(w["stn_dense_1/bias"]))
-    theta = loc @ _t(w["stn_dense_2/kernel"]) + _t(w["stn_dense_2/bias"])
-    inter["theta"] = theta
-    x = stn_transform(x.permute(0, 2, 3, 1).contiguous(), theta)  # (M,50,7,512)
+    # STN (recognition.py:243-281: only `if stn:`; a weight set without stn_* tensors = build_params["stn"] False)
+    if "stn_conv_1/kernel" in w:
+        loc = _conv(w, "stn_conv_1", x)
+        loc = _conv(w, "stn_conv_2", loc)
+        loc = loc.permute(0, 2, 3, 1).reshape(loc.shape[0], -1)  # Keras Flatten of NHWC
+        loc = F.relu(loc @ _t(w["stn_dense_1/kernel"]) + _t(w["stn_dense_1/bias"]))
+        theta = loc @ _t(w["stn_dense_2/kernel"]) + _t(w["stn_dense_2/bias"])
+        inter["theta"] = theta
+        x = stn_transform(x.permute(0, 2, 3, 1).contiguous(), theta)  # (M,50,7,512)
+    else:
+        x = x.permute(0, 2, 3, 1).contiguous()
     inter["stn"] = x
     M = x.shape[0]
     x = x.reshape(M, x.shape[1], -1)    # Reshape((W//4, (H//4)*512))

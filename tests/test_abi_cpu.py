@@ -113,3 +113,23 @@ def test_decode_labels_matches_the_per_character_loop():
     assert decode_labels("abc", np.array([0, 2, 3, -1, 1])) == ["acb"]          # a single row (1-D) is one string
     with pytest.raises(IndexError):
         decode_labels("abc", np.array([[0, 7]]))
+
+
+def test_recogniser_build_parameters_that_are_and_are_not_implemented():
+    """recognition.py:187-198 takes a dict of build parameters: the default set, stn=False and any rnn_steps_to_discard are
+    implemented; anything else must fail with an error that NAMES the parameter."""
+    import pytest
+    from keras_ocr_amd.recognition import DEFAULT_BUILD_PARAMS, _check_build_params
+
+    assert _check_build_params(dict(DEFAULT_BUILD_PARAMS)) == (True, 2)
+    assert _check_build_params({"stn": False}) == (False, 2)
+    assert _check_build_params(dict(DEFAULT_BUILD_PARAMS, rnn_steps_to_discard=0, dropout=0.5)) == (True, 0)
+    assert _check_build_params(dict(DEFAULT_BUILD_PARAMS, filters=list(DEFAULT_BUILD_PARAMS["filters"]))) == (True, 2)  # list == tuple
+    for key, value in (("color", True), ("width", 256), ("height", 32), ("filters", (64, 128, 256, 256, 512, 512, 256)),
+                       ("rnn_units", (256, 256)), ("pool_size", 3)):
+        with pytest.raises(NotImplementedError, match=key):
+            _check_build_params(dict(DEFAULT_BUILD_PARAMS, **{key: value}))
+    with pytest.raises(ValueError):
+        _check_build_params({"rnn_steps_to_discard": 50})
+    with pytest.raises(TypeError):
+        _check_build_params({"no_such_parameter": 1})

@@ -279,3 +279,46 @@ def test_bench_main_at_world_4_with_uneven_shards(pages, blocks, capfd):
     assert abs(sh["value"] - pages * 2 / (sh["ms_per_batch"] * 2 / 1e3)) < 1e-6 * sh["value"]
     out = capfd.readouterr().out
     assert sum(ln.startswith('{"metric"') for ln in out.splitlines()) == 1
+
+
+@pytest.mark.parametrize("pages,blocks", [(256, [32] * 8), (250, [32] * 7 + [26])], ids=["cfg5_256_pages_equal_blocks", "250_pages_ragged"])
+def test_bench_main_at_world_8_the_cfg5_job_shape(pages, blocks, capfd):
+    """VERDICT r05 item 7 / SURVEY 8(e): bench.main() at WORLD SIZE 8 over gloo with the job shape of BASELINE configs[4] --
+    ONE batch of 256 pages (tiny ones here), 32 per rank -- and the same with 250 pages (a short last block).  Checks the
+    N = 8 line's schema: every rank was seen by the all-reduce, every rank ends with all pages, rank 0 sends 7/8 of the
+    batch in the scatter leg (equal, zero-padded blocks), whole-job accounting of `value`.  No scaling number is claimed."""
+    import socket
+    import torch.multiprocessing as mp
+    import keras_ocr_amd
+
+    assert [e - s_ for s_, e in (keras_ocr_amd.dist.shard_bounds(pages, 8, r) for r in range(8))] == blocks
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    extra = ("--cfg5-pages", str(pages), "--batch", "32", "--side5", "16")
+    procs = [ctx.Process(target=_bench_worker, args=(r, 8, port, q, extra)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res = got[0][2]
+    assert all(g[2] is None for g in got[1:]) and isinstance(res, dict)            # ONE result, from rank 0
+    assert res["n_gpus"] == 8 and res["ranks_seen"] == 8 and res["config"]["global_batch"] == 256 and res["scaling"] == "weak"
+    assert abs(res["value"] - 256 * 2 / (res["ms_per_step"] * 2 / 1e3)) < 1e-6 * res["value"]
+    sh, sc = res["cfg5_sharded"], res["cfg5_scattered"]
+    assert sh["pages_returned_on_every_rank"] == pages and sh["backend"] == "gloo" and sh["gather_ms"] > 0
+    assert sc["scatter_bytes_sent_by_rank0"] == 32 * 7 * 16 * 16 * 3                # 7/8 of the (padded) batch leave rank 0
+    assert sc["same_strings_as_resident_blocks"]
+    assert abs(sh["value"] - pages * 2 / (sh["ms_per_batch"] * 2 / 1e3)) < 1e-6 * sh["value"]
+    out = capfd.readouterr().out
+    lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1                                                          # exactly one JSON line on stdout
+    import json
+
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and "crnn_ms_per_crop" in line["config"]
+    assert line["legs_images_per_s"]["cfg5_sharded"] > 0 and len(lines[0]) < 6000   # the driver's record holds it whole

@@ -90,3 +90,35 @@ def test_large_custom_alphabet(ctx):
     assert np.array_equal(labels[safe], ocrnn.ctc_greedy_decode(want_p)[safe])
     assert labels.max() < n_classes - 1
     c2.close()
+
+
+@pytest.mark.parametrize("stn,discard", [(False, 2), (True, 0), (False, 5)], ids=["no_stn", "discard_0", "no_stn_discard_5"])
+def test_non_default_builds_match_the_oracle(ctx, crnn_weights, stn, discard):
+    """build_params of recognition.py:187-198 beyond the default: `stn=False` (the model is built
+    without the localisation network, :243) and another `rnn_steps_to_discard` (:328) -- label rows are then 50 - steps wide."""
+    import keras_ocr_amd
+    from keras_ocr_amd.recognition import DEFAULT_BUILD_PARAMS
+    from oracle import crnn as ocrnn
+
+    x = _crops(9, seed=300)
+    try:
+        rec = keras_ocr_amd.recognition.Recognizer(weights=dict(crnn_weights), ctx=ctx,
+                                                   build_params=dict(DEFAULT_BUILD_PARAMS, stn=stn, rnn_steps_to_discard=discard))
+        assert rec.build_params["stn"] is stn and ctx.crnn_label_width() == 50 - discard
+        labels, probs = ctx.crnn_forward(x, return_probs=True)
+        w = crnn_weights if stn else {k: v for k, v in crnn_weights.items() if not k.startswith("stn_")}
+        want_p = ocrnn.crnn_forward(w, x[..., None], rnn_steps_to_discard=discard)
+        want_l = ocrnn.ctc_greedy_decode(want_p)
+        assert probs.shape == want_p.shape == (9, 50 - discard, 37) and labels.shape == (9, 50 - discard)
+        err = float(np.abs(probs - want_p).max())
+        assert err <= PROB_TOL, f"max abs prob error {err}"
+        srt = np.sort(want_p, -1)
+        safe = ((srt[..., -1] - srt[..., -2]) > MARGIN).all(1)
+        assert safe.sum() >= 3 and np.array_equal(labels[safe], want_l[safe])
+        # the string API on top of it (recognition.py:467-489)
+        img = np.repeat((x[0] * 255).astype(np.uint8)[..., None], 3, -1)
+        assert rec.recognize(img) == ocrnn.decode_strings(ctx.crnn_forward(x[:1]))[0]
+    finally:
+        ctx.crnn_set_rnn_steps_to_discard(2)
+        ctx.load_crnn(crnn_weights)
+    assert ctx.crnn_label_width() == 48

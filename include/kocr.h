@@ -191,6 +191,13 @@ int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, const int32_
  * the next libkocr call on this context that processes images (the buffers live in the context's arenas); KOCR_EINVAL when
  * no result is resident.  For callers that hand the results to another device-side consumer -- keras_ocr_amd.dist packs
  * them on the device and all-gathers them over RCCL without a host round trip. */
+/* Capacity without recomputation (round 6).  cap / max_crops size the CALLER's buffers only: when an image has more boxes than
+ * cap, or there are more crops than max_crops, kocr_pipeline still runs the whole chain once (a larger device box buffer, the
+ * post-processing alone repeated on the resident heat-maps), leaves the results in HBM and returns KOCR_ECAPACITY with the
+ * true counts / n_crops.  This call copies them into buffers sized from those numbers: boxes N x cap x 4 x 2 (cap >= the
+ * largest count), labels n_crops x 48.  Valid until the next libkocr call on this context that processes images. */
+int kocr_pipeline_results(kocr_ctx* ctx, float* boxes, int cap, int32_t* labels, int max_crops);
+
 int kocr_pipeline_device_results(kocr_ctx* ctx, const float** d_boxes, const int32_t** d_counts, const int32_t** d_labels,
                                  int32_t* N, int32_t* cap, int32_t* M);
 

@@ -72,6 +72,7 @@ def load_library():
         "kocr_pipeline": (ci, [vp, ci, ctypes.POINTER(vp), _c_int_p, _c_int_p, _c_int_p, _c_int_p, ci, ci,
                                ctypes.c_float, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, ci, vp, ci, vp, ci]),
         "kocr_pipeline_device_results": (ci, [vp, vp, vp, vp, vp, vp, vp]),
+        "kocr_pipeline_results": (ci, [vp, vp, ci, vp, ci]),
         "kocr_resize_pad_f32": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ctypes.c_float, vp]),
         "kocr_warp_crops_f32": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp]),
         "kocr_conv2d_nhwc": (ci, [vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp]),
@@ -394,14 +395,14 @@ class Context:
                 float(detection_threshold), float(text_threshold), float(link_threshold), int(size_threshold),
                 int(micro_batch), _ptr(boxes), _ptr(counts), cap, _ptr(labels), max_crops, _ptr(n_crops),
                 int(bool(on_device)))
-            if rc == -4:  # KOCR_ECAPACITY: grow and retry
-                if n and counts.max() > cap:
-                    cap = int(counts.max())
-                    max_crops = max(max_crops, int(counts.sum()))
-                    continue
-                if int(n_crops[0]) > max_crops:
-                    max_crops = int(n_crops[0])
-                    continue
+            if rc == -4 and n and (counts.max() > cap or int(n_crops[0]) > max_crops):
+                # KOCR_ECAPACITY with the true counts: the whole chain has run ONCE and its results are resident in HBM (round 6:
+                # no second detector forward) -- fetch them into buffers of the right size
+                cap = max(cap, int(counts.max()))
+                max_crops = max(max_crops, int(n_crops[0]))
+                boxes = np.zeros((n, cap, 4, 2), dtype=np.float32)
+                labels = np.full((max_crops, lw), -1, dtype=np.int32)
+                rc = self._lib.kocr_pipeline_results(self._h, _ptr(boxes), cap, _ptr(labels), max_crops)
             if rc == -6:
                 raise IndexError("list index out of range")
             if rc == -7:

@@ -171,7 +171,7 @@ void kocr_destroy(kocr_ctx* ctx) {
   craft_free(ctx);
   crnn_free(ctx);
   for (void* p : ctx->owned) hipFree(p);
-  for (Arena* a : {&ctx->ws, &ctx->pp, &ctx->pp2, &ctx->io, &ctx->pl})
+  for (Arena* a : {&ctx->ws, &ctx->pp, &ctx->pp2, &ctx->io, &ctx->pl, &ctx->bx})
     if (a->base) hipFree(a->base);
   for (auto& pd : ctx->pending) {
     hipEventDestroy(pd.a);

@@ -164,6 +164,7 @@ struct kocr_ctx {
   // pp = post-processing per-pixel scratch, pp2 = post-processing canvases, io = staging,
   // pl = buffers that live for a whole kocr_pipeline call (padded batch, heat-maps, boxes)
   Arena ws, pp, pp2, io, pl;
+  Arena bx;  // kocr_pipeline: the box buffer of a page with more boxes than the caller's cap (the pl arena holds the heat-maps)
   int ws_reserve(size_t bytes);
   void ws_reset() { ws.off = 0; }
   void* ws_alloc(size_t bytes);

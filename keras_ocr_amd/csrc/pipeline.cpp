@@ -199,13 +199,35 @@ extern "C" int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, c
   }
   // ---- boxes: the host learns only the per-image counts here (needed to size the crop batch); the boxes themselves
   // go to the caller asynchronously while the device already derives the crop homographies from its own copy ----
+  // CAPACITY WITHOUT RECOMPUTATION (round 6; the reference has no cap, detection.py:230-286): `cap` and `max_crops` size the
+  // CALLER's buffers only.  A page with more boxes than cap gets a larger device box buffer (its own arena: growing the pl
+  // arena would free the heat-maps) and ONLY the post-processing runs again on the resident heat-maps -- it stops at its
+  // counting pass when the capacity does not suffice, so the first attempt cost the threshold + labelling kernels.  Crops and
+  // recogniser then run on all M crops whatever max_crops is; when the caller's buffers are too small the results stay in
+  // HBM, KOCR_ECAPACITY reports the true counts, and kocr_pipeline_results copies them into larger buffers: one detector
+  // forward, one recogniser pass, always.
   PPDeviceOut dv;
-  KOCR_TRY(postproc_get_boxes(ctx, d_heat, N, h2, w2, detection_threshold, text_threshold, link_threshold,
-                              size_threshold, d_boxes, cap, counts, nullptr, &dv));
-  KOCR_HIP(ctx, hipMemcpyAsync(boxes, d_boxes, box_b, hipMemcpyDeviceToHost, ctx->stream));
+  int d_cap = cap;
+  int rc_pp = postproc_get_boxes(ctx, d_heat, N, h2, w2, detection_threshold, text_threshold, link_threshold,
+                                 size_threshold, d_boxes, d_cap, counts, nullptr, &dv);
+  if (rc_pp == KOCR_ECAPACITY) {
+    int need = 0;
+    for (int k = 0; k < N; ++k) need = std::max(need, (int)counts[k]);
+    if (need <= d_cap) return rc_pp;  // the other capacity error (dilation canvases beyond 2^31 pixels): not a matter of cap
+    d_cap = need;
+    KOCR_TRY(arena_reserve(ctx, ctx->bx, (size_t)N * d_cap * 8 * sizeof(float) + 256));
+    ctx->bx.off = 0;
+    d_boxes = (float*)arena_alloc(ctx->bx, (size_t)N * d_cap * 8 * sizeof(float));
+    if (!d_boxes) KOCR_FAIL(ctx, KOCR_ENOMEM, "kocr_pipeline: box arena exhausted");
+    rc_pp = postproc_get_boxes(ctx, d_heat, N, h2, w2, detection_threshold, text_threshold, link_threshold, size_threshold,
+                               d_boxes, d_cap, counts, nullptr, &dv);
+  }
+  KOCR_TRY(rc_pp);
   long M = 0;
   for (int k = 0; k < N; ++k) M += counts[k];
   if (n_crops) *n_crops = (int32_t)M;
+  const bool host_fits = d_cap == cap && labels && M <= max_crops;
+  if (d_cap == cap) KOCR_HIP(ctx, hipMemcpyAsync(boxes, d_boxes, box_b, hipMemcpyDeviceToHost, ctx->stream));
   int host_flags[5] = {0, 0, 0, 0, 0};  // totals[0..3] of the post-processing, warp status
   auto finish = [&]() -> int {
     KOCR_HIP(ctx, hipMemcpyAsync(host_flags, dv.d_totals, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -221,7 +243,7 @@ extern "C" int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, c
     ctx->last_pl = {d_boxes, dv.d_counts, nullptr, N, cap, 0, true};
     return KOCR_OK;
   }
-  if (!labels || M > max_crops) {
+  if (!labels && d_cap == cap) {
     KOCR_TRY(finish());  // an empty contour list (the reference's IndexError) takes precedence over the capacity error
     KOCR_FAIL(ctx, KOCR_ECAPACITY, "kocr_pipeline: more crops than max_crops");
   }
@@ -234,7 +256,7 @@ extern "C" int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, c
   int32_t* d_lab = (int32_t*)arena_alloc(ctx->io, lab_b);
   int* d_status = (int*)arena_alloc(ctx->io, 256);
   KOCR_HIP(ctx, hipMemsetAsync(d_status, 0, sizeof(int), ctx->stream));
-  KOCR_TRY(launch_warp_prepare(ctx, d_boxes, dv.d_counts, N, cap, 31, 200, d_prm, d_status));
+  KOCR_TRY(launch_warp_prepare(ctx, d_boxes, dv.d_counts, N, d_cap, 31, 200, d_prm, d_status));
   KOCR_TRY(launch_warp(ctx, d_bat, Hmax, Wmax, d_prm, (int)M, 31, 200, d_crops));
   // ---- recogniser ----
   const int C = crnn_classes(ctx);
@@ -245,10 +267,33 @@ extern "C" int kocr_pipeline(kocr_ctx* ctx, int N, const uint8_t* const* imgs, c
     ctx->ws_reset();
     KOCR_TRY(crnn_forward(ctx, d_crops + (size_t)s * 31 * 200, nb, d_lab + (size_t)s * crnn_label_width(ctx), nullptr));
   }
-  KOCR_HIP(ctx, hipMemcpyAsync(labels, d_lab, lab_b, hipMemcpyDeviceToHost, ctx->stream));
+  if (host_fits) KOCR_HIP(ctx, hipMemcpyAsync(labels, d_lab, lab_b, hipMemcpyDeviceToHost, ctx->stream));
   KOCR_HIP(ctx, hipMemcpyAsync(&host_flags[4], d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   KOCR_TRY(finish());
-  ctx->last_pl = {d_boxes, dv.d_counts, d_lab, N, cap, (int)M, true};
+  ctx->last_pl = {d_boxes, dv.d_counts, d_lab, N, d_cap, (int)M, true};
+  if (!host_fits) {
+    ctx->set_err("kocr_pipeline: an image has more boxes than cap, or there are more crops than max_crops; the results are "
+                 "resident -- fetch them with kocr_pipeline_results into buffers sized from counts / n_crops");
+    return KOCR_ECAPACITY;
+  }
+  return KOCR_OK;
+}
+
+// The resident results of the last kocr_pipeline call copied into the caller's (larger) buffers: see include/kocr.h
+extern "C" int kocr_pipeline_results(kocr_ctx* ctx, float* boxes, int cap, int32_t* labels, int max_crops) {
+  if (!ctx) return KOCR_EINVAL;
+  const auto& r = ctx->last_pl;
+  if (!r.valid) KOCR_FAIL(ctx, KOCR_EINVAL, "kocr_pipeline_results: no kocr_pipeline result is resident (call it right after kocr_pipeline)");
+  if (!boxes || cap < r.cap || (r.M > 0 && (!labels || max_crops < r.M)))
+    KOCR_FAIL(ctx, KOCR_ECAPACITY, "kocr_pipeline_results: buffers smaller than the resident results (cap >= " + std::to_string(r.cap) +
+                                       ", max_crops >= " + std::to_string(r.M) + ")");
+  KOCR_HIP(ctx, hipSetDevice(ctx->device));
+  // device rows are r.cap boxes apart, the caller's cap boxes
+  KOCR_HIP(ctx, hipMemcpy2DAsync(boxes, (size_t)cap * 32, r.d_boxes, (size_t)r.cap * 32, (size_t)r.cap * 32, (size_t)r.N,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+  if (r.M > 0)
+    KOCR_HIP(ctx, hipMemcpyAsync(labels, r.d_labels, (size_t)r.M * crnn_label_width(ctx) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  KOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return KOCR_OK;
 }
 

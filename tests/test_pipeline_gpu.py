@@ -334,3 +334,31 @@ def test_float_images_take_the_float_path(pipe, ctx):
     boxes = [np.asarray([b for _, b in want], np.float32)]
     texts = pipe.recognizer.recognize_from_boxes([page.astype(np.float32)], boxes)
     assert len(texts) == 1 and len(texts[0]) == len(want)
+
+
+@pytest.mark.parametrize("cap,max_crops", [(2, None), (256, 3), (2, 3)], ids=["more_boxes_than_cap", "more_crops_than_max_crops", "both"])
+def test_capacity_overflow_costs_no_second_detector_forward(pipe, ctx, cap, max_crops):
+    """the reference has no cap (detection.py:230-286).  A page with more boxes than the caller's `cap`, or a
+    batch with more crops than `max_crops`, must not run CRAFT twice: kocr_pipeline repeats only the post-processing on the
+    resident heat-maps (larger device box buffer), recognises all crops and leaves the results in HBM; kocr_pipeline_results
+    copies them into buffers of the right size.  Asserted on the profiler rows: ONE first-layer launch, ONE LSTM layer pair."""
+    pages = np.stack([synth.text_page(96, 128, 5, seed=70 + i) for i in range(3)])
+    hs, ws = [96] * 3, [128] * 3
+    want_boxes, want_labels = ctx.pipeline(list(pages), hs, ws, [192] * 3, [256] * 3, 192, 256)
+    n_boxes = [len(b) for b in want_boxes]
+    assert max(n_boxes) > 2 and sum(n_boxes) > 3, n_boxes        # the small capacities below really overflow
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    try:
+        got_boxes, got_labels = ctx.pipeline(list(pages), hs, ws, [192] * 3, [256] * 3, 192, 256, cap=cap, max_crops=max_crops)
+        rep = ctx.profile_report()
+    finally:
+        ctx.profile_enable(False)
+    assert [len(b) for b in got_boxes] == n_boxes
+    assert all(np.array_equal(a, b) for a, b in zip(got_boxes, want_boxes)) and np.array_equal(got_labels, want_labels)
+    first = [v for k, v in rep.items() if k.startswith("conv_hs_first") or k.startswith("conv_first")]
+    assert first and sum(v["launches"] for v in first) == 1, {k: v["launches"] for k, v in rep.items()}   # ONE detector forward
+    assert rep["lstm_recurrence"]["launches"] == 2                                                         # ONE recogniser pass
+    # the results are still resident: a second fetch into even larger buffers gives the same answer
+    res = ctx.pipeline_device_results()
+    assert res["n"] == 3 and res["m"] == sum(n_boxes) and res["cap"] >= max(n_boxes)

@@ -3,6 +3,8 @@
 #include "common.h"
 #include <cmath>
 #include <algorithm>
+#include <mutex>
+#include <set>
 
 // ---------------------------------------------------------------------------------------
 // ctx internals
@@ -61,6 +63,22 @@ int kocr_ctx::dev_alloc(void** out, size_t bytes) {
   owned.push_back(p);
   *out = p;
   return KOCR_OK;
+}
+
+void kocr_note_dispatch(const char* family, const ConvLayer& L, const Tensor& in) {
+  static const char* path = getenv("KOCR_DISPATCH_LOG");
+  if (!path) return;
+  static std::mutex mu;
+  static std::set<std::string> seen;
+  char line[256];
+  snprintf(line, sizeof line, "%-14s %-28s N %d H %d W %d Cin %d Cout %d k %dx%d dil %d%s", family, L.name.c_str(), in.N, in.H, in.W, L.Cin,
+           L.Cout, L.KH, L.KW, L.dil, in.cellW ? " cells" : "");
+  std::lock_guard<std::mutex> g(mu);
+  if (!seen.insert(line).second) return;
+  if (FILE* f = fopen(path, "a")) {
+    fprintf(f, "%s\n", line);
+    fclose(f);
+  }
 }
 
 void kocr_ctx::release(void* p) {

@@ -84,8 +84,6 @@ struct ConvLayer {
   float* d_post_b = nullptr;
   int relu = 0;
   float* d_w_rgb4 = nullptr;  // first layer on raw uint8: [9 taps][R,G,B,0][Cout_pad] (48 rows)
-  float* d_wino = nullptr;    // Winograd F(2,3) weights U[Cin/16][3][4][16][wino_cout_pad] (3x3, dil 1, Cin%16==0)
-  int wino_cout_pad = 0;
   unsigned short* d_ws = nullptr;  // Winograd F(2,3) weights, 3-way bf16 split, conv_wsplit.hip order (Cout > 32)
   int ws_cout_pad = 0;
   unsigned short* d_w4 = nullptr;  // Winograd F(4,3) weights, 3-way bf16 split, conv_w43.hip order (Cout > 64, Cin % 32 == 0)
@@ -279,15 +277,13 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
                  int KH, int KW, int dil, const float* pre_a, const float* pre_b, int relu,
                  const float* post_a, const float* post_b);
 // in_u8 != nullptr: first-layer mode, raw RGB bytes + LUT normalisation.
+// developer instrumentation (KOCR_DISPATCH_LOG=<file>): one line per distinct (kernel family, layer, input shape) the dispatcher
+// of launch_conv_pool chose in this process -- the table of DESIGN.md section 3 "which shapes reach which family" comes from it
+void kocr_note_dispatch(const char* family, const ConvLayer& L, const Tensor& in);
 int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8,
                 const float* lut, const Tensor& out);
 int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8,
                      const float* lut, const Tensor& out, const Tensor* pool, bool need_full = true);
-// conv_wino.hip
-int prepare_wino(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw);
-bool wino_applicable(const ConvLayer& L, const Tensor& in);
-int launch_conv_wino(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const Tensor& out, const Tensor* pool,
-                     bool need_full);
 // Split arithmetic of conv_wsplit.hip / conv_dsplit.hip: 0 = bf16 x 3 pieces / 6 products (exact split),
 // 1 = fp16 x 2 pieces / 3 products (RNE split at 2^-24, exact power-of-two scaling from Tensor::amax).
 // kocr_ctx::split_mode; KOCR_SPLIT=bf16|f16 sets the initial value, kocr_set_split_mode changes it.

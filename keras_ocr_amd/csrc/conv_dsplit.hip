@@ -701,10 +701,9 @@ int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout + (up ? (double)up->pixels() * L.Cout : 0.0));
   ProfScope ps(ctx, nm, flops, bytes);
-  // whole 128-byte lines per fetch (PAIR): 1x1 convolutions over an even number of channel groups.  KOCR_DS_LINES=0: round 5's
-  // one K-step per fetch (A/B, profiles/r06_ab_notes.txt item 3)
-  static const bool lines_on = !(getenv("KOCR_DS_LINES") && atoi(getenv("KOCR_DS_LINES")) == 0);
-  const bool line_pairs = lines_on && L.KH == 1 && L.KW == 1 && (L.Cin / 16) % 2 == 0 && in.cs % 32 == 0 && in.co % 32 == 0;
+  // whole 128-byte lines per fetch (PAIR): 1x1 convolutions over an even number of channel groups (A/B against round 5's one
+  // K-step per fetch: profiles/r06_ab_notes.txt item 3)
+  const bool line_pairs = L.KH == 1 && L.KW == 1 && (L.Cin / 16) % 2 == 0 && in.cs % 32 == 0 && in.co % 32 == 0;
   if (up) {
     // exactly 2x up-sampling with W % 4 == 0: the shared-tap epilogue (UP = 2)
     const bool no_up2 = !ctx->sw.up2x;

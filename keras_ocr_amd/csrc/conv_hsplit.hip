@@ -734,7 +734,7 @@ int prepare_hsplit(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw) 
 bool hsplit_applicable(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in) {
   static const bool off = getenv("KOCR_HSPLIT") && atoi(getenv("KOCR_HSPLIT")) == 0;
   return !off && L.d_hs && in.cs % 4 == 0 && in.co % 4 == 0 &&
-         ((uintptr_t)in.p & 15) == 0 && in.pixels() >= 4096 && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31) &&
+         ((uintptr_t)in.p & 15) == 0 && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31) &&
          (size_t)in.H * in.W * 32 * 4 < ((size_t)1 << 31);
 }
 

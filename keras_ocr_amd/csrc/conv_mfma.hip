@@ -24,8 +24,8 @@
 //
 // Measured on MI355X (profiles/): 125 TFLOP/s = 79 % of the 157.3 TF fp32 MFMA peak on the
 // 128x128 instances inside the pipeline, matrix pipe busy 80 % at 2.38 GHz, 3.8 waves/SIMD.
-// KOCR_CONV_VARIANT selects developer A/B variants (distance-2 prefetch, 8-wave 256x128 tile,
-// ablations); the default is variant 0.
+// (Round 1's developer A/B variants -- KOCR_CONV_VARIANT: fragment prefetch, 8-wave tiles, ablations; KOCR_CONV_STAGGER --
+// were removed in round 6: since round 2 this kernel is the fp32 fallback for narrow / odd layers only.)
 #include "common.h"
 #include <cmath>
 #include <type_traits>
@@ -475,7 +475,7 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
   // are released here, after the stream has drained (kept until the context died, every kocr_load_* on a live
   // context leaked the whole previous weight set -- fp32 plus every split / transformed copy).
   {
-    void* old[] = {L.d_w, L.d_pre_a, L.d_pre_b, L.d_post_a, L.d_post_b, L.d_w_rgb4, L.d_wino, L.d_pre_a_h, L.d_ws, L.d_w4,
+    void* old[] = {L.d_w, L.d_pre_a, L.d_pre_b, L.d_post_a, L.d_post_b, L.d_w_rgb4, L.d_pre_a_h, L.d_ws, L.d_w4,
                    L.d_w4h, L.d_ds, L.d_first, L.d_hs, L.d_hs16, L.d_hsh, L.d_k5};
     bool any = false;
     for (void* q : old) any = any || q != nullptr;
@@ -484,7 +484,7 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
       for (void* q : old) ctx->release(q);
     }
   }
-  L.d_w = L.d_pre_a = L.d_pre_b = L.d_post_a = L.d_post_b = L.d_w_rgb4 = L.d_wino = L.d_pre_a_h = nullptr;
+  L.d_w = L.d_pre_a = L.d_pre_b = L.d_post_a = L.d_post_b = L.d_w_rgb4 = L.d_pre_a_h = nullptr;
   L.d_ws = L.d_w4 = L.d_w4h = L.d_ds = L.d_first = L.d_hs = L.d_hs16 = L.d_hsh = L.d_k5 = nullptr;
   L.hs_wexp.clear();
   L.first_bound = 0.f;
@@ -511,7 +511,6 @@ int prepare_conv(kocr_ctx* ctx, ConvLayer& L, const float* w, bool w_is_oihw, in
           wp[row * L.Cout_pad + o] = v;
         }
   KOCR_TRY(ctx->upload(&L.d_w, wp));
-  KOCR_TRY(prepare_wino(ctx, L, w, w_is_oihw));
   KOCR_TRY(prepare_wsplit(ctx, L, w, w_is_oihw));
   KOCR_TRY(prepare_w43(ctx, L, w, w_is_oihw));
   KOCR_TRY(prepare_w43h(ctx, L, w, w_is_oihw, pre_a));
@@ -582,31 +581,8 @@ static void dispatch_mode(int mode, dim3 grid, hipStream_t s, const ConvParams& 
     hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, 2, BK, PF>), grid, dim3(64 * WM * WN), 0, s, p);
 }
 
-// developer A/B switch (KOCR_CONV_VARIANT): 0 = BK16, 1 = BK16 + fragment prefetch,
-// 2 = BK32, 3 = BK32 + fragment prefetch
-static int conv_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("KOCR_CONV_VARIANT");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
-
-template <int BM, int BN, int WM, int WN>
-static void dispatch_variant(int variant, int mode, dim3 grid, hipStream_t s, const ConvParams& p) {
-  switch (variant) {
-    case 1: dispatch_mode<BM, BN, WM, WN, 16, 1>(mode, grid, s, p); break;
-    case 4: dispatch_mode<BM, BN, WM, WN, 16, 2>(mode, grid, s, p); break;  // ablation: no global loads
-    case 5: dispatch_mode<BM, BN, WM, WN, 16, 3>(mode, grid, s, p); break;  // ablation: MFMA + LDS reads only
-    case 6: dispatch_mode<BM, BN, WM, WN, 16, 4>(mode, grid, s, p); break;  // ablation: no LDS stores
-    case 7: dispatch_mode<BM, BN, WM, WN, 16, 5>(mode, grid, s, p); break;  // ablation: no barrier
-    default: dispatch_mode<BM, BN, WM, WN, 16, 0>(mode, grid, s, p); break;
-  }
-}
 
 // BK=32 in vector mode needs Cin % 32 == 0
-static bool mode_needs_bk16(const ConvLayer& L, const Tensor&) { return L.Cin % 32 != 0 && L.Cin % 16 == 0; }
 
 int launch_conv(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const uint8_t* in_u8,
                 const float* lut, const Tensor& out) {
@@ -653,20 +629,13 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
   p.relu = L.relu;
   p.Mtotal = (int)M;
   p.Kreal = L.Kreal;
-  int variant = conv_variant();
-  if (variant >= 8) variant = 0;
-  if (mode_needs_bk16(L, in) && variant < 4) variant &= 1;
-  if (variant == 2 || variant == 3) variant = 0;  // BK=32 retired: the K order is built on 16-channel groups
   const int bk = 16;
   p.nchunks = (L.Kreal + bk - 1) / bk;  // weight rows are zero padded up to Kpad (multiple of 32)
   p.pool_out = nullptr;
   p.tap_inner = L.tap_inner ? 1 : 0;
   p.amax_out = p.amax_pool = nullptr;  // per-image slots (Tensor::amax) are filled by a reduction pass after the launch
   p.ntaps = L.KH * L.KW;
-  {
-    static const int stg = getenv("KOCR_CONV_STAGGER") ? atoi(getenv("KOCR_CONV_STAGGER")) : 0;
-    p.stagger = stg;
-  }
+  p.stagger = 0;
   p.pool_cs = p.pool_co = p.write_full = p.tiles_per_row = 0;
   int mode;
   if (in_u8) {
@@ -679,42 +648,48 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
     mode = 0;
   else
     mode = 1;
-  const bool fuse_pool = pool && mode == 0 && variant == 0 && L.BN >= 64 && (in.H % 2 == 0) && (in.W % 64 == 0) &&
-                         conv_variant() != 10;
+  const bool fuse_pool = pool && mode == 0 && L.BN >= 64 && (in.H % 2 == 0) && (in.W % 64 == 0);
   // Layouts with zero padding that belongs to the tensor (cell grids, Tensor::cellW; width-padded rows, Tensor::Wv) are
   // read and WRITTEN correctly by the fp16 F(4,3) kernels only: anything else fails here instead of silently writing
   // convolution values into the padding
   if (in.cellW || out.cellW || (pool && pool->cellW)) {
-    if (in_u8 || variant != 0 || conv_variant() != 0 || !w43_applicable(ctx, L, in))
+    if (in_u8 || !w43_applicable(ctx, L, in))
       KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": a cell-grid tensor needs the fp16 vertical-reuse F(4,3) kernel (disabled by a switch or the arithmetic mode)");
     return launch_conv_w43(ctx, L, in, out, pool, need_full);
   }
-  if (out.Wv && out.Wv < out.W && (in_u8 || variant != 0 || conv_variant() != 0 || !w43_applicable(ctx, L, in) || !w43_flat_h_ok(ctx, L)))
+  if (out.Wv && out.Wv < out.W && (in_u8 || !w43_applicable(ctx, L, in) || !w43_flat_h_ok(ctx, L)))
     KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": a width-padded output (Tensor::Wv) needs the flattened fp16 F(4,3) kernel (disabled by a switch or the arithmetic mode)");
   if (!out.p) KOCR_FAIL(ctx, KOCR_EINVAL, "conv " + L.name + ": no output buffer");
-  if (in_u8 && lut && conv_variant() == 0 && first_applicable(ctx, L, in)) {  // first layer from raw uint8 on the split path
+  if (in_u8 && lut && first_applicable(ctx, L, in)) {  // first layer from raw uint8 on the split path
+    kocr_note_dispatch("first", L, in);
     KOCR_TRY(launch_conv_first(ctx, L, in, in_u8, lut, out));  // maintains out.amax itself
     return pool ? launch_maxpool2x2(ctx, out, *pool) : KOCR_OK;
   }
-  if (!in_u8 && !pool && variant == 0 && conv_variant() == 0 && k5_applicable(ctx, L, in, out))  // 5x5, 16 couts, small images
+  if (!in_u8 && !pool && k5_applicable(ctx, L, in, out)) {  // 5x5, 16 couts, small images
+    kocr_note_dispatch("k5", L, in);
     return launch_conv_k5(ctx, L, in, out);
+  }
   // bf16x3-split Winograd on the bf16 matrix cores (fp32-class accuracy, see conv_wsplit.hip)
-  if (!in_u8 && variant == 0 && conv_variant() == 0 && w43_applicable(ctx, L, in))
+  if (!in_u8 && w43_applicable(ctx, L, in)) {
     return launch_conv_w43(ctx, L, in, out, pool, need_full);
-  if (!in_u8 && variant == 0 && conv_variant() == 0 && wsplit_applicable(L, in))
+  }
+  if (!in_u8 && wsplit_applicable(L, in)) {
+    kocr_note_dispatch("wsplit", L, in);
     return launch_conv_wsplit(ctx, L, in, out, pool, need_full);
-  if (!in_u8 && variant == 0 && conv_variant() == 0 && dsplit_applicable(L, in)) {
+  }
+  if (!in_u8 && dsplit_applicable(L, in)) {
+    kocr_note_dispatch("dsplit", L, in);
     KOCR_TRY(launch_conv_dsplit(ctx, L, in, out));
     return pool ? launch_maxpool2x2(ctx, out, *pool) : KOCR_OK;
   }
-  if (!in_u8 && variant == 0 && conv_variant() == 0 && hsplit_applicable(ctx, L, in)) {  // few couts: split once into LDS
+  if (!in_u8 && hsplit_applicable(ctx, L, in)) {  // few couts: split once into LDS
+    kocr_note_dispatch("hsplit", L, in);
     KOCR_TRY(launch_conv_hsplit(ctx, L, in, out));
     return pool ? launch_maxpool2x2(ctx, out, *pool) : KOCR_OK;
   }
-  const bool wino = !in_u8 && variant == 0 && conv_variant() == 0 && wino_applicable(L, in);
-  if (wino) {  // 1-D Winograd F(2,3): 2/3 of the MFMA work; pooling (if any) as a separate pass
-    return launch_conv_wino(ctx, L, in, out, pool, need_full);
-  }
+  // (round 1's fp32 Winograd F(2,3) kernel, conv_wino.hip, stood here: by round 5 only <= 32-cout layers on images of fewer
+  //  than 4096 pixels still reached it -- they take conv_hs_kernel now, everything else the fp32 MFMA kernel below.  Removed
+  //  in round 6; profiles/r06_dispatch.txt)
   if (pool && !fuse_pool) {  // unfused: conv to full resolution, then the pooling kernel
     KOCR_TRY(launch_conv_pool(ctx, L, in, in_u8, lut, out, nullptr));
     return launch_maxpool2x2(ctx, out, *pool);
@@ -728,11 +703,11 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
     p.write_full = need_full ? 1 : 0;
     p.tiles_per_row = in.W / 64;
   }
+  kocr_note_dispatch("mfma", L, in);
   const double flops = 2.0 * (double)M * L.Kreal * L.Cout;
   const double bytes = 4.0 * ((double)M * L.Cin + (double)M * L.Cout + (double)L.Kreal * L.Cout);
   char nm[64];
-  const bool big = (conv_variant() == 8) && L.BN == 128 && mode == 0 && M >= 256 * 1024;
-  const int BM = ((L.BN == 128 && !big) || (L.BN == 64 && conv_variant() != 9) || (L.BN == 32 && conv_variant() != 12)) ? 128 : 256;
+  const int BM = 128;
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;  // developer: one row per layer
   if (per_layer)
     snprintf(nm, sizeof nm, "conv_%dx%d_m%d%s:%s", BM, L.BN, mode, fuse_pool ? "p" : "", L.name.c_str());
@@ -747,18 +722,12 @@ int launch_conv_pool(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const 
       hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 2, 2, 0, 16, 0, 1>), grid, dim3(256), 0, ctx->stream, p);
     else
       hipLaunchKernelGGL((conv_mfma_kernel<128, 64, 2, 2, 0, 16, 0, 1>), grid, dim3(256), 0, ctx->stream, p);
-  } else if (big)
-    dispatch_mode<256, 128, 4, 2, 16, 0>(mode, grid, ctx->stream, p);
-  else if (L.BN == 128)
-    dispatch_variant<128, 128, 2, 2>(variant, mode, grid, ctx->stream, p);
-  else if (L.BN == 64 && conv_variant() != 9)
-    dispatch_mode<128, 64, 2, 2, 16, 0>(mode, grid, ctx->stream, p);
+  } else if (L.BN == 128)
+    dispatch_mode<128, 128, 2, 2, 16, 0>(mode, grid, ctx->stream, p);
   else if (L.BN == 64)
-    dispatch_variant<256, 64, 4, 1>(variant, mode, grid, ctx->stream, p);
-  else if (conv_variant() != 12)
-    dispatch_mode<128, 32, 4, 1, 16, 0>(mode, grid, ctx->stream, p);
+    dispatch_mode<128, 64, 2, 2, 16, 0>(mode, grid, ctx->stream, p);
   else
-    dispatch_variant<256, 32, 4, 1>(variant, mode, grid, ctx->stream, p);
+    dispatch_mode<128, 32, 4, 1, 16, 0>(mode, grid, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   }
   if (out.amax && (!fuse_pool || need_full)) KOCR_TRY(launch_absmax(ctx, out, out.amax));

@@ -1845,10 +1845,9 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   const bool narrow = L.w4_cout_pad == 64;  // 64-cout arrangement: 4 M-tiles x 64 couts per tile
   // ... or, when the image tiles as 2 rows x 128 columns, the row-reuse arrangement (2 M-tiles of 2 rows x 64 columns)
   static const bool no_rr = getenv("KOCR_W43R") && atoi(getenv("KOCR_W43R")) == 0;
-  static const int geo_env = getenv("KOCR_W43V_GEO") ? atoi(getenv("KOCR_W43V_GEO")) : -1;  // developer switch: force a geometry
   const bool r_ok = narrow && !no_rr && L.dil == 1 && (!pool || exact_fuse) && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31);
   const bool rgeo1_ok = r_ok && in.H % 4 == 0 && in.W % 64 == 0, rgeo0_ok = r_ok && in.H % 2 == 0 && in.W % 128 == 0;
-  int rgeo = (rgeo1_ok && geo_env != 0) ? 1 : (rgeo0_ok && geo_env != 1) ? 0 : rgeo1_ok ? 1 : -1;
+  int rgeo = rgeo1_ok ? 1 : rgeo0_ok ? 0 : -1;  // 4 x 64 tiles where the image tiles that way, else 2 x 128
   // mode of the fp16 kernels: 0 = the image tiles exactly, 1 = ragged (masked gather / stores), 2 = cell grid
   int mode = cells ? 2 : 0;
   if (rgeo < 0 && narrow && rag_geo == 1) {
@@ -1859,14 +1858,13 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   // Cout > 64 on the same image geometry: the vertical-reuse arrangement (conv_w43v_kernel)
   static const bool no_v = getenv("KOCR_W43V") && atoi(getenv("KOCR_W43V")) == 0;
   // geometries of conv_w43v_kernel: GEO 1 = 4 rows x 64 columns (H % 4 == 0, W % 64 == 0), GEO 2 = 8 rows x 32 columns
-  // (H % 8 == 0, W % 32 == 0, no fused pooling).  KOCR_W43V_GEO=2 forces GEO 2 where both apply (developer switch; the
-  // same variable = 0 / 1 picks the row-reuse kernel's 2 x 128 / 4 x 64 geometry above where both apply)
+  // (H % 8 == 0, W % 32 == 0, no fused pooling)
   const bool v_ok = !narrow && !no_v && L.dil == 1 && (!pool || exact_fuse) && (size_t)in.H * in.W * in.cs * 4 < ((size_t)1 << 31);
   // 4 rows x 64 columns where the image tiles that way, else 8 rows x 32 columns (the 96-wide layers); anything else (e.g.
   // H % 4 != 0) stays on conv_w43_kernel
   const bool geo1_ok = v_ok && in.H % 4 == 0 && in.W % 64 == 0;
   const bool geo2_ok = v_ok && !pool && in.H % 8 == 0 && in.W % 32 == 0;
-  int vgeo = geo_env == 2 ? (geo2_ok ? 2 : -1) : geo1_ok ? 1 : geo2_ok ? 2 : -1;
+  int vgeo = geo1_ok ? 1 : geo2_ok ? 2 : -1;
   if (cells) vgeo = in.cellW >= 64 ? 1 : 2;
   if (vgeo < 0 && !narrow && rag_geo > 0) {
     vgeo = rag_geo;
@@ -1947,14 +1945,19 @@ int launch_conv_w43(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, const T
   // Tile order.  The split weights of one cout block are Cin * 3 * 128 * 36 B; with every cout block of a deep layer in
   // flight on an XCD they overflow its 4 MB L2 and are re-streamed from the Infinity Cache by every round of tiles.
   // Pixel-tile-fastest order keeps ONE cout block per XCD at a time (measured +4 % on 512 -> 512, neutral below).
-  static const int mfast = getenv("KOCR_W43_MFAST") ? atoi(getenv("KOCR_W43_MFAST")) : -1;
-  p.m_fastest = mfast >= 0 ? mfast : ((size_t)L.Cin * L.w4_cout_pad * 3 * 36 > ((size_t)6 << 20) ? 1 : 0);
+  p.m_fastest = (size_t)L.Cin * L.w4_cout_pad * 3 * 36 > ((size_t)6 << 20) ? 1 : 0;
   static const bool per_layer = getenv("KOCR_PROF_LAYERS") != nullptr;
   char nm[64];
   if (per_layer)
     snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s%s:%s", use_h ? ((pieces == 2 || mode) ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : (flat_h ? "f" : use_h ? "r" : "s"), rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "p" : (L.dil != 1 ? "d" : ""), mode == 1 ? "g" : mode == 2 ? "c" : "", L.name.c_str());
   else
     snprintf(nm, sizeof nm, "conv_w4%s%s_%s%s%s", use_h ? ((pieces == 2 || mode) ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : (flat_h ? "f" : use_h ? "r" : "s"), rowreuse ? "256x64" : narrow ? "512x64" : "256x128", fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""), mode == 1 ? "_rag" : mode == 2 ? "_cells" : "");
+  {
+    char fam[48];
+    snprintf(fam, sizeof fam, "w4%s%s%s%s", use_h ? ((pieces == 2 || mode) ? "h" : "q") : "", vreuse ? (vgeo == 2 ? "t" : "v") : (flat_h ? "f" : use_h ? "r" : "s"),
+             fuse ? "_pool" : (L.dil != 1 ? "_dil" : ""), mode == 1 ? "_rag" : mode == 2 ? "_cells" : "");
+    kocr_note_dispatch(fam, L, in);
+  }
   // algorithmic (direct-convolution) FLOPs and bytes: of the crops' own pixels in a cell grid, not of the gutters
   const double Malg = cells ? (double)in.N * in.cells() * (in.H - 1) * in.cellWv : (double)M;
   const double flops = 2.0 * Malg * L.Kreal * L.Cout;

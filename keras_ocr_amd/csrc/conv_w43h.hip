@@ -1711,9 +1711,8 @@ static int w4rh_launch(kocr_ctx* ctx, W4Params& p) {
 // conv_w43r_kernel<POOL, 1>, with wgt = d_w4h, pre_a = d_pre_a_h and amax_in set
 int launch_w43rh(kocr_ctx* ctx, W4Params& p, bool fuse, int pieces, int mode) {
   // PF = 2 (two channel groups of raw pixels in flight, weights a whole channel group ahead) needs the loads of a tile to
-  // reach into the NEXT tile only: Cin >= 64.  KOCR_W43R_PF=1: round 5's one-group prefetch (A/B, profiles/r06_ab_notes.txt)
-  static const bool pf2 = !(getenv("KOCR_W43R_PF") && atoi(getenv("KOCR_W43R_PF")) == 1);
-  if (pieces == 2 && pf2 && p.Cin >= 64) {
+  // reach into the NEXT tile only: Cin >= 64 (A/B against round 5's one-group prefetch: profiles/r06_ab_notes.txt item 1)
+  if (pieces == 2 && p.Cin >= 64) {
     if (mode == 1) return fuse ? w4rh_launch<1, 2, 1, 2>(ctx, p) : w4rh_launch<0, 2, 1, 2>(ctx, p);
     return fuse ? w4rh_launch<1, 2, 0, 2>(ctx, p) : w4rh_launch<0, 2, 0, 2>(ctx, p);
   }

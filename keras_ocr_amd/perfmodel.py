@@ -19,7 +19,6 @@ _FAMILIES = [
     ("conv_hs_256x16", "bf16", 6.0 * 10.0 / 9.0, "6 bf16x3 split products x 10/9 (3x3 taps issued in 5 pairs; <= 16 output channels)"),
     ("conv_hs", "bf16", 6.0, "6 bf16x3 split products (direct 3x3 convolution, <= 32 output channels)"),
     ("conv_k5", "bf16", 6.0 * 26.0 / 25.0, "6 bf16x3 split products x 26/25 (5x5 taps issued in 13 pairs; 16 output channels, small images)"),
-    ("conv_wino", "fp32", 2.0 / 3.0, "2/3 (Winograd F(2,3) on the fp32 MFMA)"),
 ]
 
 

@@ -191,3 +191,127 @@ def get_boxes(y_pred, detection_threshold=0.7, text_threshold=0.4, link_threshol
     if return_debug:
         return box_groups, debug
     return box_groups
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cv2.minAreaRect + cv2.boxPoints in OpenCV's OWN float32 arithmetic (round 6).  [3P], parity unpinned:
+# OpenCV is not installed here and its sources are not under /root/reference; this restates the published algorithm of
+# modules/imgproc/src/rotcalipers.cpp (`rotatingCalipers`, mode CALIPERS_MINAREARECT, and `cv::minAreaRect`) and of
+# `RotatedRect::points` (modules/core/src/types.cpp), OpenCV 4.x, operation by operation in float32 where OpenCV computes in
+# float and in float64 where it computes in double.  It exists to QUANTIFY what min_area_box's exact arithmetic hides: the
+# corner deviation of cv2's float32 geometry and how often `int()` in tools.get_rotated_width_height (tools.py:49-57) turns
+# it into a crop of a different size (scripts/minarearect_deviation.py -> DESIGN.md section 4).  tests/golden/make_golden_real.py
+# is the pin: on a host with cv2 its getBoxes fixture decides between the two.
+# ---------------------------------------------------------------------------------------------------------------------
+def min_area_box_cv32(hull):
+    """hull: the strict convex hull as integer (x, y) vertices in the order ``cv2.convexHull(points, clockwise=False)``
+    lists them for ``minAreaRect`` -- ``convex_hull_rows`` order reversed is passed by ``get_boxes_cv32``.  Returns the four
+    ``boxPoints`` corners (float32)."""
+    f32 = np.float32
+    n = len(hull)
+    pts = np.asarray(hull, dtype=np.float32).reshape(n, 2)
+    if n == 1:
+        return np.repeat(pts, 4, 0)
+    if n == 2:
+        # cv::minAreaRect, n == 2: centre = midpoint, width = |p1 - p0|, height 0, angle = atan2(dy, dx)
+        cx, cy = (pts[0, 0] + pts[1, 0]) * f32(0.5), (pts[0, 1] + pts[1, 1]) * f32(0.5)
+        dx, dy = np.float64(pts[1, 0] - pts[0, 0]), np.float64(pts[1, 1] - pts[0, 1])
+        width, height = f32(math.sqrt(dx * dx + dy * dy)), f32(0)
+        angle = f32(math.atan2(dy, dx))
+    else:
+        vect = np.zeros((n, 2), np.float32)
+        inv_len = np.zeros(n, np.float32)
+        left = bottom = right = top = 0
+        left_x = right_x = pts[0, 0]
+        top_y = bottom_y = pts[0, 1]
+        pt0 = pts[0]
+        for i in range(n):
+            if pt0[0] < left_x:
+                left_x, left = pt0[0], i
+            if pt0[0] > right_x:
+                right_x, right = pt0[0], i
+            if pt0[1] > top_y:
+                top_y, top = pt0[1], i
+            if pt0[1] < bottom_y:
+                bottom_y, bottom = pt0[1], i
+            pt = pts[(i + 1) % n]
+            dx, dy = np.float64(pt[0]) - np.float64(pt0[0]), np.float64(pt[1]) - np.float64(pt0[1])  # double dx, dy
+            vect[i] = (f32(dx), f32(dy))
+            inv_len[i] = f32(1.0 / math.sqrt(dx * dx + dy * dy))
+            pt0 = pt
+        orientation = f32(0)
+        ax, ay = np.float64(vect[n - 1, 0]), np.float64(vect[n - 1, 1])
+        for i in range(n):
+            bx, by = np.float64(vect[i, 0]), np.float64(vect[i, 1])
+            convexity = ax * by - ay * bx
+            if convexity != 0:
+                orientation = f32(1) if convexity > 0 else f32(-1)
+                break
+            ax, ay = bx, by
+        assert orientation != 0
+        base_a, base_b = orientation, f32(0)
+        seq = [bottom, right, top, left]
+        minarea = f32(np.finfo(np.float32).max)
+        best = None
+        for _ in range(n):
+            dp = [base_a * vect[seq[0], 0] + base_b * vect[seq[0], 1],
+                  -base_b * vect[seq[1], 0] + base_a * vect[seq[1], 1],
+                  -base_a * vect[seq[2], 0] - base_b * vect[seq[2], 1],
+                  base_b * vect[seq[3], 0] - base_a * vect[seq[3], 1]]
+            maxcos = dp[0] * inv_len[seq[0]]
+            main = 0
+            for i in range(1, 4):
+                cosalpha = dp[i] * inv_len[seq[i]]
+                if cosalpha > maxcos:
+                    main, maxcos = i, cosalpha
+            pindex = seq[main]
+            lead_x, lead_y = vect[pindex, 0] * inv_len[pindex], vect[pindex, 1] * inv_len[pindex]
+            base_a, base_b = ((lead_x, lead_y), (lead_y, -lead_x), (-lead_x, -lead_y), (-lead_y, lead_x))[main]
+            seq[main] = (seq[main] + 1) % n
+            dx, dy = pts[seq[1], 0] - pts[seq[3], 0], pts[seq[1], 1] - pts[seq[3], 1]
+            width = dx * base_a + dy * base_b
+            dx, dy = pts[seq[2], 0] - pts[seq[0], 0], pts[seq[2], 1] - pts[seq[0], 1]
+            height = -dx * base_b + dy * base_a
+            area = width * height
+            if area <= minarea:
+                minarea = area
+                best = (seq[3], base_a, width, base_b, height, seq[0])
+        li, a1, width, b1, height, bi = best
+        a2, b2 = -b1, a1
+        c1 = a1 * pts[li, 0] + pts[li, 1] * b1
+        c2 = a2 * pts[bi, 0] + pts[bi, 1] * b2
+        idet = f32(1) / (a1 * b2 - a2 * b1)
+        px, py = (c1 * b2 - c2 * b1) * idet, (a1 * c2 - a2 * c1) * idet
+        o1x, o1y, o2x, o2y = a1 * width, b1 * width, a2 * height, b2 * height
+        cx, cy = px + (o1x + o2x) * f32(0.5), py + (o1y + o2y) * f32(0.5)
+        width = f32(math.sqrt(np.float64(o1x) * np.float64(o1x) + np.float64(o1y) * np.float64(o1y)))
+        height = f32(math.sqrt(np.float64(o2x) * np.float64(o2x) + np.float64(o2y) * np.float64(o2y)))
+        angle = f32(math.atan2(np.float64(o1y), np.float64(o1x)))
+    angle = f32(np.float64(angle) * 180 / math.pi)     # box.angle = (float)(box.angle*180/CV_PI)
+    # RotatedRect::points
+    ang = np.float64(angle) * math.pi / 180.0
+    b = f32(math.cos(ang)) * f32(0.5)
+    a = f32(math.sin(ang)) * f32(0.5)
+    p0 = (cx - a * height - b * width, cy + b * height - a * width)
+    p1 = (cx + a * height - b * width, cy - b * height - a * width)
+    p2 = (f32(2) * cx - p0[0], f32(2) * cy - p0[1])
+    p3 = (f32(2) * cx - p1[0], f32(2) * cy - p1[1])
+    return np.array([p0, p1, p2, p3], dtype=np.float32)
+
+
+def box_from_hull(hull, fx, fy, cv32=False):
+    """detection.py:273-285 on one component's hull: boxPoints(minAreaRect), the diamond rule, the roll, x 2."""
+    f32 = np.float32
+    # cv2.convexHull(points, clockwise=False) lists the hull in the opposite orientation of convex_hull_rows
+    box = min_area_box_cv32([hull[0]] + hull[1:][::-1]) if cv32 else min_area_box(hull)
+    dw, dh = box[0] - box[1], box[1] - box[2]
+    w_ = np.sqrt(dw[0] * dw[0] + dw[1] * dw[1])
+    h_ = np.sqrt(dh[0] * dh[0] + dh[1] * dh[1])
+    box_ratio = max(w_, h_) / (min(w_, h_) + f32(1e-5))
+    if abs(f32(1) - box_ratio) <= f32(0.1):
+        l, r = fx.min(), fx.max()
+        t, b = fy.min(), fy.max()
+        box = np.array([[l, t], [r, t], [r, b], [l, b]], dtype=np.float32)
+    else:
+        box = np.array(np.roll(box, 4 - box.sum(axis=1).argmin(), 0))
+    return f32(2) * box

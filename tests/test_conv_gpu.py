@@ -34,7 +34,7 @@ CASES = [
     (1, 50, 7, 512, 16, 5, 1),     # STN localisation conv (5x5)
     (4, 1, 1, 11200, 64, 1, 1),    # dense as 1x1 conv
     (1, 50, 1, 256, 37, 1, 1),     # fc_12 class (Cout = 37)
-    # W % 128 == 0, 3x3, Cin % 16 == 0: the 1-D Winograd F(2,3) kernel (conv_wino.hip)
+    # W % 128 == 0, 3x3, Cin % 16 == 0 (round 1's fp32 Winograd shape class; <= 32 couts now on conv_hs, the rest on F(4,3) / fp32 MFMA)
     (1, 8, 128, 16, 32, 3, 1),
     (2, 6, 256, 64, 64, 3, 1),
     (1, 5, 128, 128, 200, 3, 1),

@@ -6,16 +6,14 @@ cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/final_$1
 mkdir -p $OUT
-python $REPO/bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json
+python $REPO/bench.py --steps 10 --warmup 3 2> $OUT/bench.err | tail -1 > $OUT/bench.json
+cp $REPO/gpurun_out/bench_full.json $OUT/bench_full.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $REPO/bench.py --profile-all --no-live-traffic > $OUT/trace.log 2>&1
-grep '^{"metric"' $OUT/trace.log | tail -1 > $OUT/bench_under_rocprof.json
+grep '^\[bench full\] ' $OUT/trace.log | tail -1 | sed 's/^\[bench full\] //' > $OUT/bench_under_rocprof.json
 KOCR_PROF_LAYERS=1 python $REPO/scripts/perf_craft.py 8 1536 1536 5 > $OUT/craft_layers.txt 2>&1
 KOCR_PROF_LAYERS=1 python $REPO/scripts/perf_crnn.py 512 > $OUT/crnn_layers.txt 2>&1
-# round 5: the recogniser without the cell grid (round 4's dense crop batch), and the detector on a page size no level of which tiles
-KOCR_CELLS=0 KOCR_PROF_LAYERS=1 python $REPO/scripts/perf_crnn.py 512 > $OUT/crnn_layers_no_cells.txt 2>&1
+# the detector on a page size no level of which tiles
 KOCR_PROF_LAYERS=1 python $REPO/scripts/perf_craft.py 8 1500 2000 5 > $OUT/craft_layers_1500x2000.txt 2>&1
-KOCR_W43RAG=0 KOCR_PROF_LAYERS=1 python $REPO/scripts/perf_craft.py 8 1500 2000 3 > $OUT/craft_layers_1500x2000_no_ragged.txt 2>&1
-(cd $REPO && python -m pytest tests/test_range_gpu.py -q -m gpu -s 2>&1 | grep -E "lognormal|one_outlier|99pct|ordinary:|heavy_tailed:|passed|failed" > $OUT/range_stats.txt)
 CMD="python $REPO/scripts/perf_craft.py 8 1536 1536 1"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/p1 -o p1 -- $CMD > $OUT/p1.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/p2 -o p2 -- $CMD > $OUT/p2.log 2>&1
@@ -39,6 +37,13 @@ for sub in ("p1", "p4"):
             print(sub, k, {a: round(b / den, 3) for a, b in sorted(v.items())})
 PY
 rm -rf $OUT/p1 $OUT/p2 $OUT/p4
+# round 6: HBM traffic of every dispatch of one forward (FETCH_SIZE / WRITE_SIZE, separate passes, kernel-trace only)
+cd /tmp
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- $CMD > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- $CMD > $OUT/write.log 2>&1
+python $REPO/scripts/pmc_traffic_dispatch.py $OUT > $OUT/traffic_per_dispatch.txt 2>&1
+rm -rf $OUT/fetch $OUT/write $OUT/fetch.log $OUT/write.log
+cd $REPO
 find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/bench_kernel_stats.csv
 rm -rf $OUT/trace
 ls $OUT; head -c 600 $OUT/bench.json

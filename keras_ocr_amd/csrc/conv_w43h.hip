@@ -860,8 +860,13 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
   v2f raw1[PF][6];
 
   // ---- consumer state ------------------------------------------------------------------------------------------
-  const size_t w_step = (size_t)2 * 12 * 64 * 8;  // ushorts per (channel group, ky) step: two 32-cout tiles, 2 pieces
-  const unsigned short* w_ptr = p.wgt + ((size_t)wn * 12 * 64 + lane) * 8;
+  // weights through raw buffer loads (round 6, as conv_w43vh_kernel): one VGPR of lane offset, the (step, point, piece) offset a
+  // scalar -- the 64-bit address arithmetic of a plain pointer cost five VALU / SALU instructions and a 64-bit-address
+  // global_load issue per fragment pair of a kernel that is issue-bound
+  constexpr unsigned w_step = 2u * 12 * 64 * 16;  // BYTES per (channel group, ky) step: two 32-cout tiles, 2 pieces
+  const __amdgpu_buffer_rsrc_t wrsrc = w4_rsrc(reinterpret_cast<const float*>(p.wgt), 0x7FFFFFFFu);
+  const unsigned wlane = (unsigned)lane * 16u;
+  const unsigned w_wave = (unsigned)__builtin_amdgcn_readfirstlane(wn * 12 * 64 * 16 + 3 * ph * 2 * 64 * 16);  // cout tile, first point
   const int ns = 3 * ncg;
   hf8 bw[NBW][NP];
   f16v acc[3][2];  // [point of this wave's half][M-tile]
@@ -915,7 +920,9 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
       if (g < 8) {
         mfma_grp(cur, pp, PF == 2 ? g : pp);
         __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);  // the LDS fetches of the next group first
-        // VALU per MFMA gap: a full chunk is ~22 VALU, a half chunk ~10; the group's LDS stores before its last MFMA
+        // VALU per MFMA gap, in the scheduler's units (round 6: the ISA showed the five gaps of a group filled 7 / 7 / 0 / 0 / 0 --
+        // the counts below are taken before instruction expansion, ~ 1.4 machine instructions each -- so three of six MFMAs ran
+        // back to back with nothing to issue behind them); the group's LDS stores before its last MFMA
         auto ilv = [&](auto v_c, auto st_c) __attribute__((always_inline)) {
           constexpr int V = decltype(v_c)::value, ST = decltype(st_c)::value;
 #pragma unroll
@@ -928,14 +935,14 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
         const bool half = c0 >= 6;
         if (nchunks == 2) {
           if (half)
-            ilv(std::integral_constant<int, 20 / (2 * PR - 1) + 1>{}, std::integral_constant<int, 2 * NP>{});
+            ilv(std::integral_constant<int, PR == 3 ? 3 : 20>{}, std::integral_constant<int, 2 * NP>{});
           else
-            ilv(std::integral_constant<int, 44 / (2 * PR - 1) + 1>{}, std::integral_constant<int, 2 * NP>{});
+            ilv(std::integral_constant<int, PR == 3 ? 5 : 44>{}, std::integral_constant<int, 2 * NP>{});
         } else {
           if (half)
-            ilv(std::integral_constant<int, 10 / (2 * PR - 1) + 1>{}, std::integral_constant<int, NP>{});
+            ilv(std::integral_constant<int, PR == 3 ? 2 : 10>{}, std::integral_constant<int, NP>{});
           else
-            ilv(std::integral_constant<int, 22 / (2 * PR - 1) + 1>{}, std::integral_constant<int, NP>{});
+            ilv(std::integral_constant<int, PR == 3 ? 2 : 22>{}, std::integral_constant<int, NP>{});
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       } else {
@@ -948,10 +955,10 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
       {  // this point's weights of the next step (PF = 2: of the same step of the next channel group)
         int sn = PF == 2 ? s0 + 3 + ky : s0 + ky + 1;
         sn = sn >= ns ? sn - ns : sn;
-        const unsigned short* wq = w_ptr + (size_t)sn * w_step;
+        const unsigned wq = w_wave + (unsigned)sn * w_step;
 #pragma unroll
         for (int s = 0; s < NP; ++s)
-          bw[PF == 2 ? g : pp][s] = *reinterpret_cast<const hf8*>(wq + (size_t)((3 * ph + pp) * 2 + s) * 64 * 8);
+          bw[PF == 2 ? g : pp][s] = __builtin_bit_cast(hf8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (int)(wq + (unsigned)(pp * 2 + s) * 1024u), 0));
       }
       if (g == 3) load_item0(r0);
     }
@@ -970,7 +977,7 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
   for (int g = 0; g < NBW; ++g)
 #pragma unroll
     for (int s = 0; s < NP; ++s)
-      bw[g][s] = *reinterpret_cast<const hf8*>(w_ptr + (size_t)(g / 3) * w_step + (size_t)((3 * ph + g % 3) * 2 + s) * 64 * 8);
+      bw[g][s] = __builtin_bit_cast(hf8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (int)(w_wave + (unsigned)(g / 3) * w_step + (unsigned)((g % 3) * 2 + s) * 1024u), 0));
 #pragma unroll
   for (int xi = 0; xi < 6; ++xi) {
     produce4(raw0[0], As, xi, kocr_pow2(gc.e));

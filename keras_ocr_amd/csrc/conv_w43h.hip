@@ -714,17 +714,22 @@ __global__ __launch_bounds__(256) void conv_w43vh_kernel(W4Params p) {
 // CRAFT's slice1.3 (64 -> 64 at full resolution) and upconv3.conv.3.
 // ===================================================================================================
 // MODE 1 (round 5) = RAGGED, any H, W: see conv_w43vh_kernel (column bits in Geo::ok, masked stores).
-template <int POOL, int NP, int MODE = 0, int PF = 1>
-__global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
+// OCC = 2 (round 6, the fp16x2 default): TWO blocks per CU (two waves per SIMD, 256 registers each) -- one block's loads, transform
+// and epilogue run under the other's matrix products, and the other wave hides what in-order vmcnt exposes: a weight fragment is
+// fetched three MFMA groups ahead of its use and the raw pixels (HBM) are issued in between, so the wait for a fragment also
+// waits for the raw loads issued before it (profiles/r06_ab_notes.txt items 1, 8).  LDS 2 x 36 KB + coefficients: the epilogue
+// exchanges its partial output transforms in two halves of 32 KB through the free K-loop buffer instead of 64 KB behind it.
+template <int POOL, int NP, int MODE = 0, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void conv_w43rh_kernel(W4Params p) {
   static_assert(MODE == 0 || MODE == 1, "exact tiling or ragged");
-  static_assert(PF == 1 || PF == 2, "prefetch depth in channel groups");
-  constexpr int NBW = PF == 2 ? 9 : 3;  // weight fragments held: one (ky, point) row of three, or a whole channel group
+  constexpr int NBW = 3;  // weight fragments held: one (ky, point) row
   constexpr int PR = NP == 2 ? 3 : 1;
   constexpr int NROWS = 6, QPR = 16, KHS = QPR * 8, ROW_STRIDE = 2 * KHS, PLANE_R = NROWS * ROW_STRIDE;
   constexpr int BUF_R = 6 * NP * PLANE_R;  // one channel group: 36 KB (NP = 2)
   constexpr int TCOLS = QPR * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned short As[];
-  float* coef = reinterpret_cast<float*>(As + BUF_R + 4 * 16 * 64 * 8);  // behind the buffer and the exchange area: w4_stage_coef
+  // behind the buffer and the exchange area (OCC = 2: behind the two K-loop buffers): w4_stage_coef
+  float* coef = reinterpret_cast<float*>(OCC == 2 ? As + 2 * BUF_R : As + BUF_R + 4 * 16 * 64 * 8);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, ph = wave >> 1;  // cout half, point half (points 3 ph .. 3 ph + 2)
@@ -856,8 +861,8 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
       *reinterpret_cast<unsigned*>(dst) = __builtin_bit_cast(unsigned, hf2{(_Float16)V[0], (_Float16)V[1]});
     }
   };
-  v4f raw0[PF][6];
-  v2f raw1[PF][6];
+  v4f raw0[1][6];
+  v2f raw1[1][6];
 
   // ---- consumer state ------------------------------------------------------------------------------------------
   // weights through raw buffer loads (round 6, as conv_w43vh_kernel): one VGPR of lane offset, the (step, point, piece) offset a
@@ -894,13 +899,8 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
   // of the image it belongs to.  See conv_w43r_kernel for the a0 / a1 flip and the weight replacement.
   hf8 a0[2][NP], a1[2][NP];
   auto phase = [&](const unsigned short* bufc, unsigned short* bufn, int s0, int flip, float sk) __attribute__((always_inline)) {
-    // PF = 2: the raw pixels of TWO channel groups are in flight (register set `flip` is transformed now and refilled
-    // with the channel group after next but one), and a group's weight fragments are replaced by the NEXT channel
-    // group's right after their use -- every load is consumed at least nine MFMA groups after its issue.  vmcnt
-    // retires in order: with the weights only three groups ahead (PF = 1) a raw load had to be back within four
-    // groups of its issue, i.e. the loop ran at two exposed HBM latencies per channel group (profiles/r06_ab_notes.txt).
-    v4f(&r0)[6] = (PF == 2 && flip) ? raw0[PF - 1] : raw0[0];
-    v2f(&r1)[6] = (PF == 2 && flip) ? raw1[PF - 1] : raw1[0];
+    v4f(&r0)[6] = raw0[0];
+    v2f(&r1)[6] = raw1[0];
 #pragma unroll
     for (int g = 0; g < 9; ++g) {
       __builtin_amdgcn_sched_barrier(0);
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
           produce2(r1, bufn, c - 6, sk);
       }
       if (g < 8) {
-        mfma_grp(cur, pp, PF == 2 ? g : pp);
+        mfma_grp(cur, pp, pp);
         __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);  // the LDS fetches of the next group first
         // VALU per MFMA gap, in the scheduler's units (round 6: the ISA showed the five gaps of a group filled 7 / 7 / 0 / 0 / 0 --
         // the counts below are taken before instruction expansion, ~ 1.4 machine instructions each -- so three of six MFMAs ran
@@ -949,16 +949,16 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
         __syncthreads();  // the next channel group is complete in bufn, bufc is free
         load_a(nxt, bufn, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_grp(cur, pp, PF == 2 ? g : pp);
+        mfma_grp(cur, pp, pp);
       }
       __builtin_amdgcn_sched_barrier(0);
-      {  // this point's weights of the next step (PF = 2: of the same step of the next channel group)
-        int sn = PF == 2 ? s0 + 3 + ky : s0 + ky + 1;
+      {  // this point's weights of the next step
+        int sn = s0 + ky + 1;
         sn = sn >= ns ? sn - ns : sn;
         const unsigned wq = w_wave + (unsigned)sn * w_step;
 #pragma unroll
         for (int s = 0; s < NP; ++s)
-          bw[PF == 2 ? g : pp][s] = __builtin_bit_cast(hf8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (int)(wq + (unsigned)(pp * 2 + s) * 1024u), 0));
+          bw[pp][s] = __builtin_bit_cast(hf8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (int)(wq + (unsigned)(pp * 2 + s) * 1024u), 0));
       }
       if (g == 3) load_item0(r0);
     }
@@ -986,11 +986,6 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
   load_item0(raw0[0]);
   load_item1(raw1[0]);
   advance();  // channel group 1 loaded
-  if constexpr (PF == 2) {
-    load_item0(raw0[1]);
-    load_item1(raw1[1]);
-    advance();  // channel group 2 (of the next tile when Cin = 32: the launcher takes PF = 2 from Cin >= 64 on)
-  }
   __syncthreads();
   load_a(a0, As, 0, 0);
 
@@ -1052,11 +1047,13 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
             o[3] = W4_B3 * d34 + w;
           }
         };
+        if constexpr (OCC == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float o[4];
-          partial(std::integral_constant<int, 1 - PH>{}, r, o);
-          xch[(wave * 16 + r) * 64 + lane_e] = v4f{o[0], o[1], o[2], o[3]};
+          for (int r = 0; r < 16; ++r) {
+            float o[4];
+            partial(std::integral_constant<int, 1 - PH>{}, r, o);
+            xch[(wave * 16 + r) * 64 + lane_e] = v4f{o[0], o[1], o[2], o[3]};
+          }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1065,17 +1062,43 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) out[j][r] = o[j];
         }
+        if constexpr (OCC == 2) {  // the exchange in two halves of eight accumulator rows: 32 KB, inside the free buffer
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int r = 8 * h; r < 8 * h + 8; ++r) {
+              float o[4];
+              partial(std::integral_constant<int, 1 - PH>{}, r, o);
+              xch[(wave * 8 + r - 8 * h) * 64 + lane_e] = v4f{o[0], o[1], o[2], o[3]};
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 8 * h; r < 8 * h + 8; ++r) {
+              const v4f q = xch[((wave ^ 2) * 8 + r - 8 * h) * 64 + lane_e];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) out[j][r] += q[j];
+            }
+            __syncthreads();  // the second half / the next channel group is written into this buffer
+          }
+        }
       };
       if (ph == 0)
         halves(std::integral_constant<int, 0>{});
       else
         halves(std::integral_constant<int, 1>{});
-      __syncthreads();
+      if constexpr (OCC == 1) {
+        __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const v4f q = xch[((wave ^ 2) * 16 + r) * 64 + lane_e];
+        for (int r = 0; r < 16; ++r) {
+          const v4f q = xch[((wave ^ 2) * 16 + r) * 64 + lane_e];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out[j][r] = act(out[j][r] + q[j]);
+          for (int j = 0; j < 4; ++j) out[j][r] = act(out[j][r] + q[j]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) out[j][r] = act(out[j][r]);
       }
       if (has_post) {
 #pragma unroll
@@ -1083,7 +1106,7 @@ __global__ __launch_bounds__(256) void conv_w43rh_kernel(W4Params p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) out[j][r] = out[j][r] * qa + qb;
       }
-      __syncthreads();  // the next channel group is transformed into this buffer
+      if constexpr (OCC == 1) __syncthreads();  // the next channel group is transformed into this buffer
       int ocs4 = p.out_cs * 4;
       asm volatile("" : "+s"(ocs4));
       int pcs4 = p.pool_cs * 4;
@@ -1684,14 +1707,15 @@ int launch_w43vh(kocr_ctx* ctx, W4Params& p, bool fuse, int geo, int pieces, int
   return fuse ? w4vh_launch<1, 1, 1>(ctx, p) : w4vh_launch<0, 1, 1>(ctx, p);
 }
 
-template <int POOL, int NP, int MODE = 0, int PF = 1>
+template <int POOL, int NP, int MODE = 0, int OCC = 1>
 static int w4rh_launch(kocr_ctx* ctx, W4Params& p) {
-  constexpr int LDSR0 = 6 * NP * 6 * 256 * 2 + 4 * 16 * 64 * 16;  // one 36 KB buffer + the epilogue's 64 KB exchange area
+  // one 36 KB buffer + the epilogue's 64 KB exchange area (its head is the second buffer); OCC = 2: the two buffers only
+  constexpr int LDSR0 = OCC == 2 ? 2 * 6 * NP * 6 * 256 * 2 : 6 * NP * 6 * 256 * 2 + 4 * 16 * 64 * 16;
   const int LDSR = LDSR0 + 4 * p.Cout_pad * 4;                    // + the epilogue's coefficients
   static std::atomic<bool> attr_done[64];
   const int dev = ctx->device & 63;
   if (!attr_done[dev]) {
-    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43rh_kernel<POOL, NP, MODE, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSR0 + W4_COEF_BYTES_MAX));
+    KOCR_HIP(ctx, hipFuncSetAttribute((const void*)conv_w43rh_kernel<POOL, NP, MODE, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSR0 + W4_COEF_BYTES_MAX));
     attr_done[dev] = true;
   }
   static std::atomic<int> n_cus[64];
@@ -1701,13 +1725,14 @@ static int w4rh_launch(kocr_ctx* ctx, W4Params& p) {
     n_cus[dev] = prop.multiProcessorCount;
   }
   const int n_cu = n_cus[dev];
-  const int grid = p.total_tiles < n_cu ? p.total_tiles : n_cu;
+  const int slots = n_cu * OCC;
+  const int grid = p.total_tiles < slots ? p.total_tiles : slots;
   PROBE_RESET(ctx);
-  hipLaunchKernelGGL((conv_w43rh_kernel<POOL, NP, MODE, PF>), dim3(grid), dim3(256), LDSR, ctx->stream, p);
+  hipLaunchKernelGGL((conv_w43rh_kernel<POOL, NP, MODE, OCC>), dim3(grid), dim3(256), LDSR, ctx->stream, p);
   KOCR_HIP(ctx, hipGetLastError());
   {
     char what[80];
-    snprintf(what, sizeof what, "conv_w43rh<%d,%d,%d,pf%d> tiles %d steps %d", POOL, NP, MODE, PF, p.total_tiles, p.nsteps);
+    snprintf(what, sizeof what, "conv_w43rh<%d,%d,%d,occ%d> tiles %d steps %d", POOL, NP, MODE, OCC, p.total_tiles, p.nsteps);
     (void)what;
     PROBE_REPORT(ctx, what, grid);
   }
@@ -1717,14 +1742,10 @@ static int w4rh_launch(kocr_ctx* ctx, W4Params& p) {
 // the 64-cout row-reuse arrangement (4 x 64 tiles) in fp16 arithmetic: p as launch_conv_w43 filled it for
 // conv_w43r_kernel<POOL, 1>, with wgt = d_w4h, pre_a = d_pre_a_h and amax_in set
 int launch_w43rh(kocr_ctx* ctx, W4Params& p, bool fuse, int pieces, int mode) {
-  // PF = 2 (two channel groups of raw pixels in flight, weights a whole channel group ahead) needs the loads of a tile to
-  // reach into the NEXT tile only: Cin >= 64 (A/B against round 5's one-group prefetch: profiles/r06_ab_notes.txt item 1)
-  if (pieces == 2 && p.Cin >= 64) {
-    if (mode == 1) return fuse ? w4rh_launch<1, 2, 1, 2>(ctx, p) : w4rh_launch<0, 2, 1, 2>(ctx, p);
-    return fuse ? w4rh_launch<1, 2, 0, 2>(ctx, p) : w4rh_launch<0, 2, 0, 2>(ctx, p);
-  }
-  if (mode == 1) return fuse ? w4rh_launch<1, 2, 1>(ctx, p) : w4rh_launch<0, 2, 1>(ctx, p);
-  if (pieces == 2) return fuse ? w4rh_launch<1, 2>(ctx, p) : w4rh_launch<0, 2>(ctx, p);
+  // fp16x2: two 256-register blocks per CU (OCC = 2; A/B against one 512-register block with two channel groups of loads in
+  // flight: profiles/r06_ab_notes.txt items 1, 8)
+  if (mode == 1) return fuse ? w4rh_launch<1, 2, 1, 2>(ctx, p) : w4rh_launch<0, 2, 1, 2>(ctx, p);
+  if (pieces == 2) return fuse ? w4rh_launch<1, 2, 0, 2>(ctx, p) : w4rh_launch<0, 2, 0, 2>(ctx, p);
   return fuse ? w4rh_launch<1, 1>(ctx, p) : w4rh_launch<0, 1>(ctx, p);
 }
 

@@ -17,5 +17,9 @@ Pinning status (DESIGN.md section 4 has the full table):
     weights are installed nowhere in this image, so they cannot be executed; each is cross-checked against an
     INDEPENDENT statement of the same operation (scikit-image / scipy / Qhull / Pillow fixtures generated under the
     image's second interpreter by ``tests/golden/make_golden_3p.py``; ``torch.nn`` modules;
-    ``tests/test_thirdparty_crosscheck_cpu.py``).
+    ``tests/test_thirdparty_crosscheck_cpu.py``).  PARITY WITH THOSE LIBRARIES' OWN NUMERICS IS UNPINNED here;
+    ``tests/golden/make_golden_real.py`` is the one-command pin for a host that has them (the unmodified reference on this
+    repository's synthetic weights -> ``tests/golden/real_golden.npz``; ``tests/test_real_golden.py`` then holds this oracle and
+    the GPU path to it), and ``oracle.postproc.min_area_box_cv32`` restates cv2.minAreaRect's float32 rotating calipers next to
+    the exact rectangle the GPU reproduces, to measure what the difference costs (``scripts/minarearect_deviation.py``).
 """

@@ -44,7 +44,11 @@ constexpr int HC = 31, WC = 200, UNITS = 128, T = 50, DISCARD = 2;
 // the crop batch as a cell grid (Tensor::cellW): CN crops side by side per image; cell = (HC + 1) x 208 at full resolution
 // (one zero row on top, eight zero columns behind the crop), 16 x 104 and 8 x 52 after the two poolings.  208 CN, 104 CN and
 // 52 CN are multiples of 64: the grid tiles as 4 rows x 64 columns at every level.
+// CN = 16 cells per row; batches of at most 8 crops (Recognizer.recognize, a page with a few words) take 8 -- 208 * 8, 104 * 8 and
+// 52 * 8 are multiples of 64 / 64 / 32 as well -- so that a single crop convolves 8 cells, not 16.  A crop's result
+// does not depend on its cell or its neighbours (tests/test_cells_gpu.py), hence not on this choice.
 constexpr int CN = 16, CELL_W = 208;
+static inline int cells_per_row(int M) { return M <= 8 ? 8 : CN; }
 const int kFilters[7] = {64, 128, 256, 256, 512, 512, 512};
 
 struct Blob {
@@ -258,18 +262,19 @@ int crnn_forward(kocr_ctx* ctx, const float* d_crops, int M, int* d_labels, floa
   bool cells = true;
   for (int i = 2; i <= 7; ++i) cells = cells && w43_cells_ok(ctx, net->L["conv_" + std::to_string(i)]);
   if (cells) {
-    const int R = (M + CN - 1) / CN;
+    const int cn = cells_per_row(M);
+    const int R = (M + cn - 1) / cn;
     auto mkc = [&](int hc, int wc, int wv, int c, bool alloc, Tensor* t) -> int {
       t->N = R;
       t->H = hc;
-      t->W = CN * wc;
+      t->W = cn * wc;
       t->C = t->cs = c;
       t->co = 0;
       t->cellW = wc;
       t->cellWv = wv;
-      t->amax = ctx->amax_slots(R * CN);
+      t->amax = ctx->amax_slots(R * cn);
       if (!t->amax) KOCR_FAIL(ctx, KOCR_ECAPACITY, "kocr_crnn_forward: out of max-|x| slots");
-      t->p = alloc ? (float*)ctx->ws_alloc((size_t)R * hc * CN * wc * c * sizeof(float)) : nullptr;
+      t->p = alloc ? (float*)ctx->ws_alloc((size_t)R * hc * cn * wc * c * sizeof(float)) : nullptr;
       if (alloc && !t->p) KOCR_FAIL(ctx, KOCR_ENOMEM, "kocr_crnn_forward: workspace exhausted");
       return KOCR_OK;
     };

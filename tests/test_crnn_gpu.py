@@ -122,3 +122,14 @@ def test_non_default_builds_match_the_oracle(ctx, crnn_weights, stn, discard):
         ctx.crnn_set_rnn_steps_to_discard(2)
         ctx.load_crnn(crnn_weights)
     assert ctx.crnn_label_width() == 48
+
+
+def test_small_batches_take_a_narrower_cell_grid_with_identical_results(crnn_ctx):
+    """batches of <= 8 crops lay the crops out 8 cells per row instead of 16 (a single crop no longer convolves 16
+    cells).  A crop's result must not depend on that: the same crops in a batch of 3 (8 cells per row) and inside a batch of 12
+    (16 per row) give bit-identical probabilities."""
+    x = _crops(12, seed=900)
+    _, p12 = crnn_ctx.crnn_forward(x, return_probs=True)
+    _, p3 = crnn_ctx.crnn_forward(x[:3], return_probs=True)
+    _, p1 = crnn_ctx.crnn_forward(x[2:3], return_probs=True)
+    assert np.array_equal(p3, p12[:3]) and np.array_equal(p1[0], p12[2])

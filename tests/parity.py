@@ -2,7 +2,7 @@
 reasoning): count the heat-map pixels that fall on the other side of a getBoxes threshold, and require every
 oracle box no such pixel touches to be reproduced to 1e-3 px with the identical string.  The logic itself lives in
 oracle/parity.py (bench.py's parity leg uses it too)."""
-from oracle.parity import flips, page_report  # noqa: F401  (re-exported)
+from oracle.parity import flips, page_report, heat_tolerance, heat_within_tolerance  # noqa: F401  (re-exported)
 
 
 def compare_page(got, want, flipped, scale, heat_shape, report):

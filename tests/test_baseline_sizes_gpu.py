@@ -20,11 +20,13 @@ import numpy as np
 import pytest
 
 from tests import synth
-from tests.parity import flips as _flips, compare_page as _compare_page
+from tests.parity import flips as _flips, compare_page as _compare_page, heat_tolerance, heat_within_tolerance
 
 pytestmark = pytest.mark.gpu
 
-HEAT_TOL = 5e-5     # stated fp32 tolerance on heat-maps (measured ~2e-5; the reference's own Keras-vs-PyTorch bar is 1.5e-4)
+HEAT_TOL = 5e-5     # stated fp32 tolerance on heat-maps of magnitude O(1) (measured ~2e-5; the reference's own Keras-vs-PyTorch bar is 1.5e-4)
+# full-size pages with the calibrated head (maps of magnitude ~ 4.3): oracle.parity.heat_tolerance -- 1.5e-5 per unit of max |heat|
+# (6.5e-5), never below 5e-5, plus an rms bound; the maximum alone is a noisy statistic (see its docstring)
 PROB_TOL = 1e-4  # measured ~4e-5
 MARGIN = 1e-3
 FLIP_BUDGET = 2e-5  # fraction of heat-map pixels allowed to sit on the other side of a threshold
@@ -105,7 +107,7 @@ def test_cfg4_pages_from_a_32_batch_vs_oracle(pipe, ctx, calibrated, crnn_weight
         assert np.array_equal(ctx.resize_pad(pages[i][None], (1536, 1536)), big)
         h_ref = ocraft.detector_predict(calibrated, big)[0]
         h_gpu = ctx.craft_forward(big)[0]
-        assert float(np.abs(h_gpu - h_ref).max()) <= HEAT_TOL
+        assert heat_within_tolerance(h_gpu, h_ref), (float(np.abs(h_gpu - h_ref).max()), heat_tolerance(h_ref))
         _compare_page(got[i], want, _flips(h_gpu, h_ref), 2.0, h_ref.shape[:2], report)
     print("cfg4:", report)
     assert report["boxes_equal"] >= 20
@@ -128,7 +130,7 @@ def test_cfg5_one_1536_page_scale3_vs_oracle(ctx, calibrated, crnn_weights):
     assert big.shape[:2] == (2048, 2048) and abs(sc - 2048 / 1536) < 1e-12
     h_ref = ocraft.detector_predict(calibrated, big[None])[0]
     h_gpu = ctx.craft_forward(big[None])[0]
-    assert float(np.abs(h_gpu - h_ref).max()) <= HEAT_TOL
+    assert heat_within_tolerance(h_gpu, h_ref), (float(np.abs(h_gpu - h_ref).max()), heat_tolerance(h_ref))
     report = {"boxes_equal": 0, "boxes_moved_by_flips": 0, "flipped_pixels": 0, "pixels": 0}
     _compare_page(got, want, _flips(h_gpu, h_ref), sc, h_ref.shape[:2], report)
     print("cfg5:", report)

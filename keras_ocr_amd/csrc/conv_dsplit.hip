@@ -707,8 +707,6 @@ int launch_conv_dsplit(kocr_ctx* ctx, const ConvLayer& L, const Tensor& in, cons
   if (up) {
     // exactly 2x up-sampling with W % 4 == 0: the shared-tap epilogue (UP = 2)
     const bool no_up2 = !ctx->sw.up2x;
-    // KOCR_DS_PAIR: 0 = one 512-thread block per CU everywhere (round 5), 1 = the 64-cout layers on two 256-thread blocks per
-    // CU, 2 (default) = every up-sampling 1x1 (A/B: profiles/r06_ab_notes.txt)
     if (!no_up2 && in.H == 2 * up->H && in.W == 2 * up->W && in.W % 4 == 0) {
       if (line_pairs) return wcls == 128 ? ds_launch<1, 4, 0, 2, 1>(ctx, p, M) : ds_launch<2, 2, 0, 2, 1>(ctx, p, M);
       return wcls == 128 ? ds_launch<1, 4, 0, 2>(ctx, p, M) : ds_launch<2, 2, 0, 2>(ctx, p, M);

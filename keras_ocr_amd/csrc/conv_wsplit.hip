@@ -14,14 +14,14 @@
 // max error 1.56e-7 / rms 3.4e-8 of sum|ab| against 1.76e-7 / 2.9e-8 for the fp32 MFMA (== fmaf
 // chain) — the same accuracy class, which tests/test_conv_gpu.py asserts against an fp64 oracle.
 //
-// Same operator and Winograd algebra as conv_wino.hip (keras Conv2D 3x3 'same' + folded BN + ReLU,
+// 1-D Winograd F(2,3) along image rows (keras Conv2D 3x3 'same' + folded BN + ReLU,
 // detection.py:87-103): for the output pair (x0, x0+1) of a row and every (ky, c)
 //     d_i = in[y+ky-1][x0-1+i][c],   V = (d0-d2, d1+d2, d2-d1, d1-d3),   U = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)
 //     M_xi[pair][o] = sum_{ky,c} V_xi U_xi,   out[x0] = M0+M1+M2,   out[x0+1] = M1-M2-M3.
 //
 // Block = 512 threads, persistent (one per CU, walking over tiles): waves 4-7 PRODUCE -- thread (pair,
 // channel quad) loads the four raw pixels through raw buffer loads (out-of-range offset = zero padding),
-// forms V in fp32 exactly as conv_wino.hip does, splits and writes bf16 operands to LDS in MFMA A-operand
+// forms V in fp32, splits and writes bf16 operands to LDS in MFMA A-operand
 // order As[buf][xi][piece][M-tile][k half][32 pairs][8 ch] (a 32x32x16 A fetch is two contiguous 512-B
 // runs, bank-conflict free) -- and waves 0-3 CONSUME: wave (wm, wn) owns 64 pairs x 32 output channels
 // for all four points (128 accumulator VGPRs), so the inverse transform is register-only.  Tile = 128 px x

@@ -362,3 +362,30 @@ def test_capacity_overflow_costs_no_second_detector_forward(pipe, ctx, cap, max_
     # the results are still resident: a second fetch into even larger buffers gives the same answer
     res = ctx.pipeline_device_results()
     assert res["n"] == 3 and res["m"] == sum(n_boxes) and res["cap"] >= max(n_boxes)
+
+
+def test_resident_results_and_build_parameter_error_paths(pipe, ctx):
+    """kocr_pipeline_results: buffers smaller than the resident results -> KOCR_ECAPACITY naming the sizes, nothing written past
+    them; no resident result -> KOCR_EINVAL.  kocr_crnn_set_rnn_steps_to_discard: out of range -> KOCR_EINVAL."""
+    import ctypes
+    import keras_ocr_amd
+    from keras_ocr_amd._lib import _ptr
+
+    pages = np.stack([synth.text_page(96, 128, 5, seed=70 + i) for i in range(2)])
+    boxes, labels = ctx.pipeline(list(pages), [96] * 2, [128] * 2, [192] * 2, [256] * 2, 192, 256)
+    res = ctx.pipeline_device_results()
+    lib, h = ctx._lib, ctx._h  # pylint: disable=protected-access
+    small_b = np.zeros((2, 1, 4, 2), np.float32)
+    small_l = np.full((1, 48), -1, np.int32)
+    assert res["cap"] >= 1 and res["m"] > 1
+    rc = lib.kocr_pipeline_results(h, _ptr(small_b), 1 if res["cap"] > 1 else 0, _ptr(small_l), 1)
+    assert rc == -4 and not small_b.any() and (small_l == -1).all()
+    big_b = np.zeros((2, res["cap"] + 3, 4, 2), np.float32)
+    big_l = np.full((res["m"] + 5, 48), -1, np.int32)
+    assert lib.kocr_pipeline_results(h, _ptr(big_b), res["cap"] + 3, _ptr(big_l), res["m"] + 5) == 0
+    assert all(np.array_equal(big_b[i, :len(b)], b) for i, b in enumerate(boxes)) and np.array_equal(big_l[:res["m"]], labels)
+    ctx.resize_pad(pages, (256, 192))                      # any call that processes images invalidates the resident results
+    assert lib.kocr_pipeline_results(h, _ptr(big_b), res["cap"] + 3, _ptr(big_l), res["m"] + 5) == -1   # KOCR_EINVAL
+    with pytest.raises(keras_ocr_amd.KocrError):
+        ctx.crnn_set_rnn_steps_to_discard(50)
+    assert ctx.crnn_label_width() == 48
